@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- DoF-updates/s of one Newmark step (Newton x (assembly + CG) + Newmark updates) of the
+neo-Hookean solver on a synthetic 3D Q2 block (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one full Newmark step on the resident mesh under the ramped constant interface traction
+(0,-2e3,0) Pa (ramp over the first 10 steps).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def _pkg():
+    name = "dealii_adapter_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "dealii-adapter_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def spmv_bytes(nnodes, nnzb, dim):
+    """algorithmic HBM bytes of one block-CSR SpMV launch: every stored value and block column index once,
+    block row pointers, x read once, y written once (the fused dot's second read of p is not credited)"""
+    n = nnodes * dim
+    return 8 * nnzb * dim * dim + 4 * nnzb + 4 * (nnodes + 1) + 8 * n + 8 * n
+
+
+def spmv_bytes_scalar_csr(nnodes, nnzb, dim):
+    """SURVEY.md section 8(d) figure for a scalar CSR of the same matrix: 12*nnz + 4*(N+1) + 16*N"""
+    n = nnodes * dim
+    return 12 * nnzb * dim * dim + 4 * (n + 1) + 16 * n
+
+
+def cpu_baseline(n_cells_side, threads):
+    """one Newmark step of the CPU oracle (restatement of the reference algorithm: WorkStream-style
+    assembly over all host threads, CG + SSOR(0.65)) on a bounded sample of the same workload"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    O.lib().orc_set_threads(threads)
+    d = O.make_desc(dim=3, degree=2, reps=(n_cells_side,) * 3)
+    P = O.Problem(d)
+    P.set_interface_traction((0.0, -2e2, 0.0))  # first ramp step
+    t0 = time.perf_counter()
+    rc, info = P.newmark_step(O.SOLVER_CG_SSOR, tol_lin=1e-6, max_it_mult=1.0)
+    dt = time.perf_counter() - t0
+    assert rc == 0
+    return {
+        "value": P.n / dt,
+        "unit": "DoF-updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "1 Newmark step, 3D Q2 block %d^3 cells (%d DoFs), CG+SSOR(0.65) tol 1e-6, %d Newton its, "
+                  "%d CG its, assembly %.1fs + solve %.1fs; restatement of the reference algorithm, not the "
+                  "deal.II binary" % (n_cells_side, P.n, info.newton_iterations, info.lin_its_total,
+                                      info.t_assemble, info.t_solve),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--cells", type=int, default=59, help="cells per side of the Q2 block (59 -> 5,055,477 DoFs)")
+    ap.add_argument("--tol-lin", type=float, default=1e-6)
+    ap.add_argument("--cpu-cells", type=int, default=16, help="cells per side of the CPU-baseline sample (0: skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
+                  file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    M = _pkg()
+    n = args.cells
+    G = M.Context(dim=3, degree=2, reps=(n, n, n), lo=(0, 0, 0), hi=(1, 1, 1), mu=0.5e6, nu=0.4, rho=1000.0,
+                  beta=0.25, gamma=0.5, delta_t=0.005, device=local_rank)
+    nnzb = G.nnz // 9
+    traction = (0.0, -2e3, 0.0)
+
+    def one_step(k):
+        ramp = min(1.0, (k + 1) / 10.0)
+        G.set_interface_traction(tuple(ramp * t for t in traction))
+        _, info = G.newmark_step(tol_lin=args.tol_lin, max_it_mult=1.0)
+        return info
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    G.set_profiling(True)
+    G.reset_timings()
+    barrier()
+    t0 = time.perf_counter()
+    newton = cg_its = assemblies = 0
+    for k in range(args.steps):
+        info = one_step(args.warmup + k)
+        newton += info.newton_iterations
+        cg_its += info.lin_its_total
+        assemblies += info.assemblies
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = G.timings()
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        spmv_ms, spmv_n = tm["spmv"]
+        spmv_avg_ms = spmv_ms / max(spmv_n, 1)
+        bytes_bsr = spmv_bytes(G.nnodes, nnzb, 3)
+        achieved = bytes_bsr / (spmv_avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        out = {
+            "metric": "DoF-updates/sec per Newmark step (assembly+CG), 3D Q2 ~5M DoFs",
+            "value": world * G.n * args.steps / elapsed if world > 1 else G.n * args.steps / elapsed,
+            "unit": "DoF-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %d^3 cells, %d DoFs, %d nnz, Newton+Newmark, "
+                            "Jacobi-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
+                            % (n, G.n, G.nnz, args.tol_lin),
+                "n_dofs": G.n,
+                "nnz": G.nnz,
+                "decomposition": "single GPU" if world == 1 else "independent replicas per GPU (domain "
+                                 "decomposition not yet wired into bench)",
+                "newton_iterations_per_step": newton / args.steps,
+                "cg_iterations_per_step": cg_its / args.steps,
+                "assemblies_per_step": assemblies / args.steps,
+                "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
+                "ms_cg_per_step": tm["cg_total"][0] / args.steps,
+                "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
+            },
+            "roofline": {
+                "kernel": "bsr_spmv<3> (CG matrix-vector product)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "bytes_per_launch": bytes_bsr,
+                "launches_timed": spmv_n,
+                "avg_launch_ms": spmv_avg_ms,
+                "achieved_scalar_csr_equivalent": spmv_bytes_scalar_csr(G.nnodes, nnzb, 3) / (spmv_avg_ms * 1e-3) / 1e9
+                if spmv_n else 0.0,
+            },
+        }
+        if args.cpu_cells > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_cells, os.cpu_count() or 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

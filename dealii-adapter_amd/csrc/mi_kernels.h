@@ -1,0 +1,77 @@
+// mi_kernels.h -- kernel argument blocks and launchers shared by mi_kernels.hip and mi_ctx.cpp
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi
+{
+  // arguments of assemble_cells / neumann_faces (device pointers unless noted)
+  struct AsmParams
+  {
+    const int32_t  *conn;   // [ncells][npc]       colour-sorted
+    const double   *cverts; // [ncells][2^dim][dim]
+    const uint16_t *off;    // [ncells][npc][npc]
+    const int32_t  *rowptr; // [nnodes+1] block rows
+    const uint8_t  *cmask;  // [nnodes]
+    const double   *tab1d;  // N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1]
+    const double   *u, *du, *acc, *stress;
+    double         *rhs;
+    double         *vals;   // block-CSR values [nnzb][dim*dim]
+    double          mu, kappa, rho, alpha1;
+    double          body[3];
+    int64_t         cell_begin;
+    int32_t         cell_count;
+  };
+
+  struct SpmvParams
+  {
+    const int32_t *rowptr;
+    const int32_t *col;
+    const double  *vals;
+    const double  *x;
+    double        *y;
+    const double  *dotv;     // optional: partials of y . dotv
+    double        *partials; // [grid]
+    const int32_t *done;     // optional early-exit flag
+    int64_t        row0, nrows;
+  };
+
+  struct CgParams
+  {
+    double       *x, *r, *p, *q;
+    const double *dinv;
+    double       *part_rr, *part_rz, *part_pq;
+    double       *sc;    // [8] device scalars
+    int32_t      *flags; // [2] done, iterations
+    int64_t       n;
+    int32_t       npart, npart_pq;
+  };
+
+  struct NewmarkParams
+  {
+    double *u, *u_old, *v, *v_old, *a, *a_old;
+    const double *du;
+    double  alpha1, alpha2, alpha3, alpha4, alpha5, alpha6;
+    int64_t n;
+  };
+
+  int  launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s);
+  int  launch_neumann_faces(int dim, int degree, const AsmParams &p, const int32_t *faces, int face_begin,
+                            int face_count, hipStream_t s);
+  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s);
+  void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s);
+  void launch_cg_update_xr(const CgParams &c, int it, int grid, hipStream_t s);
+  void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s);
+  void launch_cg_set_tolerance(const CgParams &c, const double *part_bb, double rel_tol, hipStream_t s);
+  void launch_cg_final_check(const CgParams &c, int it, hipStream_t s);
+  void launch_extract_dinv(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
+                           hipStream_t s);
+  void launch_masked_norm(int dim, const double *v, const uint8_t *cmask, int64_t n, double *part, int grid,
+                          double *out, hipStream_t s);
+  void launch_zero_constrained(int dim, double *x, const uint8_t *cmask, int64_t n, hipStream_t s);
+  void launch_newmark_acceleration(const NewmarkParams &p, hipStream_t s);
+  void launch_newmark_finish(const NewmarkParams &p, hipStream_t s);
+  void launch_vec_add(double *y, const double *x, int64_t n, hipStream_t s);
+  void launch_gather_nodes(int dim, const double *v, const int32_t *nodes, int n, double *out, hipStream_t s);
+  void launch_scatter_nodes(int dim, double *v, const int32_t *nodes, int n, const double *in, hipStream_t s);
+} // namespace mi

@@ -1,0 +1,1167 @@
+// mi_kernels.hip -- hand-written gfx950 kernels of the hot path (fp64, HBM/LDS/VALU; no MFMA by design).
+//
+//   assemble_cells   : per-cell tangent + residual of the neo-Hookean Newmark problem, one workgroup per
+//                      cell, scattered into the block-CSR by graph colouring
+//                      (nonlinear_elasticity.cc:872-1036 + :760-774; maths restated in DESIGN.md section 4)
+//   neumann_faces    : interface traction with area pull-back incl. the reference's cell-QP quirk (:791-859)
+//   bsr_spmv         : y = K x on dim x dim blocks, one wavefront per block row, fused dot product
+//   cg_* / vec_*     : fused CG vector updates with deterministic two-level reductions (:1153-1191)
+//   newmark_*        : Newmark predictor/corrector vector updates (:592-622)
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mi_kernels.h"
+
+namespace mi
+{
+  __device__ __forceinline__ int64_t imin64(int64_t a, int64_t b)
+  {
+    return a < b ? a : b;
+  }
+
+  // ------------------------------------------------------------------ reductions
+  __device__ __forceinline__ double wave_sum(double v)
+  {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+      v += __shfl_xor(v, o, 64);
+    return v;
+  }
+
+  // sum over the workgroup, result valid in every thread; s_red needs blockDim/64 doubles
+  template <int NT>
+  __device__ __forceinline__ double block_sum(double v, double *s_red)
+  {
+    constexpr int NW = NT / 64;
+    v                = wave_sum(v);
+    if constexpr (NW == 1)
+      return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+      s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      t += s_red[w];
+    return t;
+  }
+
+  // every workgroup reduces the same partials in the same order -> identical totals everywhere
+  template <int NT>
+  __device__ __forceinline__ double reduce_partials(const double *__restrict__ part, int n, double *s_red)
+  {
+    double s = 0;
+    for (int i = threadIdx.x; i < n; i += NT)
+      s += part[i];
+    return block_sum<NT>(s, s_red);
+  }
+
+  // ------------------------------------------------------------------ element traits
+  template <int DIM, int P>
+  struct Elem
+  {
+    static constexpr int NP1  = P + 1;
+    static constexpr int NPC  = (DIM == 2) ? NP1 * NP1 : NP1 * NP1 * NP1;
+    static constexpr int NQ1  = P + 2; // qf_cell(p+2), nonlinear_elasticity.cc:74
+    static constexpr int NQ   = (DIM == 2) ? NQ1 * NQ1 : NQ1 * NQ1 * NQ1;
+    static constexpr int NQF  = (DIM == 2) ? NQ1 : NQ1 * NQ1;
+    static constexpr int NV   = 1 << DIM;
+    static constexpr int DD   = DIM * DIM;
+    static constexpr int NT2  = (NPC + 1) / 2;        // node pairs along one side of the 2x2-block tile grid
+    static constexpr int NPCP = 2 * NT2;              // node count padded to even
+    static constexpr int NTILES = NT2 * (NT2 + 1) / 2; // lower triangle of the tile grid
+  };
+
+  constexpr int RQ = 32; // doubles per quadrature-point record in LDS
+  constexpr int RN = 10; // doubles per (qp,node) record: g[3], m[3], v[3], n
+  // quadrature-point record layout
+  constexpr int Q_M    = 0;  // 9: Jinv * Finv  (unit gradient -> spatial gradient)
+  constexpr int Q_TAU  = 9;  // 6: tau      xx yy zz xy xz yz
+  constexpr int Q_TISO = 15; // 6: tau_iso
+  constexpr int Q_W    = 21; // JxW
+  constexpr int Q_WCII = 22; // JxW * c_II
+  constexpr int Q_CS2  = 23; // c_S / 2
+  constexpr int Q_SQN  = 24; // sqrt(alpha1 rho JxW)
+  constexpr int Q_NINV = 25; // 1 / Q_SQN (0 if rho == 0)
+  constexpr int Q_FACC = 26; // 3: rho JxW (acc - b)
+
+  __device__ __forceinline__ double det3x3(const double *A)
+  {
+    return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+  }
+  __device__ __forceinline__ void inv3x3(const double *A, double det, double *B)
+  {
+    const double r = 1.0 / det;
+    B[0]           = (A[4] * A[8] - A[5] * A[7]) * r;
+    B[1]           = (A[2] * A[7] - A[1] * A[8]) * r;
+    B[2]           = (A[1] * A[5] - A[2] * A[4]) * r;
+    B[3]           = (A[5] * A[6] - A[3] * A[8]) * r;
+    B[4]           = (A[0] * A[8] - A[2] * A[6]) * r;
+    B[5]           = (A[2] * A[3] - A[0] * A[5]) * r;
+    B[6]           = (A[3] * A[7] - A[4] * A[6]) * r;
+    B[7]           = (A[1] * A[6] - A[0] * A[7]) * r;
+    B[8]           = (A[0] * A[4] - A[1] * A[3]) * r;
+  }
+
+  // 3x3 (row-major, embedded: for DIM==2 the [2][2] entry is 1 and off entries 0) geometry Jacobian of the
+  // d-linear cell map at unit point xi:  Jm[i][j] = dX_i / dxi_j
+  template <int DIM>
+  __device__ __forceinline__ void q1_jacobian(const double *__restrict__ verts, const double *xi, double *Jm)
+  {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      Jm[k] = 0.0;
+    if constexpr (DIM == 2)
+      Jm[8] = 1.0;
+#pragma unroll
+    for (int v = 0; v < (1 << DIM); ++v)
+      {
+        double f[3], s[3];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          {
+            const bool hi = (v >> d) & 1;
+            f[d]          = hi ? xi[d] : 1.0 - xi[d];
+            s[d]          = hi ? 1.0 : -1.0;
+          }
+#pragma unroll
+        for (int j = 0; j < DIM; ++j)
+          {
+            double g = s[j];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d)
+              if (d != j)
+                g *= f[d];
+#pragma unroll
+            for (int i = 0; i < DIM; ++i)
+              Jm[i * 3 + j] += verts[v * DIM + i] * g;
+          }
+      }
+  }
+
+  // unit-cell value and gradient of cell shape function a at cell quadrature point q from the 1D tables
+  template <int DIM, int P>
+  __device__ __forceinline__ void shape_at_qp(const double *__restrict__ sN1, const double *__restrict__ sdN1, int q,
+                                              int a, double &N, double *dN)
+  {
+    using E = Elem<DIM, P>;
+    int qi[3], ai[3];
+    qi[0] = q % E::NQ1;
+    qi[1] = (q / E::NQ1) % E::NQ1;
+    qi[2] = (DIM == 3) ? q / (E::NQ1 * E::NQ1) : 0;
+    ai[0] = a % E::NP1;
+    ai[1] = (a / E::NP1) % E::NP1;
+    ai[2] = (DIM == 3) ? a / (E::NP1 * E::NP1) : 0;
+    double n[3], d[3];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k)
+      {
+        n[k] = sN1[qi[k] * E::NP1 + ai[k]];
+        d[k] = sdN1[qi[k] * E::NP1 + ai[k]];
+      }
+    if constexpr (DIM == 2)
+      {
+        N     = n[0] * n[1];
+        dN[0] = d[0] * n[1];
+        dN[1] = n[0] * d[1];
+        dN[2] = 0.0;
+      }
+    else
+      {
+        N     = n[0] * n[1] * n[2];
+        dN[0] = d[0] * n[1] * n[2];
+        dN[1] = n[0] * d[1] * n[2];
+        dN[2] = n[0] * n[1] * d[2];
+      }
+  }
+
+  // Kinematics + compressible neo-Hookean response at one quadrature point
+  // (nonlinear_elasticity.cc:927-934, compressible_neo_hook_material.h:17-138 in closed form):
+  //   F = I + Grad u, J = det F, b_bar = J^(-2/d) F F^T, tau_bar = mu b_bar,
+  //   tau_iso = dev(tau_bar), tau = tau_iso + kappa/2 (J^2-1) I,
+  //   c_II = kappa J^2 - 2/d^2 tr(tau_bar),  c_S = -kappa (J^2-1) + 2/d tr(tau_bar)
+  // gu is the 3x3-embedded displacement gradient w.r.t. reference coordinates.
+  template <int DIM>
+  __device__ __forceinline__ void neo_hooke_qp(const double *gu, double mu, double kappa, double *Finv, double &J,
+                                               double *tau, double *tiso, double &cII, double &cS)
+  {
+    double F[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      F[k] = gu[k];
+    F[0] += 1.0;
+    F[4] += 1.0;
+    F[8] += 1.0; // DIM==2: gu[8]==0 -> F33 = 1 (embedding keeps det and inverse of the 2x2 part)
+    J = det3x3(F);
+    inv3x3(F, J, Finv);
+    const double Jm = (DIM == 3) ? 1.0 / (cbrt(J) * cbrt(J)) : 1.0 / J; // J^(-2/d)
+    double       b[6];                                                  // xx yy zz xy xz yz
+    b[0]            = F[0] * F[0] + F[1] * F[1] + (DIM == 3 ? F[2] * F[2] : 0.0);
+    b[1]            = F[3] * F[3] + F[4] * F[4] + (DIM == 3 ? F[5] * F[5] : 0.0);
+    b[2]            = (DIM == 3) ? F[6] * F[6] + F[7] * F[7] + F[8] * F[8] : 0.0;
+    b[3]            = F[0] * F[3] + F[1] * F[4] + (DIM == 3 ? F[2] * F[5] : 0.0);
+    b[4]            = (DIM == 3) ? F[0] * F[6] + F[1] * F[7] + F[2] * F[8] : 0.0;
+    b[5]            = (DIM == 3) ? F[3] * F[6] + F[4] * F[7] + F[5] * F[8] : 0.0;
+    const double s  = mu * Jm;
+    const double tr = s * (b[0] + b[1] + b[2]);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      tiso[k] = s * b[k];
+    tiso[0] -= tr / DIM;
+    tiso[1] -= tr / DIM;
+    if constexpr (DIM == 3)
+      tiso[2] -= tr / DIM;
+    const double pv = 0.5 * kappa * (J * J - 1.0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+      tau[k] = tiso[k];
+    tau[0] += pv;
+    tau[1] += pv;
+    if constexpr (DIM == 3)
+      tau[2] += pv;
+    cII = kappa * J * J - (2.0 / (DIM * DIM)) * tr;
+    cS  = -kappa * (J * J - 1.0) + (2.0 / DIM) * tr;
+  }
+
+  __device__ __forceinline__ void sym_mul(const double *S, const double *g, double *out)
+  {
+    out[0] = S[0] * g[0] + S[3] * g[1] + S[4] * g[2];
+    out[1] = S[3] * g[0] + S[1] * g[1] + S[5] * g[2];
+    out[2] = S[4] * g[0] + S[5] * g[1] + S[2] * g[2];
+  }
+
+  // ------------------------------------------------------------------ cell assembly
+  // One workgroup per cell of the current colour.  Threads are (tile, qslot): a tile is a 2x2 group of
+  // node-pair blocks in the lower triangle of the element tangent, kept in registers; the QSPLIT lanes of a
+  // tile split the quadrature points and are summed by wave shuffles at the end.
+  //   phase A: per-QP kinematics/material records -> LDS (4 lanes per QP)
+  //   per chunk of QC points: phase B (qp,node) records g, m, v, n -> LDS; main loop; residual
+  //   epilogue: read-modify-write of the cell's blocks into the global block-CSR (colouring => race free)
+  template <int DIM, int P, int QSPLIT, int NT, int QC>
+  __global__ __launch_bounds__(NT) void assemble_cells(AsmParams prm)
+  {
+    using E = Elem<DIM, P>;
+    constexpr int NPC = E::NPC, NPCP = E::NPCP, NQ = E::NQ, NQ1 = E::NQ1, NP1 = E::NP1, DD = E::DD, NV = E::NV;
+    static_assert(NQ % QC == 0, "chunk must divide the number of quadrature points");
+    static_assert(E::NTILES * QSPLIT <= NT, "not enough threads for the tile grid");
+    static_assert(NPC * DIM <= NT, "residual needs one thread per local dof");
+
+    __shared__ double s_N1[NQ1 * NP1], s_dN1[NQ1 * NP1], s_qw[NQ1], s_qx[NQ1];
+    __shared__ double s_u[NPC * 3], s_a[NPC * 3], s_verts[NV * DIM];
+    __shared__ int    s_conn[NPC];
+    __shared__ __attribute__((aligned(16))) double s_qp[NQ * RQ];
+    __shared__ __attribute__((aligned(16))) double s_nd[QC * NPCP * RN];
+
+    const int     tid  = threadIdx.x;
+    const int64_t cell = prm.cell_begin + blockIdx.x;
+
+    // ---- stage tables, connectivity, vertices, gathered u_total and acceleration
+    for (int i = tid; i < NQ1 * NP1; i += NT)
+      {
+        s_N1[i]  = prm.tab1d[i];
+        s_dN1[i] = prm.tab1d[NQ1 * NP1 + i];
+      }
+    if (tid < NQ1)
+      {
+        s_qw[tid] = prm.tab1d[2 * NQ1 * NP1 + tid];
+        s_qx[tid] = prm.tab1d[2 * NQ1 * NP1 + NQ1 + tid];
+      }
+    if (tid < NPC)
+      s_conn[tid] = prm.conn[cell * NPC + tid];
+    if (tid < NV * DIM)
+      s_verts[tid] = prm.cverts[cell * (NV * DIM) + tid];
+    for (int i = tid; i < QC * NPCP * RN; i += NT)
+      s_nd[i] = 0.0; // the padding node stays zero for the whole kernel
+    __syncthreads();
+    for (int i = tid; i < NPC * 3; i += NT)
+      {
+        const int a = i / 3, c = i - a * 3;
+        double    uv = 0.0, av = 0.0;
+        if (c < DIM)
+          {
+            const int64_t g = int64_t(s_conn[a]) * DIM + c;
+            uv              = prm.u[g] + prm.du[g]; // get_total_solution, :580-588
+            av              = prm.acc[g];
+          }
+        s_u[i] = uv;
+        s_a[i] = av;
+      }
+    __syncthreads();
+
+    // ---- phase A: quadrature-point records, 4 lanes per point
+    for (int task = tid; task < NQ * 4; task += NT)
+      {
+        const int q = task >> 2, part = task & 3;
+        double    gxi[9], acc[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          gxi[k] = 0.0;
+        acc[0] = acc[1] = acc[2] = 0.0;
+        for (int a = part; a < NPC; a += 4)
+          {
+            double N, dN[3];
+            shape_at_qp<DIM, P>(s_N1, s_dN1, q, a, N, dN);
+#pragma unroll
+            for (int i = 0; i < DIM; ++i)
+              {
+                const double ui = s_u[a * 3 + i];
+#pragma unroll
+                for (int j = 0; j < DIM; ++j)
+                  gxi[i * 3 + j] += ui * dN[j];
+                acc[i] += s_a[a * 3 + i] * N;
+              }
+          }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          {
+            gxi[k] += __shfl_xor(gxi[k], 1, 64);
+            gxi[k] += __shfl_xor(gxi[k], 2, 64);
+          }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          {
+            acc[k] += __shfl_xor(acc[k], 1, 64);
+            acc[k] += __shfl_xor(acc[k], 2, 64);
+          }
+        // geometry of the d-linear map at this point
+        double xi[3], wq = 1.0;
+        {
+          int qi[3] = {q % NQ1, (q / NQ1) % NQ1, (DIM == 3) ? q / (NQ1 * NQ1) : 0};
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            {
+              xi[d] = s_qx[qi[d]];
+              wq *= s_qw[qi[d]];
+            }
+        }
+        double Jm[9], Ji[9];
+        q1_jacobian<DIM>(s_verts, xi, Jm);
+        const double detJ = det3x3(Jm);
+        inv3x3(Jm, detJ, Ji);
+        // Grad_X u = grad_xi u * Jinv
+        double gu[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            gu[i * 3 + j] = (i < DIM && j < DIM) ? gxi[i * 3 + 0] * Ji[0 * 3 + j] + gxi[i * 3 + 1] * Ji[1 * 3 + j] +
+                                                     (DIM == 3 ? gxi[i * 3 + 2] * Ji[2 * 3 + j] : 0.0) :
+                                                   0.0;
+        double Finv[9], J, tau[6], tiso[6], cII, cS;
+        neo_hooke_qp<DIM>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS);
+        if (part == 0)
+          {
+            double *r = &s_qp[q * RQ];
+            // M = Jinv * Finv
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+                r[Q_M + i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] +
+                                     Ji[i * 3 + 2] * Finv[2 * 3 + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+              {
+                r[Q_TAU + k]  = tau[k];
+                r[Q_TISO + k] = tiso[k];
+              }
+            const double w   = detJ * wq; // JxW of the reference configuration
+            const double sqn = sqrt(prm.alpha1 * prm.rho * w);
+            r[Q_W]           = w;
+            r[Q_WCII]        = w * cII;
+            r[Q_CS2]         = 0.5 * cS;
+            r[Q_SQN]         = sqn;
+            r[Q_NINV]        = sqn > 0.0 ? 1.0 / sqn : 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              r[Q_FACC + i] = prm.rho * w * (acc[i] - prm.body[i]);
+          }
+      }
+    __syncthreads();
+
+    // ---- tile of this thread
+    const int  tile   = tid / QSPLIT, qslot = tid % QSPLIT;
+    const bool active = tile < E::NTILES;
+    int        ta = 0, tb = 0;
+    if (active)
+      {
+        ta = int((sqrtf(8.0f * float(tile) + 1.0f) - 1.0f) * 0.5f);
+        while ((ta + 1) * (ta + 2) / 2 <= tile)
+          ++ta;
+        while (ta * (ta + 1) / 2 > tile)
+          --ta;
+        tb = tile - ta * (ta + 1) / 2;
+      }
+    double K[4][DD];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int k = 0; k < DD; ++k)
+        K[b][k] = 0.0;
+    double rres = 0.0; // residual entry of local dof tid (threads tid < NPC*DIM)
+
+    for (int chunk = 0; chunk < NQ / QC; ++chunk)
+      {
+        // ---- phase B: (qp,node) records for this chunk
+        for (int task = tid; task < QC * NPC; task += NT)
+          {
+            const int qq = task / NPC, a = task - qq * NPC;
+            const int q  = chunk * QC + qq;
+            double    N, dN[3];
+            shape_at_qp<DIM, P>(s_N1, s_dN1, q, a, N, dN);
+            const double *r = &s_qp[q * RQ];
+            double        g[3], t[3], v[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              g[j] = dN[0] * r[Q_M + 0 * 3 + j] + dN[1] * r[Q_M + 1 * 3 + j] + dN[2] * r[Q_M + 2 * 3 + j];
+            double *o = &s_nd[(qq * NPCP + a) * RN];
+            sym_mul(&r[Q_TISO], g, t);
+            sym_mul(&r[Q_TAU], g, v);
+            const double cs2 = r[Q_CS2];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              {
+                o[j]     = g[j];
+                o[3 + j] = (-2.0 / DIM) * t[j];
+                o[6 + j] = cs2 * g[j] + v[j];
+              }
+            o[9] = r[Q_SQN] * N;
+          }
+        __syncthreads();
+
+        // ---- main loop: accumulate the 2x2 tile over this lane's share of the chunk
+        if (active)
+          {
+            for (int qq = qslot; qq < QC; qq += QSPLIT)
+              {
+                const double *r    = &s_qp[(chunk * QC + qq) * RQ];
+                const double  w    = r[Q_W], wcII = r[Q_WCII], wcs2 = w * r[Q_CS2];
+                const double *nd   = &s_nd[qq * NPCP * RN];
+                double        ha[2][3], gw[2][3], gc[2][3], na[2];
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+                  {
+                    const double *pa = &nd[(2 * ta + x) * RN];
+#pragma unroll
+                    for (int i = 0; i < DIM; ++i)
+                      {
+                        const double g = pa[i];
+                        ha[x][i]       = wcII * g + w * pa[3 + i];
+                        gw[x][i]       = w * g;
+                        gc[x][i]       = wcs2 * g;
+                      }
+                    na[x] = pa[9];
+                  }
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                  {
+                    const double *pb = &nd[(2 * tb + y) * RN];
+                    double        gb[3], mb[3], vb[3];
+#pragma unroll
+                    for (int j = 0; j < DIM; ++j)
+                      {
+                        gb[j] = pb[j];
+                        mb[j] = pb[3 + j];
+                        vb[j] = pb[6 + j];
+                      }
+                    const double nb = pb[9];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+                      {
+                        double dg = na[x] * nb;
+#pragma unroll
+                        for (int i = 0; i < DIM; ++i)
+                          dg += gw[x][i] * vb[i];
+#pragma unroll
+                        for (int i = 0; i < DIM; ++i)
+                          {
+#pragma unroll
+                            for (int j = 0; j < DIM; ++j)
+                              K[x * 2 + y][i * DIM + j] += ha[x][i] * gb[j] + gw[x][i] * mb[j] + gb[i] * gc[x][j];
+                            K[x * 2 + y][i * DIM + i] += dg;
+                          }
+                      }
+                  }
+              }
+          }
+        // ---- residual (:984-995 collapsed by partition of unity): r_a -= w (tau g_a) + N_a rho w (acc - b)
+        if (tid < NPC * DIM)
+          {
+            const int a = tid / DIM, i = tid - a * DIM;
+            for (int qq = 0; qq < QC; ++qq)
+              {
+                const double *r  = &s_qp[(chunk * QC + qq) * RQ];
+                const double *pa = &s_nd[(qq * NPCP + a) * RN];
+                const double  tg = pa[6 + i] - r[Q_CS2] * pa[i]; // (tau g_a)_i
+                rres -= r[Q_W] * tg + (pa[9] * r[Q_NINV]) * r[Q_FACC + i];
+              }
+          }
+        __syncthreads();
+      }
+
+    // ---- reduce the QSPLIT partial tiles
+#pragma unroll
+    for (int o = 1; o < QSPLIT; o <<= 1)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < DD; ++k)
+          K[b][k] += __shfl_xor(K[b][k], o, 64);
+
+    // ---- residual scatter (:769-773; constrained rows get no rhs)
+    if (tid < NPC * DIM)
+      {
+        const int     a = tid / DIM, i = tid - a * DIM;
+        const int32_t A = s_conn[a];
+        if (!((prm.cmask[A] >> i) & 1))
+          prm.rhs[int64_t(A) * DIM + i] += rres;
+      }
+
+    // ---- tangent scatter: lane `qslot` of a tile writes the blocks bl with bl % QSPLIT == qslot.
+    // [DEAL.II distribute_local_to_global] constrained rows/cols are dropped, the diagonal of a constrained
+    // dof receives |K_e(i,i)|.
+    if (active)
+      {
+        const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
+#pragma unroll
+        for (int bl = 0; bl < 4; ++bl)
+          {
+            if (bl % QSPLIT != qslot)
+              continue;
+            const int a = 2 * ta + (bl >> 1), b = 2 * tb + (bl & 1);
+            if (a >= NPC || b >= NPC || a < b)
+              continue;
+            const int32_t A = s_conn[a], B = s_conn[b];
+            const int     ma = prm.cmask[A], mb = prm.cmask[B];
+            double *__restrict__ pab = prm.vals + (int64_t(prm.rowptr[A]) + offc[a * NPC + b]) * DD;
+            double *__restrict__ pba = prm.vals + (int64_t(prm.rowptr[B]) + offc[b * NPC + a]) * DD;
+#pragma unroll
+            for (int i = 0; i < DIM; ++i)
+#pragma unroll
+              for (int j = 0; j < DIM; ++j)
+                {
+                  double v = K[bl][i * DIM + j];
+                  if (((ma >> i) | (mb >> j)) & 1)
+                    v = (a == b && i == j) ? fabs(v) : 0.0;
+                  pab[i * DIM + j] += v;
+                  if (a != b)
+                    pba[j * DIM + i] += v;
+                }
+          }
+      }
+  }
+
+  // ------------------------------------------------------------------ Neumann faces (:791-859)
+  // one 64-thread workgroup per interface face of the current colour
+  template <int DIM, int P>
+  __global__ __launch_bounds__(64) void neumann_faces(AsmParams prm, const int32_t *__restrict__ faces, int face_begin)
+  {
+    using E = Elem<DIM, P>;
+    constexpr int NPC = E::NPC, NQ1 = E::NQ1, NP1 = E::NP1, NQF = E::NQF, NV = E::NV;
+    __shared__ double s_N1[NQ1 * NP1], s_dN1[NQ1 * NP1], s_qw[NQ1], s_qx[NQ1];
+    __shared__ double s_u[NPC * 3], s_t[NPC * 3], s_verts[NV * DIM];
+    __shared__ int    s_conn[NPC];
+    __shared__ double s_fq[NQF * 4]; // per face QP: referential traction (3) and unused
+    const int     tid  = threadIdx.x;
+    const int32_t cell = faces[2 * (face_begin + blockIdx.x)], f = faces[2 * (face_begin + blockIdx.x) + 1];
+    for (int i = tid; i < NQ1 * NP1; i += 64)
+      {
+        s_N1[i]  = prm.tab1d[i];
+        s_dN1[i] = prm.tab1d[NQ1 * NP1 + i];
+      }
+    if (tid < NQ1)
+      {
+        s_qw[tid] = prm.tab1d[2 * NQ1 * NP1 + tid];
+        s_qx[tid] = prm.tab1d[2 * NQ1 * NP1 + NQ1 + tid];
+      }
+    if (tid < NPC)
+      s_conn[tid] = prm.conn[int64_t(cell) * NPC + tid];
+    if (tid < NV * DIM)
+      s_verts[tid] = prm.cverts[int64_t(cell) * (NV * DIM) + tid];
+    __syncthreads();
+    for (int i = tid; i < NPC * 3; i += 64)
+      {
+        const int a = i / 3, c = i - a * 3;
+        double    uv = 0.0, tv = 0.0;
+        if (c < DIM)
+          {
+            const int64_t g = int64_t(s_conn[a]) * DIM + c;
+            uv              = prm.u[g] + prm.du[g];
+            tv              = prm.stress[g];
+          }
+        s_u[i] = uv;
+        s_t[i] = tv;
+      }
+    __syncthreads();
+
+    const int nd = f >> 1, side = f & 1;
+    // face-local axes [DEAL.II, recalled]: x-normal (y,z); y-normal (z,x) in 3D, (x) in 2D; z-normal (x,y)
+    int ax0, ax1;
+    if (DIM == 2)
+      {
+        ax0 = nd == 0 ? 1 : 0;
+        ax1 = 2;
+      }
+    else
+      {
+        ax0 = nd == 0 ? 1 : (nd == 1 ? 2 : 0);
+        ax1 = nd == 0 ? 2 : (nd == 1 ? 0 : 1);
+      }
+    for (int fq = tid; fq < NQF; fq += 64)
+      {
+        const int f1 = fq % NQ1, f2 = fq / NQ1;
+        // (1) F at the CELL quadrature point with index fq  -- the reference's quirk (:825-827 vs :902-903)
+        double gxi[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          gxi[k] = 0.0;
+        for (int a = 0; a < NPC; ++a)
+          {
+            double N, dN[3];
+            shape_at_qp<DIM, P>(s_N1, s_dN1, fq, a, N, dN);
+#pragma unroll
+            for (int i = 0; i < DIM; ++i)
+#pragma unroll
+              for (int j = 0; j < DIM; ++j)
+                gxi[i * 3 + j] += s_u[a * 3 + i] * dN[j];
+          }
+        double xi[3] = {0, 0, 0};
+        {
+          int qi[3] = {fq % NQ1, (fq / NQ1) % NQ1, (DIM == 3) ? fq / (NQ1 * NQ1) : 0};
+#pragma unroll
+          for (int d = 0; d < DIM; ++d)
+            xi[d] = s_qx[qi[d]];
+        }
+        double Jm[9], Ji[9], F[9], Fi[9];
+        q1_jacobian<DIM>(s_verts, xi, Jm);
+        inv3x3(Jm, det3x3(Jm), Ji);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            F[i * 3 + j] = (i == j ? 1.0 : 0.0) + gxi[i * 3 + 0] * Ji[0 * 3 + j] + gxi[i * 3 + 1] * Ji[1 * 3 + j] +
+                           gxi[i * 3 + 2] * Ji[2 * 3 + j];
+        if (DIM == 2)
+          F[8] = 1.0;
+        const double J = det3x3(F);
+        inv3x3(F, J, Fi);
+        // (2) face geometry at the face quadrature point
+        double xf[3] = {0, 0, 0};
+        xf[nd]       = side ? 1.0 : 0.0;
+        xf[ax0]      = s_qx[f1];
+        double wf    = s_qw[f1];
+        if (DIM == 3)
+          {
+            xf[ax1] = s_qx[f2];
+            wf *= s_qw[f2];
+          }
+        q1_jacobian<DIM>(s_verts, xf, Jm);
+        double cr[3];
+        if (DIM == 2)
+          {
+            const int t = nd == 0 ? 1 : 0;
+            cr[0]       = Jm[1 * 3 + t];
+            cr[1]       = -Jm[0 * 3 + t];
+            cr[2]       = 0.0;
+          }
+        else
+          {
+            const int    t1 = (nd + 1) % 3, t2 = (nd + 2) % 3;
+            const double a0 = Jm[0 * 3 + t1], a1 = Jm[1 * 3 + t1], a2 = Jm[2 * 3 + t1];
+            const double b0 = Jm[0 * 3 + t2], b1 = Jm[1 * 3 + t2], b2 = Jm[2 * 3 + t2];
+            cr[0]           = a1 * b2 - a2 * b1;
+            cr[1]           = a2 * b0 - a0 * b2;
+            cr[2]           = a0 * b1 - a1 * b0;
+          }
+        double dotn = cr[0] * Jm[0 * 3 + nd] + cr[1] * Jm[1 * 3 + nd] + cr[2] * Jm[2 * 3 + nd];
+        double sg   = (dotn < 0 ? -1.0 : 1.0) * (side ? 1.0 : -1.0); // outward
+        const double len = sqrt(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+        double       nrm[3] = {sg * cr[0] / len, sg * cr[1] / len, sg * cr[2] / len};
+        // n* = det F F^{-T} N  (:831-833)
+        double ns[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          ns[i] = J * (Fi[0 * 3 + i] * nrm[0] + Fi[1 * 3 + i] * nrm[1] + Fi[2 * 3 + i] * nrm[2]);
+        const double nn = sqrt(ns[0] * ns[0] + ns[1] * ns[1] + (DIM == 3 ? ns[2] * ns[2] : 0.0));
+        // (3) traction interpolated on the face (:815-816): only nodes on the face have non-zero shape values
+        double ts[3] = {0, 0, 0};
+        for (int a = 0; a < NPC; ++a)
+          {
+            int ai[3] = {a % NP1, (a / NP1) % NP1, (DIM == 3) ? a / (NP1 * NP1) : 0};
+            if (ai[nd] != (side ? P : 0))
+              continue;
+            double N = s_N1[f1 * NP1 + ai[ax0]];
+            if (DIM == 3)
+              N *= s_N1[f2 * NP1 + ai[ax1]];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              ts[c] += N * s_t[a * 3 + c];
+          }
+        const double sc = nn * len * wf; // ||n*|| JxW_face  (:836-837, :850-851)
+        s_fq[fq * 4 + 0] = ts[0] * sc;
+        s_fq[fq * 4 + 1] = ts[1] * sc;
+        s_fq[fq * 4 + 2] = ts[2] * sc;
+      }
+    __syncthreads();
+    // (4) rhs_i += N_i * referential_stress[c_i] * JxW  (:839-856)
+    for (int i = tid; i < NPC * DIM; i += 64)
+      {
+        const int a = i / DIM, c = i - a * DIM;
+        int       ai[3] = {a % NP1, (a / NP1) % NP1, (DIM == 3) ? a / (NP1 * NP1) : 0};
+        if (ai[nd] != (side ? P : 0))
+          continue;
+        double s = 0.0;
+        for (int fq = 0; fq < NQF; ++fq)
+          {
+            const int f1 = fq % NQ1, f2 = fq / NQ1;
+            double    N  = s_N1[f1 * NP1 + ai[ax0]];
+            if (DIM == 3)
+              N *= s_N1[f2 * NP1 + ai[ax1]];
+            s += N * s_fq[fq * 4 + c];
+          }
+        const int32_t A = s_conn[a];
+        if (!((prm.cmask[A] >> c) & 1))
+          prm.rhs[int64_t(A) * DIM + c] += s;
+      }
+  }
+
+  // ------------------------------------------------------------------ block-CSR SpMV
+  // One wavefront per block row; lane = (block slot kb, entry e) so that a wave reads 64/DD whole blocks
+  // (504 or 512 contiguous bytes) per step.  Workgroups are renumbered so that the 8 XCDs own contiguous
+  // eighths of the rows (x stays in the XCD's L2).  Optional fused dot product with `dotv`, written as
+  // one partial per workgroup (deterministic two-level reduction).
+  template <int D>
+  __global__ __launch_bounds__(256) void bsr_spmv(SpmvParams prm)
+  {
+    if (prm.done && *prm.done)
+      return;
+    constexpr int DD = D * D, BPW = 64 / DD, PW = (BPW > 8 ? 16 : 8);
+    __shared__ double s_red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int lb  = (nwg % 8 == 0) ? (b % 8) * (nwg / 8) + b / 8 : b;
+    const int64_t per = (prm.nrows + nwg - 1) / nwg;
+    const int64_t r0 = prm.row0 + lb * per, r1 = imin64(prm.row0 + prm.nrows, r0 + per);
+    const int     kb = lane / DD, e = lane - kb * DD, i = e / D, j = e - i * D;
+    const bool    act = kb < BPW;
+    double        dsum = 0.0;
+    for (int64_t row = r0 + wave; row < r1; row += 4)
+      {
+        const int s = prm.rowptr[row], t = prm.rowptr[row + 1];
+        double    acc0 = 0.0, acc1 = 0.0;
+        if (act)
+          {
+            int k = s + kb;
+            for (; k + BPW < t; k += 2 * BPW)
+              {
+                const double  v0 = prm.vals[int64_t(k) * DD + e];
+                const double  v1 = prm.vals[int64_t(k + BPW) * DD + e];
+                const int32_t c0 = prm.col[k], c1 = prm.col[k + BPW];
+                acc0 += v0 * prm.x[int64_t(c0) * D + j];
+                acc1 += v1 * prm.x[int64_t(c1) * D + j];
+              }
+            if (k < t)
+              acc0 += prm.vals[int64_t(k) * DD + e] * prm.x[int64_t(prm.col[k]) * D + j];
+          }
+        double sacc = acc0 + acc1;
+        // sum over j (adjacent lanes), then over block slots (stride DD lanes)
+        if constexpr (D == 3)
+          {
+            const double t1 = __shfl_down(sacc, 1, 64), t2 = __shfl_down(sacc, 2, 64);
+            sacc += t1 + t2;
+          }
+        else
+          sacc += __shfl_down(sacc, 1, 64);
+#pragma unroll
+        for (int o = PW / 2; o >= 1; o >>= 1)
+          {
+            const double t1 = __shfl_down(sacc, o * DD, 64);
+            if (kb < o && kb + o < BPW)
+              sacc += t1;
+          }
+        if (kb == 0 && j == 0)
+          {
+            prm.y[row * D + i] = sacc;
+            if (prm.dotv)
+              dsum += sacc * prm.dotv[row * D + i];
+          }
+      }
+    if (prm.partials)
+      {
+        const double tot = block_sum<256>(dsum, s_red);
+        if (threadIdx.x == 0)
+          prm.partials[b] = tot;
+      }
+  }
+
+  // ------------------------------------------------------------------ CG vector kernels (Jacobi-PCG)
+  // scalars: sc[0..1] rz ping-pong, sc[2] tolerance (absolute), sc[3] final residual; flags: [0] done, [1] its
+  //
+  // cg_update_p (iteration it >= 1): totals of the previous update's partials give ||r||^2 and r.z;
+  // decide convergence (SolverControl: ||r|| <= tol), else p = z + beta p with z = dinv*r.
+  __global__ __launch_bounds__(256) void cg_update_p(CgParams c, int it)
+  {
+    __shared__ double s_red[4];
+    if (c.flags[0])
+      return;
+    const double rr = reduce_partials<256>(c.part_rr, c.npart, s_red);
+    const double rz = reduce_partials<256>(c.part_rz, c.npart, s_red);
+    const double res = sqrt(rr);
+    if (res <= c.sc[2])
+      {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+          {
+            c.flags[0] = 1;
+            c.flags[1] = it - 1;
+            c.sc[3]    = res;
+          }
+        return;
+      }
+    const double beta = (it == 1) ? 0.0 : rz / c.sc[(it - 1) & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      {
+        c.sc[it & 1] = rz;
+        c.sc[3]      = res;
+        c.flags[1]   = it - 1;
+      }
+    const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
+  }
+
+  // cg_update_xr: alpha = rz / (p.Ap); x += alpha p; r -= alpha Ap; partials of ||r||^2 and r.dinv.r
+  __global__ __launch_bounds__(256) void cg_update_xr(CgParams c, int it)
+  {
+    __shared__ double s_red[4];
+    if (c.flags[0])
+      return;
+    const double pq    = reduce_partials<256>(c.part_pq, c.npart_pq, s_red);
+    const double alpha = c.sc[it & 1] / pq;
+    const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
+    double        srr = 0.0, srz = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      {
+        c.x[i] += alpha * c.p[i];
+        const double ri = c.r[i] - alpha * c.q[i];
+        c.r[i]          = ri;
+        srr += ri * ri;
+        srz += ri * ri * c.dinv[i];
+      }
+    srr = block_sum<256>(srr, s_red);
+    srz = block_sum<256>(srz, s_red);
+    if (threadIdx.x == 0)
+      {
+        c.part_rr[blockIdx.x] = srr;
+        c.part_rz[blockIdx.x] = srz;
+      }
+  }
+
+  // r = b - q (q = A x0), partials of ||r||^2, r.dinv.r and ||b||^2
+  __global__ __launch_bounds__(256) void cg_init_residual(CgParams c, const double *__restrict__ b, double *part_bb)
+  {
+    __shared__ double s_red[4];
+    const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
+    double        srr = 0.0, srz = 0.0, sbb = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      {
+        const double bi = b[i], ri = bi - c.q[i];
+        c.r[i]          = ri;
+        srr += ri * ri;
+        srz += ri * ri * c.dinv[i];
+        sbb += bi * bi;
+      }
+    srr = block_sum<256>(srr, s_red);
+    srz = block_sum<256>(srz, s_red);
+    sbb = block_sum<256>(sbb, s_red);
+    if (threadIdx.x == 0)
+      {
+        c.part_rr[blockIdx.x] = srr;
+        c.part_rz[blockIdx.x] = srz;
+        part_bb[blockIdx.x]   = sbb;
+      }
+  }
+
+  // tol = rel_tol * ||b||  (:1171-1172); reset flags
+  __global__ __launch_bounds__(256) void cg_set_tolerance(CgParams c, const double *part_bb, double rel_tol)
+  {
+    __shared__ double s_red[4];
+    const double bb = reduce_partials<256>(part_bb, c.npart, s_red);
+    if (threadIdx.x == 0)
+      {
+        c.sc[2]    = rel_tol * sqrt(bb);
+        c.sc[3]    = 0.0;
+        c.sc[4]    = sqrt(bb);
+        c.flags[0] = 0;
+        c.flags[1] = 0;
+      }
+  }
+
+  // last check after the final enqueued iteration (convergence is otherwise detected by the next update_p)
+  __global__ __launch_bounds__(256) void cg_final_check(CgParams c, int it)
+  {
+    __shared__ double s_red[4];
+    if (c.flags[0])
+      return;
+    const double rr  = reduce_partials<256>(c.part_rr, c.npart, s_red);
+    const double res = sqrt(rr);
+    if (threadIdx.x == 0)
+      {
+        c.sc[3]    = res;
+        c.flags[1] = it;
+        if (res <= c.sc[2])
+          c.flags[0] = 1;
+      }
+  }
+
+  // ------------------------------------------------------------------ small vector kernels
+  // dinv = 1 / diag(K); constraints.distribute afterwards keeps constrained entries of x at 0
+  template <int D>
+  __global__ __launch_bounds__(256) void extract_dinv(const double *__restrict__ vals,
+                                                      const int32_t *__restrict__ diagpos, double *dinv, int64_t nnodes)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= nnodes * D)
+      return;
+    const int64_t n = i / D;
+    const int     c = int(i - n * D);
+    dinv[i]         = 1.0 / vals[int64_t(diagpos[n]) * (D * D) + c * D + c];
+  }
+
+  // masked l2 norm partials: sum over dofs whose constraint bit is clear (:549-576)
+  template <int D>
+  __global__ __launch_bounds__(256) void masked_norm_partials(const double *__restrict__ v,
+                                                              const uint8_t *__restrict__ cmask, int64_t n, double *part)
+  {
+    __shared__ double s_red[4];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = blockIdx.x * per, i1 = imin64(n, i0 + per);
+    double        s  = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      {
+        const int64_t nd = i / D;
+        const int     c  = int(i - nd * D);
+        if (!((cmask[nd] >> c) & 1))
+          s += v[i] * v[i];
+      }
+    s = block_sum<256>(s, s_red);
+    if (threadIdx.x == 0)
+      part[blockIdx.x] = s;
+  }
+  __global__ __launch_bounds__(256) void finish_norm(const double *part, int n, double *out)
+  {
+    __shared__ double s_red[4];
+    const double s = reduce_partials<256>(part, n, s_red);
+    if (threadIdx.x == 0)
+      *out = sqrt(s);
+  }
+
+  // constraints.distribute for homogeneous constraints (:1208): x[constrained] = 0
+  template <int D>
+  __global__ __launch_bounds__(256) void zero_constrained(double *x, const uint8_t *__restrict__ cmask, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n)
+      return;
+    const int64_t nd = i / D;
+    if ((cmask[nd] >> int(i - nd * D)) & 1)
+      x[i] = 0.0;
+  }
+
+  // update_acceleration (:592-599): a = alpha1 du - alpha2 v_old - alpha3 a_old
+  __global__ __launch_bounds__(256) void newmark_acceleration(NewmarkParams p)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < p.n)
+      {
+        double a = p.alpha1 * p.du[i];
+        a += -p.alpha2 * p.v_old[i] + -p.alpha3 * p.a_old[i];
+        p.a[i] = a;
+      }
+  }
+  // delta += newton_update (:487)
+  __global__ __launch_bounds__(256) void vec_add(double *y, const double *__restrict__ x, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+      y[i] += x[i];
+  }
+  // run() :139-144 fused: u += du; a = ...; v = alpha4 du + alpha5 v_old + alpha6 a_old; old := new
+  __global__ __launch_bounds__(256) void newmark_finish(NewmarkParams p)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < p.n)
+      {
+        const double du = p.du[i], vo = p.v_old[i], ao = p.a_old[i];
+        const double u  = p.u[i] + du;
+        double       a  = p.alpha1 * du;
+        a += -p.alpha2 * vo + -p.alpha3 * ao;
+        double v = p.alpha4 * du;
+        v += p.alpha5 * vo + p.alpha6 * ao;
+        p.u[i]     = u;
+        p.u_old[i] = u;
+        p.a[i]     = a;
+        p.a_old[i] = a;
+        p.v[i]     = v;
+        p.v_old[i] = v;
+      }
+  }
+
+  // interface gather / scatter (adapter.h:389-443)
+  template <int D>
+  __global__ __launch_bounds__(256) void gather_nodes(const double *__restrict__ v, const int32_t *__restrict__ nodes,
+                                                      int n, double *out)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n * D)
+      out[i] = v[int64_t(nodes[i / D]) * D + i % D];
+  }
+  template <int D>
+  __global__ __launch_bounds__(256) void scatter_nodes(double *v, const int32_t *__restrict__ nodes, int n,
+                                                       const double *__restrict__ in)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n * D)
+      v[int64_t(nodes[i / D]) * D + i % D] = in[i];
+  }
+
+  // ------------------------------------------------------------------ launchers
+  template <int DIM, int P, int QSPLIT, int NT, int QC>
+  static void launch_asm(const AsmParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL((assemble_cells<DIM, P, QSPLIT, NT, QC>), dim3(p.cell_count), dim3(NT), 0, s, p);
+  }
+
+  int launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s)
+  {
+    if (p.cell_count <= 0)
+      return 0;
+    // <DIM, P, QSPLIT, NT, QC>: NT >= NTILES*QSPLIT and >= NPC*DIM; QC divides NQ
+    if (dim == 3 && degree == 2)
+      launch_asm<3, 2, 2, 256, 16>(p, s); // 105 tiles x 2, 64 QPs in chunks of 16
+    else if (dim == 3 && degree == 1)
+      launch_asm<3, 1, 4, 64, 27>(p, s); // 10 tiles x 4
+    else if (dim == 2 && degree == 1)
+      launch_asm<2, 1, 4, 64, 9>(p, s); // 3 tiles
+    else if (dim == 2 && degree == 2)
+      launch_asm<2, 2, 4, 64, 16>(p, s); // 15 tiles x 4
+    else if (dim == 2 && degree == 3)
+      launch_asm<2, 3, 2, 128, 25>(p, s); // 36 tiles x 2
+    else if (dim == 2 && degree == 4)
+      launch_asm<2, 4, 2, 192, 18>(p, s); // 91 tiles x 2
+    else
+      return -1;
+    return 0;
+  }
+
+  int launch_neumann_faces(int dim, int degree, const AsmParams &p, const int32_t *faces, int face_begin,
+                           int face_count, hipStream_t s)
+  {
+    if (face_count <= 0)
+      return 0;
+#define MI_NF(D_, P_)                                                                                               \
+  if (dim == D_ && degree == P_)                                                                                    \
+    {                                                                                                               \
+      hipLaunchKernelGGL((neumann_faces<D_, P_>), dim3(face_count), dim3(64), 0, s, p, faces, face_begin);          \
+      return 0;                                                                                                     \
+    }
+    MI_NF(3, 2)
+    MI_NF(3, 1)
+    MI_NF(2, 1)
+    MI_NF(2, 2)
+    MI_NF(2, 3)
+    MI_NF(2, 4)
+#undef MI_NF
+    return -1;
+  }
+
+  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s)
+  {
+    if (dim == 3)
+      hipLaunchKernelGGL((bsr_spmv<3>), dim3(grid), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((bsr_spmv<2>), dim3(grid), dim3(256), 0, s, p);
+  }
+
+  void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cg_update_p, dim3(grid), dim3(256), 0, s, c, it);
+  }
+  void launch_cg_update_xr(const CgParams &c, int it, int grid, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cg_update_xr, dim3(grid), dim3(256), 0, s, c, it);
+  }
+  void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cg_init_residual, dim3(grid), dim3(256), 0, s, c, b, part_bb);
+  }
+  void launch_cg_set_tolerance(const CgParams &c, const double *part_bb, double rel_tol, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cg_set_tolerance, dim3(1), dim3(256), 0, s, c, part_bb, rel_tol);
+  }
+  void launch_cg_final_check(const CgParams &c, int it, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cg_final_check, dim3(1), dim3(256), 0, s, c, it);
+  }
+  void launch_extract_dinv(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
+                           hipStream_t s)
+  {
+    const int grid = int((nnodes * dim + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((extract_dinv<3>), dim3(grid), dim3(256), 0, s, vals, diagpos, dinv, nnodes);
+    else
+      hipLaunchKernelGGL((extract_dinv<2>), dim3(grid), dim3(256), 0, s, vals, diagpos, dinv, nnodes);
+  }
+  void launch_masked_norm(int dim, const double *v, const uint8_t *cmask, int64_t n, double *part, int grid,
+                          double *out, hipStream_t s)
+  {
+    if (dim == 3)
+      hipLaunchKernelGGL((masked_norm_partials<3>), dim3(grid), dim3(256), 0, s, v, cmask, n, part);
+    else
+      hipLaunchKernelGGL((masked_norm_partials<2>), dim3(grid), dim3(256), 0, s, v, cmask, n, part);
+    hipLaunchKernelGGL(finish_norm, dim3(1), dim3(256), 0, s, part, grid, out);
+  }
+  void launch_zero_constrained(int dim, double *x, const uint8_t *cmask, int64_t n, hipStream_t s)
+  {
+    const int grid = int((n + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((zero_constrained<3>), dim3(grid), dim3(256), 0, s, x, cmask, n);
+    else
+      hipLaunchKernelGGL((zero_constrained<2>), dim3(grid), dim3(256), 0, s, x, cmask, n);
+  }
+  void launch_newmark_acceleration(const NewmarkParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL(newmark_acceleration, dim3(int((p.n + 255) / 256)), dim3(256), 0, s, p);
+  }
+  void launch_newmark_finish(const NewmarkParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL(newmark_finish, dim3(int((p.n + 255) / 256)), dim3(256), 0, s, p);
+  }
+  void launch_vec_add(double *y, const double *x, int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(vec_add, dim3(int((n + 255) / 256)), dim3(256), 0, s, y, x, n);
+  }
+  void launch_gather_nodes(int dim, const double *v, const int32_t *nodes, int n, double *out, hipStream_t s)
+  {
+    const int grid = (n * dim + 255) / 256;
+    if (grid == 0)
+      return;
+    if (dim == 3)
+      hipLaunchKernelGGL((gather_nodes<3>), dim3(grid), dim3(256), 0, s, v, nodes, n, out);
+    else
+      hipLaunchKernelGGL((gather_nodes<2>), dim3(grid), dim3(256), 0, s, v, nodes, n, out);
+  }
+  void launch_scatter_nodes(int dim, double *v, const int32_t *nodes, int n, const double *in, hipStream_t s)
+  {
+    const int grid = (n * dim + 255) / 256;
+    if (grid == 0)
+      return;
+    if (dim == 3)
+      hipLaunchKernelGGL((scatter_nodes<3>), dim3(grid), dim3(256), 0, s, v, nodes, n, in);
+    else
+      hipLaunchKernelGGL((scatter_nodes<2>), dim3(grid), dim3(256), 0, s, v, nodes, n, in);
+  }
+} // namespace mi

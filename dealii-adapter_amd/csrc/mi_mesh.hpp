@@ -1,0 +1,432 @@
+// mi_mesh.hpp -- host-side mesh / DoF / sparsity / colouring setup for the device solver.
+//
+// Replaces, for the hot path, what the reference gets from deal.II in make_grid
+// (nonlinear_elasticity.cc:171-301) and system_setup (:305-380): a subdivided box with Q1 geometry,
+// FE_Q(p)^dim DoFs, the all-components-couple sparsity (:339-345) and the Dirichlet index set of
+// make_constraints (:1094-1150).  Layout is chosen for the GPU, not translated from deal.II:
+//   * node-major DoF numbering  dof = dim*node + comp,  nodes lexicographic on the (p*reps+1)^dim lattice
+//   * tangent stored as block CSR with dim x dim blocks over nodes (every node pair couples in all components)
+//   * cells grouped by parity colour (2^dim colours): two cells of one colour share no node, so a colour
+//     scatters into the matrix with plain read-modify-write
+//   * all per-cell arrays are stored in colour-sorted order so a colour's launch reads them contiguously
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace mi
+{
+  // ------------------------------------------------------------------ 1D rules and nodal bases
+  // n-point Gauss-Legendre on [0,1] (deal.II QGauss<1>(n))
+  inline void gauss_legendre_unit(int n, std::vector<double> &x, std::vector<double> &w)
+  {
+    x.assign(n, 0.0);
+    w.assign(n, 0.0);
+    const int half = (n + 1) / 2;
+    for (int i = 0; i < half; ++i)
+      {
+        long double t = std::cos(3.14159265358979323846L * (4 * i + 3) / (4 * n + 2)); // root i, descending
+        long double dp = 0;
+        for (int it = 0; it < 64; ++it)
+          {
+            long double pm = 1, pc = t; // P_0, P_1
+            for (int k = 2; k <= n; ++k)
+              {
+                const long double pn = ((2 * k - 1) * t * pc - (k - 1) * pm) / k;
+                pm                   = pc;
+                pc                   = pn;
+              }
+            if (n == 1)
+              {
+                pm = 1;
+                pc = t;
+              }
+            dp                   = n * (pm - t * pc) / (1 - t * t);
+            const long double dt = pc / dp;
+            t -= dt;
+            if (std::fabs((double)dt) < 1e-18)
+              break;
+          }
+        const long double wt = 2 / ((1 - t * t) * dp * dp);
+        x[n - 1 - i]         = double(0.5L * (1 + t));
+        x[i]                 = double(0.5L * (1 - t));
+        w[i] = w[n - 1 - i] = double(0.5L * wt);
+      }
+  }
+
+  // FE_Q(p) support points on [0,1]: equidistant for p <= 2, Gauss-Lobatto for p >= 3
+  inline std::vector<double> feq_nodes_unit(int p)
+  {
+    std::vector<double> x(p + 1);
+    if (p <= 2)
+      {
+        for (int i = 0; i <= p; ++i)
+          x[i] = double(i) / p;
+        return x;
+      }
+    const int m = p; // interior points are the roots of P'_m
+    x[0]        = 0.0;
+    x[p]        = 1.0;
+    for (int i = 1; i < p; ++i)
+      {
+        long double t = -std::cos(3.14159265358979323846L * i / p);
+        for (int it = 0; it < 64; ++it)
+          {
+            long double pm = 1, pc = t;
+            for (int k = 2; k <= m; ++k)
+              {
+                const long double pn = ((2 * k - 1) * t * pc - (k - 1) * pm) / k;
+                pm                   = pc;
+                pc                   = pn;
+              }
+            const long double d1 = m * (pm - t * pc) / (1 - t * t);         // P'_m
+            const long double d2 = (2 * t * d1 - m * (m + 1) * pc) / (1 - t * t); // P''_m
+            const long double dt = d1 / d2;
+            t -= dt;
+            if (std::fabs((double)dt) < 1e-18)
+              break;
+          }
+        x[i] = double(0.5L * (1 + t));
+      }
+    for (int i = 0; i < (p + 1) / 2; ++i) // enforce symmetry
+      {
+        const double s = 0.5 * (x[i] + 1.0 - x[p - i]);
+        x[i]           = s;
+        x[p - i]       = 1.0 - s;
+      }
+    if (p % 2 == 0)
+      x[p / 2] = 0.5;
+    return x;
+  }
+
+  // barycentric-free Lagrange value/derivative of basis a at x
+  inline void lagrange_eval(const std::vector<double> &nodes, double x, double *val, double *der)
+  {
+    const int n = int(nodes.size());
+    for (int a = 0; a < n; ++a)
+      {
+        double denom = 1.0;
+        for (int m = 0; m < n; ++m)
+          if (m != a)
+            denom *= nodes[a] - nodes[m];
+        double v = 1.0, d = 0.0;
+        for (int m = 0; m < n; ++m)
+          if (m != a)
+            v *= x - nodes[m];
+        for (int k = 0; k < n; ++k)
+          if (k != a)
+            {
+              double t = 1.0;
+              for (int m = 0; m < n; ++m)
+                if (m != a && m != k)
+                  t *= x - nodes[m];
+              d += t;
+            }
+        val[a] = v / denom;
+        der[a] = d / denom;
+      }
+  }
+
+  // 1D tables handed to the kernels: N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1]
+  struct Tables1D
+  {
+    int                 p, np1, nq1;
+    std::vector<double> nodes, qx, qw, N, dN;
+    void                build(int p_, int nq1_)
+    {
+      p   = p_;
+      np1 = p + 1;
+      nq1 = nq1_;
+      nodes = feq_nodes_unit(p);
+      gauss_legendre_unit(nq1, qx, qw);
+      N.resize(size_t(nq1) * np1);
+      dN.resize(size_t(nq1) * np1);
+      for (int q = 0; q < nq1; ++q)
+        lagrange_eval(nodes, qx[q], &N[size_t(q) * np1], &dN[size_t(q) * np1]);
+    }
+    std::vector<double> packed() const
+    {
+      std::vector<double> t;
+      t.insert(t.end(), N.begin(), N.end());
+      t.insert(t.end(), dN.begin(), dN.end());
+      t.insert(t.end(), qw.begin(), qw.end());
+      t.insert(t.end(), qx.begin(), qx.end());
+      return t;
+    }
+  };
+
+  struct InterfaceFace
+  {
+    int32_t cell; // colour-sorted cell position
+    int32_t face; // 0..2*dim-1  (x-,x+,y-,y+,z-,z+)
+  };
+
+  struct HostMesh
+  {
+    int dim = 0, p = 0, np1 = 0, npc = 0, nv = 0;
+    int reps[3] = {1, 1, 1}, nn[3] = {1, 1, 1}, nvx[3] = {1, 1, 1};
+    int64_t ncells = 0, nnodes = 0, nverts = 0, ndofs = 0, nnzb = 0;
+    int     ncolours = 0;
+
+    std::vector<double>   node_xyz;     // [nnodes][dim]
+    std::vector<int32_t>  conn;         // [ncells][npc], colour-sorted cells
+    std::vector<double>   cverts;       // [ncells][nv][dim], colour-sorted cells
+    std::vector<int32_t>  cell_orig;    // colour-sorted position -> lexicographic cell id
+    std::vector<int64_t>  colour_begin; // [ncolours+1] into the colour-sorted order
+    std::vector<int32_t>  rowptr;       // [nnodes+1] block rows
+    std::vector<int32_t>  colidx;       // [nnzb]
+    std::vector<int32_t>  diagpos;      // [nnodes] block index of (node,node)
+    std::vector<uint16_t> off;          // [ncells][npc][npc]: column slot of node b in block row of node a
+    std::vector<uint8_t>  cmask;        // [nnodes] bit c set: dof (node,c) is Dirichlet-constrained
+    std::vector<int32_t>  iface_nodes;  // ascending
+    std::vector<InterfaceFace> iface_faces;         // sorted by colour
+    std::vector<int64_t>       iface_colour_begin;  // [ncolours+1]
+
+    static void split(int64_t id, const int *ext, int dim, int *out)
+    {
+      for (int d = 0; d < 3; ++d)
+        out[d] = 0;
+      for (int d = 0; d < dim; ++d)
+        {
+          out[d] = int(id % ext[d]);
+          id /= ext[d];
+        }
+    }
+
+    // range of lattice nodes coupled to lattice index i along one direction
+    void couple_range(int d, int i, int &lo, int &hi) const
+    {
+      if (i % p == 0)
+        {
+          lo = std::max(0, i - p);
+          hi = std::min(nn[d] - 1, i + p);
+        }
+      else
+        {
+          lo = (i / p) * p;
+          hi = lo + p;
+        }
+    }
+
+    void build(int dim_, int p_, const int *reps_, const double *lo, const double *hi, const int *face_role,
+               const double *perturb)
+    {
+      dim = dim_;
+      p   = p_;
+      if (dim != 2 && dim != 3)
+        throw std::invalid_argument("dim must be 2 or 3");
+      if (p < 1 || p > 4)
+        throw std::invalid_argument("polynomial degree must be in 1..4");
+      np1 = p + 1;
+      npc = 1;
+      nv  = 1 << dim;
+      ncells = nnodes = nverts = 1;
+      for (int d = 0; d < dim; ++d)
+        {
+          if (reps_[d] < 1)
+            throw std::invalid_argument("repetitions must be >= 1");
+          reps[d] = reps_[d];
+          nn[d]   = p * reps[d] + 1;
+          nvx[d]  = reps[d] + 1;
+          npc *= np1;
+          ncells *= reps[d];
+          nnodes *= nn[d];
+          nverts *= nvx[d];
+        }
+      ndofs = nnodes * dim;
+      const std::vector<double> nodes1 = feq_nodes_unit(p);
+
+      // vertices
+      std::vector<double> vx(size_t(nverts) * dim);
+      for (int64_t v = 0; v < nverts; ++v)
+        {
+          int vi[3];
+          split(v, nvx, dim, vi);
+          for (int d = 0; d < dim; ++d)
+            vx[size_t(v) * dim + d] =
+              lo[d] + (hi[d] - lo[d]) * vi[d] / reps[d] + (perturb ? perturb[size_t(v) * dim + d] : 0.0);
+        }
+
+      // parity colouring, colour-sorted cell order
+      ncolours = 1 << dim;
+      std::vector<std::vector<int32_t>> by_colour(ncolours);
+      for (int64_t c = 0; c < ncells; ++c)
+        {
+          int ci[3];
+          split(c, reps, dim, ci);
+          const int col = (ci[0] & 1) | ((ci[1] & 1) << 1) | ((ci[2] & 1) << 2);
+          by_colour[col].push_back(int32_t(c));
+        }
+      cell_orig.clear();
+      colour_begin.assign(1, 0);
+      {
+        std::vector<std::vector<int32_t>> kept;
+        for (auto &v : by_colour)
+          if (!v.empty())
+            kept.push_back(std::move(v));
+        ncolours = int(kept.size());
+        for (auto &v : kept)
+          {
+            cell_orig.insert(cell_orig.end(), v.begin(), v.end());
+            colour_begin.push_back(int64_t(cell_orig.size()));
+          }
+      }
+
+      // block-CSR pattern: the coupled set of a lattice node is a tensor-product box
+      rowptr.assign(size_t(nnodes) + 1, 0);
+      for (int64_t n = 0; n < nnodes; ++n)
+        {
+          int ni[3];
+          split(n, nn, dim, ni);
+          int64_t cnt = 1;
+          for (int d = 0; d < dim; ++d)
+            {
+              int a, b;
+              couple_range(d, ni[d], a, b);
+              cnt *= (b - a + 1);
+            }
+          if (cnt > 65535)
+            throw std::invalid_argument("row too long for uint16 scatter offsets");
+          rowptr[size_t(n) + 1] = int32_t(cnt);
+        }
+      {
+        int64_t run = 0;
+        for (int64_t n = 0; n < nnodes; ++n)
+          {
+            run += rowptr[size_t(n) + 1];
+            if (run > INT32_MAX)
+              throw std::invalid_argument("more than 2^31 blocks: partition the mesh over more GPUs");
+            rowptr[size_t(n) + 1] = int32_t(run);
+          }
+        nnzb = run;
+      }
+      colidx.resize(size_t(nnzb));
+      diagpos.resize(size_t(nnodes));
+      for (int64_t n = 0; n < nnodes; ++n)
+        {
+          int ni[3], a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+          split(n, nn, dim, ni);
+          for (int d = 0; d < dim; ++d)
+            couple_range(d, ni[d], a[d], b[d]);
+          int64_t k = rowptr[size_t(n)];
+          for (int z = a[2]; z <= b[2]; ++z)
+            for (int y = a[1]; y <= b[1]; ++y)
+              for (int x = a[0]; x <= b[0]; ++x)
+                {
+                  const int64_t m = x + int64_t(nn[0]) * (y + int64_t(nn[1]) * z);
+                  if (m == n)
+                    diagpos[size_t(n)] = int32_t(k);
+                  colidx[size_t(k++)] = int32_t(m);
+                }
+        }
+
+      // per-cell data in colour-sorted order
+      conn.resize(size_t(ncells) * npc);
+      cverts.resize(size_t(ncells) * nv * dim);
+      off.resize(size_t(ncells) * npc * npc);
+      node_xyz.assign(size_t(nnodes) * dim, 0.0);
+      cmask.assign(size_t(nnodes), 0);
+      std::vector<uint8_t> on_iface((size_t)nnodes, 0);
+      std::vector<std::vector<InterfaceFace>> faces_by_colour(ncolours);
+      std::vector<int> colour_of_pos((size_t)ncells, 0);
+      for (int c = 0; c < ncolours; ++c)
+        for (int64_t k = colour_begin[c]; k < colour_begin[c + 1]; ++k)
+          colour_of_pos[size_t(k)] = c;
+
+      for (int64_t pos = 0; pos < ncells; ++pos)
+        {
+          int ci[3];
+          split(cell_orig[size_t(pos)], reps, dim, ci);
+          double *cv = &cverts[size_t(pos) * nv * dim];
+          for (int v = 0; v < nv; ++v)
+            {
+              const int     vi[3] = {ci[0] + (v & 1), ci[1] + ((v >> 1) & 1), ci[2] + ((v >> 2) & 1)};
+              const int64_t id    = vi[0] + int64_t(nvx[0]) * (vi[1] + int64_t(nvx[1]) * vi[2]);
+              for (int d = 0; d < dim; ++d)
+                cv[v * dim + d] = vx[size_t(id) * dim + d];
+            }
+          int32_t *cn = &conn[size_t(pos) * npc];
+          int      lat[64][3];
+          for (int a = 0; a < npc; ++a)
+            {
+              int ai[3];
+              const int ext[3] = {np1, np1, np1};
+              split(a, ext, dim, ai);
+              for (int d = 0; d < 3; ++d)
+                lat[a][d] = d < dim ? ci[d] * p + ai[d] : 0;
+              const int64_t node = lat[a][0] + int64_t(nn[0]) * (lat[a][1] + int64_t(nn[1]) * lat[a][2]);
+              cn[a]              = int32_t(node);
+              // support point under the d-linear (Q1) map of the cell
+              double X[3] = {0, 0, 0};
+              for (int v = 0; v < nv; ++v)
+                {
+                  double w = 1.0;
+                  for (int d = 0; d < dim; ++d)
+                    {
+                      const double xi = nodes1[ai[d]];
+                      w *= ((v >> d) & 1) ? xi : 1.0 - xi;
+                    }
+                  for (int d = 0; d < dim; ++d)
+                    X[d] += w * cv[v * dim + d];
+                }
+              for (int d = 0; d < dim; ++d)
+                node_xyz[size_t(node) * dim + d] = X[d];
+            }
+          // scatter slots
+          uint16_t *co = &off[size_t(pos) * npc * npc];
+          for (int a = 0; a < npc; ++a)
+            {
+              int rlo[3] = {0, 0, 0}, rhi[3] = {0, 0, 0};
+              for (int d = 0; d < dim; ++d)
+                couple_range(d, lat[a][d], rlo[d], rhi[d]);
+              const int lx = rhi[0] - rlo[0] + 1, ly = rhi[1] - rlo[1] + 1;
+              for (int b = 0; b < npc; ++b)
+                co[a * npc + b] =
+                  uint16_t((lat[b][0] - rlo[0]) + lx * ((lat[b][1] - rlo[1]) + ly * (lat[b][2] - rlo[2])));
+            }
+          // boundary faces of this cell
+          for (int f = 0; f < 2 * dim; ++f)
+            {
+              const int  d    = f / 2;
+              const bool side = f & 1;
+              if (side ? (ci[d] != reps[d] - 1) : (ci[d] != 0))
+                continue;
+              const int role = face_role[f];
+              if (role == 0)
+                continue;
+              for (int a = 0; a < npc; ++a)
+                {
+                  int ai[3];
+                  const int ext[3] = {np1, np1, np1};
+                  split(a, ext, dim, ai);
+                  if (ai[d] != (side ? p : 0))
+                    continue;
+                  const int32_t node = cn[a];
+                  if (role == 1) // clamped: all components (:1107-1124)
+                    cmask[size_t(node)] |= uint8_t((1 << dim) - 1);
+                  else if (role == 8 && dim == 3) // out-of-plane: z only (:1126-1147)
+                    cmask[size_t(node)] |= 4;
+                  else if (role == 7)
+                    on_iface[size_t(node)] = 1;
+                }
+              if (role == 7)
+                faces_by_colour[colour_of_pos[size_t(pos)]].push_back({int32_t(pos), int32_t(f)});
+            }
+        }
+      iface_nodes.clear();
+      for (int64_t n = 0; n < nnodes; ++n)
+        if (on_iface[size_t(n)])
+          iface_nodes.push_back(int32_t(n));
+      iface_faces.clear();
+      iface_colour_begin.assign(1, 0);
+      for (int c = 0; c < ncolours; ++c)
+        {
+          iface_faces.insert(iface_faces.end(), faces_by_colour[c].begin(), faces_by_colour[c].end());
+          iface_colour_begin.push_back(int64_t(iface_faces.size()));
+        }
+    }
+  };
+} // namespace mi

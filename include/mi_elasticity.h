@@ -1,0 +1,181 @@
+/*
+ * mi_elasticity.h -- C-ABI of the MI355X-native structural-elasticity hot path.
+ *
+ * This is the drop-in boundary for the hot path of precice/dealii-adapter's nonlinear solver
+ * (source/nonlinear_elasticity/nonlinear_elasticity.cc): one Newmark step =
+ * Newton iterations x (cell tangent/residual assembly + CG) + Newmark vector updates.
+ * The host-side Solid<dim>/Adapter (dealii-adapter_amd/host/) call exactly these entry points at the
+ * sites cited below; nothing else crosses the boundary.  All device memory is owned by the opaque
+ * context; the host only passes interface-sized buffers and scalars (plain pointers + sizes).
+ *
+ * Conventions: every function returns MI_OK (0) or a negative MI_E* code; mi_last_error() gives text.
+ * One host thread per context; a context is not re-entrant.  DoF numbering is node-major:
+ * dof = dim*node + component; nodes are lexicographic (x fastest) on the (p*reps+1)^dim lattice.
+ */
+#ifndef MI_ELASTICITY_H
+#define MI_ELASTICITY_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OK 0
+#define MI_EINVAL (-1)      /* bad argument / unsupported (dim, degree)            */
+#define MI_EHIP (-2)        /* HIP runtime error                                   */
+#define MI_ENOCONV_LIN (-3) /* CG hit max iterations (SolverControl::NoConvergence) */
+#define MI_ENOCONV_NR (-4)  /* "No convergence in nonlinear solver!" (nonlinear_elasticity.cc:497) */
+#define MI_ECOMM (-5)       /* RCCL error                                          */
+
+/* role of each side of the box, order x-,x+,y-,y+,z-,z+ (deal.II colorize ids 0..5,
+ * nonlinear_elasticity.cc:237-241), values = the ids the reference relabels to (:255-278, .h:256-257) */
+#define MI_FACE_FREE 0
+#define MI_FACE_CLAMPED 1   /* clamped_boundary_id: u = 0                     */
+#define MI_FACE_INTERFACE 7 /* boundary_interface_id: coupling traction       */
+#define MI_FACE_ZCLAMP 8    /* out_of_plane_clamped_mesh_id: u_z = 0 (3D)     */
+
+typedef struct mi_ctx mi_ctx;
+
+/* replaces make_grid (nonlinear_elasticity.cc:171-301) + system_setup (:305-380) inputs */
+typedef struct
+{
+  int32_t       dim;       /* 2 or 3 (the reference's -DDIM, CMakeLists.txt:15-18)        */
+  int32_t       degree;    /* FE_Q degree ("Polynomial degree", parameters.cc:110-113)    */
+  int32_t       reps[3];   /* subdivided_hyper_rectangle repetitions                      */
+  double        lo[3], hi[3];
+  int32_t       face_role[6];
+  const double *vertex_perturbation; /* optional nverts*dim offsets (tests), else NULL    */
+} mi_mesh_desc;
+
+/* parameters.cc:35-50 */
+typedef struct
+{
+  double mu, nu, rho;
+  double body_force[3];
+} mi_material_desc;
+
+/* parameters.cc:120-125, parameters.cc:12-15; alpha_1..6 derived as nonlinear_elasticity.h:242-250 */
+typedef struct
+{
+  double beta, gamma, delta_t;
+} mi_newmark_desc;
+
+/* domain decomposition over the GPUs of one node; size==1 -> single GPU, unique_id ignored.
+ * The reference has no counterpart (adapter.h:152-154 hard-codes one rank). */
+typedef struct
+{
+  int32_t     rank, size;
+  const void *nccl_unique_id; /* 128-byte ncclUniqueId shared by all ranks */
+} mi_comm_desc;
+
+/* parameters.cc:61-99 ("Solver" subsection) */
+typedef struct
+{
+  double  tol_lin;            /* "Residual": CG stops at ||r|| <= tol_lin*||rhs||  (:1171-1172) */
+  double  max_iterations_lin; /* "Max iteration multiplier" (x n_dofs)             (:1169-1170) */
+  int32_t max_iterations_NR;  /* :436 */
+  double  tol_f, tol_u;       /* :459-463 */
+} mi_solver_desc;
+
+typedef struct
+{
+  int32_t newton_iterations; /* linear solves done                          */
+  int32_t assemblies;        /* = newton_iterations + 1 when converged      */
+  int32_t lin_its_total;
+  int32_t converged;
+  double  res_norm, res_abs, upd_norm, upd_abs; /* last Newton table row (:489-494) */
+  int32_t lin_its[16];       /* per Newton iteration (first 16)             */
+  double  lin_res[16];
+} mi_step_info;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int         mi_ctx_create(const mi_mesh_desc *mesh, const mi_material_desc *mat, const mi_newmark_desc *nm,
+                          int device_id, const mi_comm_desc *comm, mi_ctx **out);
+void        mi_ctx_destroy(mi_ctx *ctx);
+const char *mi_last_error(const mi_ctx *ctx); /* ctx may be NULL: error of the last failed create */
+
+/* ---- sizes / topology (global numbers, identical on every rank) --------------------------- */
+int64_t mi_n_dofs(const mi_ctx *ctx);
+int64_t mi_n_nodes(const mi_ctx *ctx);
+int64_t mi_n_cells(const mi_ctx *ctx);
+int64_t mi_nnz(const mi_ctx *ctx);   /* scalar non-zeros of the tangent (= dim^2 * stored blocks) */
+int     mi_n_colours(const mi_ctx *ctx);
+int     mi_get_node_coords(const mi_ctx *ctx, double *xyz /* n_nodes*dim */);
+int     mi_get_constrained(const mi_ctx *ctx, uint8_t *flags /* n_dofs */);
+
+/* ---- coupling interface: replaces Adapter::format_* (adapter.h:389-443) ------------------- */
+/* interface nodes = nodes on MI_FACE_INTERFACE sides in ascending node (= x-dof) order (adapter.h:313-321);
+ * coords interleaved [x0,y0,(z0),x1,...] exactly as passed to precice::setMeshVertices (adapter.h:305-326) */
+int mi_n_interface_nodes(const mi_ctx *ctx);
+int mi_get_interface_nodes(const mi_ctx *ctx, int32_t *node_ids, double *coords);
+/* external_stress[interface dofs] = vals (format_precice_to_deal, adapter.h:421-443); vals [x0,y0,(z0),...] */
+int mi_set_interface_traction(mi_ctx *ctx, int n, const double *vals);
+/* vals = total_displacement[interface dofs] (format_deal_to_precice, adapter.h:389-417) */
+int mi_get_interface_displacement(mi_ctx *ctx, int n, double *vals);
+
+/* ---- the hot path, piecewise (call sites in solve_nonlinear_timestep, :410-499) ----------- */
+int mi_newton_begin_step(mi_ctx *ctx);              /* solution_delta = 0 (:121); newton_update = 0 (:419) */
+int mi_update_acceleration(mi_ctx *ctx);            /* :444 -> :592-599                                   */
+int mi_assemble(mi_ctx *ctx, double *res_norm);     /* :446 -> :1044-1087 incl. Neumann :791-859, scatter
+                                                       :760-774; *res_norm = get_error_residual :549-560  */
+int mi_cg_solve(mi_ctx *ctx, double rel_tol, int64_t max_it, int *its, double *res);
+                                                    /* :472 -> :1153-1191 (Jacobi-PCG, warm start) + :1208 */
+int mi_apply_newton_update(mi_ctx *ctx, double *upd_norm); /* get_error_update :564-576; delta += update :487 */
+int mi_newmark_finish_step(mi_ctx *ctx);            /* :139-144: u += delta; a, v updates; old := new      */
+/* the whole of solve_nonlinear_timestep + :139-144 with the reference's convergence logic */
+int mi_newmark_step(mi_ctx *ctx, const mi_solver_desc *s, mi_step_info *info);
+
+/* implicit-coupling checkpoint of the 6 state vectors (adapter.h:447-489), device-to-device */
+int mi_state_save(mi_ctx *ctx);
+int mi_state_restore(mi_ctx *ctx);
+
+/* ---- inspection hooks (tests, bench) ------------------------------------------------------ */
+enum
+{
+  MI_V_TOTAL_DISPLACEMENT = 0,
+  MI_V_TOTAL_DISPLACEMENT_OLD,
+  MI_V_VELOCITY,
+  MI_V_VELOCITY_OLD,
+  MI_V_ACCELERATION,
+  MI_V_ACCELERATION_OLD,
+  MI_V_EXTERNAL_STRESS,
+  MI_V_SOLUTION_DELTA,
+  MI_V_NEWTON_UPDATE,
+  MI_V_SYSTEM_RHS,
+  MI_V_COUNT
+};
+int mi_vec_get(mi_ctx *ctx, int which, double *host, int64_t n);
+int mi_vec_set(mi_ctx *ctx, int which, const double *host, int64_t n);
+/* tangent as scalar CSR (host arrays: rowptr n_dofs+1 (int64), col nnz (int32), val nnz) */
+int mi_matrix_get_csr(mi_ctx *ctx, int64_t *rowptr, int32_t *col, double *val);
+int mi_spmv(mi_ctx *ctx, const double *x_host, double *y_host); /* y = K x through the device kernel */
+
+/* per-kernel-class device timings from HIP events on the context's stream */
+enum
+{
+  MI_T_ASSEMBLE_CELLS = 0, /* all colours of one assembly                     */
+  MI_T_ASSEMBLE_TOTAL,     /* memset + cells + faces + diag + norm            */
+  MI_T_SPMV,
+  MI_T_CG_VECTOR,          /* the two fused vector kernels of a CG iteration  */
+  MI_T_CG_TOTAL,
+  MI_T_NEWMARK,
+  MI_T_STEP,               /* whole mi_newmark_step                           */
+  MI_T_COUNT
+};
+typedef struct
+{
+  double  ms[MI_T_COUNT];    /* accumulated milliseconds   */
+  int64_t count[MI_T_COUNT]; /* launches / calls           */
+} mi_timings;
+int mi_set_profiling(mi_ctx *ctx, int enable);
+int mi_reset_timings(mi_ctx *ctx);
+int mi_get_timings(mi_ctx *ctx, mi_timings *out);
+/* isolated kernel benches on the current matrix/state: average ms per launch over reps */
+int mi_bench_spmv(mi_ctx *ctx, int reps, double *ms_per_launch);
+int mi_bench_assemble(mi_ctx *ctx, int reps, double *ms_per_assembly);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ELASTICITY_H */

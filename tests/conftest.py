@@ -24,3 +24,17 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def load_pkg():
+    """import dealii-adapter_amd/ (the directory name is not a valid module name) as dealii_adapter_amd"""
+    import importlib.util
+    name = "dealii_adapter_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, "dealii-adapter_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod

@@ -1,0 +1,53 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every entry
+point declared in include/mi_elasticity.h, and refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+from conftest import load_pkg
+
+M = load_pkg()
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(M.LIB_PATH):
+        M.build()
+    return M.lib()
+
+
+def test_header_symbols_are_exported(built):
+    syms = M.declared_symbols()
+    assert len(syms) >= 30 and "mi_newmark_step" in syms and "mi_cg_solve" in syms
+    missing = [s for s in syms if not hasattr(built, s)]
+    assert missing == []
+
+
+def test_library_has_gfx950_code_object():
+    blob = open(M.LIB_PATH, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90"):  # gfx950 only, no dual paths
+        assert other not in blob
+
+
+def test_no_cpu_fallback_without_device(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(M.MiError) as e:
+        M.Context(dim=3, degree=1, reps=(2, 2, 2))
+    assert e.value.code == M.MI_EHIP
+    assert "no HIP device" in str(e.value)
+
+
+def test_product_does_not_reference_the_oracle(built):
+    """the shipped library and its sources never link, load or mention oracle/"""
+    for root, _, files in os.walk(M.PKG_DIR):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".hpp", ".py", ".cc")) or f == "Makefile":
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                assert "liboracle" not in txt and "elasticity_oracle" not in txt, os.path.join(root, f)
+    deps = subprocess.run(["ldd", M.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in deps
