@@ -553,7 +553,8 @@ namespace mi
   }
 
   // ------------------------------------------------------------------ Neumann faces (:791-859)
-  // one 64-thread workgroup per interface face of the current colour
+  // one 64-thread workgroup per cell of the current colour that owns interface faces; the cell's faces are
+  // processed one after the other (faces of one cell share edge/corner nodes, cells of one colour do not)
   template <int DIM, int P>
   __global__ __launch_bounds__(64) void neumann_faces(AsmParams prm, const int32_t *__restrict__ faces, int face_begin)
   {
@@ -564,7 +565,7 @@ namespace mi
     __shared__ int    s_conn[NPC];
     __shared__ double s_fq[NQF * 4]; // per face QP: referential traction (3) and unused
     const int     tid  = threadIdx.x;
-    const int32_t cell = faces[2 * (face_begin + blockIdx.x)], f = faces[2 * (face_begin + blockIdx.x) + 1];
+    const int32_t cell = faces[2 * (face_begin + blockIdx.x)], fmask = faces[2 * (face_begin + blockIdx.x) + 1];
     for (int i = tid; i < NQ1 * NP1; i += 64)
       {
         s_N1[i]  = prm.tab1d[i];
@@ -595,6 +596,10 @@ namespace mi
       }
     __syncthreads();
 
+    for (int f = 0; f < 2 * DIM; ++f)
+      {
+    if (!((fmask >> f) & 1))
+      continue;
     const int nd = f >> 1, side = f & 1;
     // face-local axes [DEAL.II, recalled]: x-normal (y,z); y-normal (z,x) in 3D, (x) in 2D; z-normal (x,y)
     int ax0, ax1;
@@ -723,6 +728,8 @@ namespace mi
         const int32_t A = s_conn[a];
         if (!((prm.cmask[A] >> c) & 1))
           prm.rhs[int64_t(A) * DIM + c] += s;
+      }
+    __syncthreads(); // s_fq is reused by the next face
       }
   }
 

@@ -161,7 +161,7 @@ namespace mi
   struct InterfaceFace
   {
     int32_t cell; // colour-sorted cell position
-    int32_t face; // 0..2*dim-1  (x-,x+,y-,y+,z-,z+)
+    int32_t face; // bit f set: side f (x-,x+,y-,y+,z-,z+) of the cell is an interface face
   };
 
   struct HostMesh
@@ -388,6 +388,7 @@ namespace mi
                   uint16_t((lat[b][0] - rlo[0]) + lx * ((lat[b][1] - rlo[1]) + ly * (lat[b][2] - rlo[2])));
             }
           // boundary faces of this cell
+          int iface_mask = 0;
           for (int f = 0; f < 2 * dim; ++f)
             {
               const int  d    = f / 2;
@@ -413,8 +414,10 @@ namespace mi
                     on_iface[size_t(node)] = 1;
                 }
               if (role == 7)
-                faces_by_colour[colour_of_pos[size_t(pos)]].push_back({int32_t(pos), int32_t(f)});
+                iface_mask |= 1 << f;
             }
+          if (iface_mask)
+            faces_by_colour[colour_of_pos[size_t(pos)]].push_back({int32_t(pos), int32_t(iface_mask)});
         }
       iface_nodes.clear();
       for (int64_t n = 0; n < nnodes; ++n)
