@@ -167,7 +167,7 @@ def main():
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
             },
             "roofline": {
-                "kernel": "bsr_spmv<3> (CG matrix-vector product)",
+                "kernel": "sell_spmv<3,2> (CG matrix-vector product, sliced-ELL copy of the block-CSR tangent)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -107,6 +107,8 @@ def lib():
         L.mi_spmv.argtypes = [vp, dp, dp]
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.mi_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
+        L.mi_set_tuning.restype = C.c_int
         L.mi_bench_spmv.argtypes = [vp, C.c_int, dp]
         L.mi_bench_assemble.argtypes = [vp, C.c_int, dp]
         for f in ("mi_get_node_coords", "mi_get_constrained", "mi_get_interface_nodes", "mi_set_interface_traction",
@@ -272,6 +274,9 @@ class Context:
 
     def set_profiling(self, on=True):
         self._chk(lib().mi_set_profiling(self.h, int(on)))
+
+    def set_tuning(self, key, value):
+        self._chk(lib().mi_set_tuning(self.h, key.encode(), int(value)))
 
     def reset_timings(self):
         self._chk(lib().mi_reset_timings(self.h))

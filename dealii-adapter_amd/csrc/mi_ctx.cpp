@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,7 +23,7 @@ namespace
 {
   std::string g_create_error;
 
-  constexpr int MAX_PART = 4096; // upper bound of per-workgroup reduction partials
+  constexpr int MAX_PART = 16384; // upper bound of per-workgroup reduction partials
   constexpr int CG_BATCH = 16;   // CG iterations enqueued between two host polls of the convergence flag
 
   enum
@@ -54,6 +55,9 @@ struct mi_ctx
           *d_faces = nullptr, *d_flags = nullptr;
   double   *d_cverts = nullptr, *d_tab = nullptr, *d_vals = nullptr, *d_vecs = nullptr, *d_work = nullptr,
          *d_saved = nullptr, *d_part = nullptr, *d_sc = nullptr, *d_iface_buf = nullptr;
+  int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr;
+  int64_t  *d_sell_off = nullptr;
+  double   *d_sell_vals = nullptr;
   uint16_t *d_off   = nullptr;
   uint8_t  *d_cmask = nullptr;
   double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
@@ -61,6 +65,7 @@ struct mi_ctx
   bool      have_saved = false;
 
   int grid_vec = 0, grid_spmv = 0;
+  int spmv_variant = 3, maxrow = 0, sell_unroll = 2, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
 
   // profiling
   bool profiling = false;
@@ -214,7 +219,38 @@ namespace
     p.done     = done;
     p.row0     = 0;
     p.nrows    = c->mesh.nnodes;
+    p.rowptr_host_nnzb = c->mesh.nnzb;
     return p;
+  }
+
+  mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
+                             const int32_t *done)
+  {
+    mi::SellParams p{};
+    p.perm     = c->d_sell_perm;
+    p.len      = c->d_sell_len;
+    p.off      = c->d_sell_off;
+    p.col      = c->d_sell_col;
+    p.vals     = c->d_sell_vals;
+    p.x        = x;
+    p.y        = y;
+    p.dotv     = dotv;
+    p.partials = partials;
+    p.done     = done;
+    p.nslices  = int32_t(c->mesh.sell_nslices);
+    p.xcd_remap = c->xcd_remap;
+    return p;
+  }
+
+  // y = K x (+ optional fused dot partials) with the selected kernel variant
+  void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done)
+  {
+    if (c->spmv_variant == 3)
+      mi::launch_sell_spmv(c->dim, sell_params(c, x, y, dotv, partials, done), c->grid_spmv, c->stream,
+                           c->sell_unroll);
+    else
+      mi::launch_spmv(c->dim, spmv_params(c, x, y, dotv, partials, done), c->grid_spmv, c->stream, c->spmv_variant,
+                      c->maxrow);
   }
 
   // the enqueue part of assemble_system (no host synchronisation)
@@ -238,6 +274,9 @@ namespace
       }
     toc(c, t0);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
+    // SpMV-side copy of the tangent in sliced-ELL order
+    mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
+                           c->d_sell_vals, c->stream);
     HIPCHK(c, hipGetLastError());
     return MI_OK;
   }
@@ -264,7 +303,8 @@ void mi_ctx_destroy(mi_ctx *c)
     }
   void *ptrs[] = {c->d_conn, c->d_rowptr, c->d_col,  c->d_diagpos, c->d_iface_nodes, c->d_faces, c->d_flags,
                   c->d_cverts, c->d_tab, c->d_vals, c->d_vecs, c->d_work, c->d_saved, c->d_part,
-                  c->d_sc, c->d_iface_buf, c->d_off, c->d_cmask};
+                  c->d_sc, c->d_iface_buf, c->d_off, c->d_cmask, c->d_sell_perm, c->d_sell_len, c->d_sell_col,
+                  c->d_sell_off, c->d_sell_vals};
   for (void *p : ptrs)
     if (p)
       hipFree(p);
@@ -371,7 +411,12 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   }
   CREATE_CHK(upload(c, &c->d_tab, c->tab.packed()));
   const size_t dd = size_t(c->dim) * c->dim;
-  CREATE_HIP(hipMalloc((void **)&c->d_vals, size_t(m.nnzb) * dd * sizeof(double)));
+  CREATE_HIP(hipMalloc((void **)&c->d_vals, (size_t(m.nnzb) * dd + 2) * sizeof(double))); // +2: 16-byte row reads
+  CREATE_CHK(upload(c, &c->d_sell_perm, m.sell_perm));
+  CREATE_CHK(upload(c, &c->d_sell_len, m.sell_len));
+  CREATE_CHK(upload(c, &c->d_sell_off, m.sell_off));
+  CREATE_HIP(hipMalloc((void **)&c->d_sell_col, size_t(m.sell_nblk64) * 64 * sizeof(int32_t)));
+  CREATE_HIP(hipMalloc((void **)&c->d_sell_vals, size_t(m.sell_nblk64) * 64 * dd * sizeof(double)));
   CREATE_HIP(hipMalloc((void **)&c->d_vecs, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double)));
   CREATE_HIP(hipMalloc((void **)&c->d_work, size_t(W_COUNT) * size_t(c->n) * sizeof(double)));
   CREATE_HIP(hipMalloc((void **)&c->d_saved, size_t(6) * size_t(c->n) * sizeof(double)));
@@ -387,16 +432,20 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   CREATE_HIP(hipMemsetAsync(c->d_work, 0, size_t(W_COUNT) * size_t(c->n) * sizeof(double), c->stream));
   CREATE_HIP(hipMemsetAsync(c->d_sc, 0, 16 * sizeof(double), c->stream));
   CREATE_HIP(hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int32_t), c->stream));
+  CREATE_HIP(hipMemsetAsync(c->d_sell_vals, 0, size_t(m.sell_nblk64) * 64 * dd * sizeof(double), c->stream));
+  mi::launch_sell_build_cols(sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_col,
+                             c->d_sell_col, c->stream);
+  CREATE_HIP(hipGetLastError());
   CREATE_HIP(hipStreamSynchronize(c->stream));
 
   // launch geometry: vector kernels and SpMV use fixed grids so that reduction partials are deterministic
   c->grid_vec = int(std::min<int64_t>(1024, (c->n + 255) / 256));
-  {
-    int64_t g = std::min<int64_t>(2048, (m.nnodes + 3) / 4);
-    if (g >= 8)
-      g -= g % 8; // multiple of 8 for the XCD-contiguous row mapping
-    c->grid_spmv = int(std::max<int64_t>(1, g));
-  }
+  // SpMV: one wavefront per 64-row slice (measured best), grid-stride above MAX_PART workgroups
+  c->grid_spmv = int(std::max<int64_t>(1, std::min<int64_t>(MAX_PART, (m.sell_nslices + 3) / 4)));
+  for (int64_t nd = 0; nd < m.nnodes; ++nd)
+    c->maxrow = std::max(c->maxrow, int(m.rowptr[size_t(nd) + 1] - m.rowptr[size_t(nd)]));
+  if (const char *v = getenv("MI_SPMV_VARIANT"))
+    c->spmv_variant = atoi(v);
   *out = c;
   return MI_OK;
 #undef CREATE_CHK
@@ -548,7 +597,7 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
   {
     const int t = tic(c, MI_T_SPMV);
-    mi::launch_spmv(c->dim, spmv_params(c, x, cg.q, nullptr, nullptr, nullptr), c->grid_spmv, c->stream);
+    enqueue_spmv(c, x, cg.q, nullptr, nullptr, nullptr);
     toc(c, t);
   }
   mi::launch_cg_init_residual(cg, c->vec(MI_V_SYSTEM_RHS), c->part(4), c->grid_vec, c->stream);
@@ -567,7 +616,7 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
           mi::launch_cg_update_p(cg, int(it), c->grid_vec, c->stream);
           toc(c, t);
           t = tic(c, MI_T_SPMV);
-          mi::launch_spmv(c->dim, spmv_params(c, cg.p, cg.q, cg.p, cg.part_pq, cg.flags), c->grid_spmv, c->stream);
+          enqueue_spmv(c, cg.p, cg.q, cg.p, cg.part_pq, cg.flags);
           toc(c, t);
           t = tic(c, MI_T_CG_VECTOR);
           mi::launch_cg_update_xr(cg, int(it), c->grid_vec, c->stream);
@@ -766,11 +815,26 @@ int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->work(W_P), x_host, size_t(c->n) * sizeof(double), hipMemcpyHostToDevice));
-  mi::launch_spmv(c->dim, spmv_params(c, c->work(W_P), c->work(W_Q), nullptr, nullptr, nullptr), c->grid_spmv,
-                  c->stream);
+  enqueue_spmv(c, c->work(W_P), c->work(W_Q), nullptr, nullptr, nullptr);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(y_host, c->work(W_Q), size_t(c->n) * sizeof(double), hipMemcpyDeviceToHost));
+  return MI_OK;
+}
+
+int mi_set_tuning(mi_ctx *c, const char *key, int value)
+{
+  const std::string k(key ? key : "");
+  if (k == "spmv_variant" && (value == 1 || value == 3 || (value >= 11 && value <= 14)))
+    c->spmv_variant = value;
+  else if (k == "xcd_remap" && (value == 0 || value == 1))
+    c->xcd_remap = value;
+  else if (k == "sell_unroll" && value >= -2 && value <= 4 && value != 0)
+    c->sell_unroll = value;
+  else if (k == "spmv_grid" && value >= 1 && value <= MAX_PART)
+    c->grid_spmv = value;
+  else
+    return fail(c, MI_EINVAL, "unknown tuning key '%s' or value %d out of range", k.c_str(), value);
   return MI_OK;
 }
 
@@ -798,11 +862,10 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
   hipEvent_t a, b;
   HIPCHK(c, hipEventCreate(&a));
   HIPCHK(c, hipEventCreate(&b));
-  const mi::SpmvParams p = spmv_params(c, c->work(W_P), c->work(W_Q), c->work(W_P), c->part(2), nullptr);
-  mi::launch_spmv(c->dim, p, c->grid_spmv, c->stream); // warm-up
+  enqueue_spmv(c, c->work(W_P), c->work(W_Q), c->work(W_P), c->part(2), nullptr); // warm-up
   HIPCHK(c, hipEventRecord(a, c->stream));
   for (int i = 0; i < reps; ++i)
-    mi::launch_spmv(c->dim, p, c->grid_spmv, c->stream);
+    enqueue_spmv(c, c->work(W_P), c->work(W_Q), c->work(W_P), c->part(2), nullptr);
   HIPCHK(c, hipEventRecord(b, c->stream));
   HIPCHK(c, hipEventSynchronize(b));
   float ms = 0;

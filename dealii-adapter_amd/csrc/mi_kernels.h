@@ -34,6 +34,24 @@ namespace mi
     double        *partials; // [grid]
     const int32_t *done;     // optional early-exit flag
     int64_t        row0, nrows;
+    int64_t        rowptr_host_nnzb; // number of stored blocks (timing-only stream kernels)
+  };
+
+  // sliced-ELL SpMV (see mi_kernels.hip)
+  struct SellParams
+  {
+    const int32_t *perm; // [nslices*64]
+    const int32_t *len;  // [nslices]
+    const int64_t *off;  // [nslices+1]
+    const int32_t *col;  // [nblk64*64]
+    const double  *vals; // [nblk64*DD*64]
+    const double  *x;
+    double        *y;
+    const double  *dotv;
+    double        *partials;
+    const int32_t *done;
+    int32_t        nslices;
+    int32_t        xcd_remap; // 1: workgroups of one XCD take a contiguous eighth of the slices (measured slower)
   };
 
   struct CgParams
@@ -58,7 +76,12 @@ namespace mi
   int  launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s);
   int  launch_neumann_faces(int dim, int degree, const AsmParams &p, const int32_t *faces, int face_begin,
                             int face_count, hipStream_t s);
-  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s);
+  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
+  void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
+  void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
+                          double *sell_vals, hipStream_t s);
+  void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
+                              hipStream_t s);
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s);
   void launch_cg_update_xr(const CgParams &c, int it, int grid, hipStream_t s);
   void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s);

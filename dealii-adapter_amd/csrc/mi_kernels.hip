@@ -4,7 +4,8 @@
 //                      cell, scattered into the block-CSR by graph colouring
 //                      (nonlinear_elasticity.cc:872-1036 + :760-774; maths restated in DESIGN.md section 4)
 //   neumann_faces    : interface traction with area pull-back incl. the reference's cell-QP quirk (:791-859)
-//   bsr_spmv         : y = K x on dim x dim blocks, one wavefront per block row, fused dot product
+//   sell_spmv        : y = K x on the sliced-ELL copy of the tangent (lane = row), fused dot product
+//   bsr_spmv_mlp     : y = K x directly on the block-CSR (cross-check / baseline)
 //   cg_* / vec_*     : fused CG vector updates with deterministic two-level reductions (:1153-1191)
 //   newmark_*        : Newmark predictor/corrector vector updates (:592-622)
 #include <hip/hip_runtime.h>
@@ -733,13 +734,14 @@ namespace mi
       }
   }
 
-  // ------------------------------------------------------------------ block-CSR SpMV
-  // One wavefront per block row; lane = (block slot kb, entry e) so that a wave reads 64/DD whole blocks
-  // (504 or 512 contiguous bytes) per step.  Workgroups are renumbered so that the 8 XCDs own contiguous
-  // eighths of the rows (x stays in the XCD's L2).  Optional fused dot product with `dotv`, written as
-  // one partial per workgroup (deterministic two-level reduction).
-  template <int D>
-  __global__ __launch_bounds__(256) void bsr_spmv(SpmvParams prm)
+  // ------------------------------------------------------------------ block-CSR SpMV (cross-check variant)
+  // y = K x directly on the block-CSR: one wavefront per block row, lane = (block slot kb, entry e), so a wave
+  // reads 64/DD whole blocks (504 or 512 contiguous bytes) per step; the loads of up to MAXSTEPS steps are all
+  // issued before the first use.  Kept as an independent implementation to cross-check the sliced-ELL kernel
+  // (tests) and as the measured baseline in profiles/ (2.1 ms vs 1.45 ms at 5M DoFs).
+  // ABL (timing-only ablations, results wrong): 1 = x index independent of the column, 2 = no column / x loads
+  template <int D, int MAXSTEPS, int ABL = 0>
+  __global__ __launch_bounds__(256) void bsr_spmv_mlp(SpmvParams prm)
   {
     if (prm.done && *prm.done)
       return;
@@ -747,7 +749,7 @@ namespace mi
     __shared__ double s_red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwg = gridDim.x, b = blockIdx.x;
-    const int lb  = (nwg % 8 == 0) ? (b % 8) * (nwg / 8) + b / 8 : b;
+    const int lb  = b;
     const int64_t per = (prm.nrows + nwg - 1) / nwg;
     const int64_t r0 = prm.row0 + lb * per, r1 = imin64(prm.row0 + prm.nrows, r0 + per);
     const int     kb = lane / DD, e = lane - kb * DD, i = e / D, j = e - i * D;
@@ -755,24 +757,44 @@ namespace mi
     double        dsum = 0.0;
     for (int64_t row = r0 + wave; row < r1; row += 4)
       {
-        const int s = prm.rowptr[row], t = prm.rowptr[row + 1];
-        double    acc0 = 0.0, acc1 = 0.0;
-        if (act)
+        const int rr = __builtin_amdgcn_readfirstlane(int(row));
+        const int s = prm.rowptr[rr], nb = prm.rowptr[rr + 1] - s;
+        double    sacc = 0.0;
+        for (int base = 0; base < nb; base += MAXSTEPS * BPW)
           {
-            int k = s + kb;
-            for (; k + BPW < t; k += 2 * BPW)
+            const int32_t *__restrict__ cp = prm.col + s + base + kb;
+            const double *__restrict__ vp  = prm.vals + int64_t(s + base) * DD + lane;
+            int32_t c[MAXSTEPS];
+            double  v[MAXSTEPS], xv[MAXSTEPS];
+#pragma unroll
+            for (int st = 0; st < MAXSTEPS; ++st)
               {
-                const double  v0 = prm.vals[int64_t(k) * DD + e];
-                const double  v1 = prm.vals[int64_t(k + BPW) * DD + e];
-                const int32_t c0 = prm.col[k], c1 = prm.col[k + BPW];
-                acc0 += v0 * prm.x[int64_t(c0) * D + j];
-                acc1 += v1 * prm.x[int64_t(c1) * D + j];
+                const bool ok = act && (base + st * BPW + kb < nb);
+                if constexpr (ABL == 2)
+                  c[st] = ok ? 0 : -1;
+                else
+                  c[st] = ok ? cp[st * BPW] : -1;
               }
-            if (k < t)
-              acc0 += prm.vals[int64_t(k) * DD + e] * prm.x[int64_t(prm.col[k]) * D + j];
+#pragma unroll
+            for (int st = 0; st < MAXSTEPS; ++st)
+              v[st] = (c[st] >= 0) ? vp[st * BPW * DD] : 0.0;
+#pragma unroll
+            for (int st = 0; st < MAXSTEPS; ++st)
+              {
+                if constexpr (ABL == 0)
+                  xv[st] = (c[st] >= 0) ? prm.x[int64_t(c[st]) * D + j] : 0.0;
+                else if constexpr (ABL == 1)
+                  {
+                    asm volatile("" ::"v"(c[st]));
+                    xv[st] = (c[st] >= 0) ? prm.x[(row + st) * D + j] : 0.0;
+                  }
+                else
+                  xv[st] = 1.0;
+              }
+#pragma unroll
+            for (int st = 0; st < MAXSTEPS; ++st)
+              sacc += v[st] * xv[st];
           }
-        double sacc = acc0 + acc1;
-        // sum over j (adjacent lanes), then over block slots (stride DD lanes)
         if constexpr (D == 3)
           {
             const double t1 = __shfl_down(sacc, 1, 64), t2 = __shfl_down(sacc, 2, 64);
@@ -800,6 +822,185 @@ namespace mi
         if (threadIdx.x == 0)
           prm.partials[b] = tot;
       }
+  }
+
+  // ------------------------------------------------------------------ sliced-ELL SpMV (production variant)
+  // The block pattern of a box mesh has only dim+1 distinct row lengths, so rows are grouped by length into
+  // slices of 64 rows without padding inside a slice.  Layout: col[(off+k)*64 + lane],
+  // vals[((off+k)*DD + e)*64 + lane] -> every load of a wave is one contiguous 512-byte (256-byte for col)
+  // segment, lane = row, so there is no cross-lane reduction and neighbouring rows gather neighbouring x.
+  // One wavefront per slice (grid-stride), U blocks in flight per lane.
+  // ABL (timing only): 1 = x read at a coalesced slot-based index, 2 = no column / x loads
+  template <int D, int U, int ABL = 0>
+  __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
+  {
+    if (prm.done && *prm.done)
+      return;
+    constexpr int DD = D * D;
+    __shared__ double s_red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwg = gridDim.x, b = blockIdx.x;
+    const int lb  = (prm.xcd_remap && nwg % 8 == 0) ? (b % 8) * (nwg / 8) + b / 8 : b;
+    const int per = (prm.nslices + nwg - 1) / nwg;
+    const int s0 = lb * per, s1 = min(prm.nslices, s0 + per);
+    double    dsum = 0.0;
+    for (int sl0 = s0 + wave; sl0 < s1; sl0 += 4)
+      {
+        const int     sl  = __builtin_amdgcn_readfirstlane(sl0);
+        const int     len = prm.len[sl];
+        const int64_t off = prm.off[sl];
+        const int     node = prm.perm[int64_t(sl) * 64 + lane];
+        const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
+        const double *__restrict__ vp  = prm.vals + off * (DD * 64) + lane;
+        double acc[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          acc[i] = 0.0;
+        int k = 0;
+        for (; k + U <= len; k += U)
+          {
+            int32_t c[U];
+            double  v[U][DD], xx[U][D];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              c[u] = (ABL == 2) ? 0 : cp[int64_t(k + u) * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int e = 0; e < DD; ++e)
+                v[u][e] = vp[(int64_t(k + u) * DD + e) * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                {
+                  if constexpr (ABL == 1)
+                    {
+                      asm volatile("" ::"v"(c[u]));
+                      xx[u][j] = prm.x[(int64_t(sl) * 64 + lane) * D + j];
+                    }
+                  else if constexpr (ABL == 2)
+                    xx[u][j] = 1.0;
+                  else
+                    xx[u][j] = prm.x[int64_t(c[u]) * D + j];
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                  acc[i] += v[u][i * D + j] * xx[u][j];
+          }
+        for (; k < len; ++k)
+          {
+            const int32_t c = cp[int64_t(k) * 64];
+            double        v[DD], xx[D];
+#pragma unroll
+            for (int e = 0; e < DD; ++e)
+              v[e] = vp[(int64_t(k) * DD + e) * 64];
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              xx[j] = prm.x[int64_t(c) * D + j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                acc[i] += v[i * D + j] * xx[j];
+          }
+        if (node >= 0)
+          {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+              {
+                prm.y[int64_t(node) * D + i] = acc[i];
+                if (prm.dotv)
+                  dsum += acc[i] * prm.dotv[int64_t(node) * D + i];
+              }
+          }
+      }
+    if (prm.partials)
+      {
+        const double tot = block_sum<256>(dsum, s_red);
+        if (threadIdx.x == 0)
+          prm.partials[b] = tot;
+      }
+  }
+
+  // block-CSR -> sliced-ELL copy of the values (after every assembly); one wavefront per slice
+  template <int D>
+  __global__ __launch_bounds__(256) void bsr_to_sell(SellParams prm, const int32_t *__restrict__ rowptr,
+                                                     const double *__restrict__ bsr_vals, double *sell_vals)
+  {
+    constexpr int DD = D * D;
+    const int     sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sl >= prm.nslices)
+      return;
+    const int     node = prm.perm[int64_t(sl) * 64 + lane];
+    if (node < 0)
+      return; // padding rows stay zero
+    const int     len = prm.len[sl];
+    const int64_t off = prm.off[sl];
+    const double *__restrict__ src = bsr_vals + int64_t(rowptr[node]) * DD;
+    double *__restrict__ dst       = sell_vals + off * (DD * 64) + lane;
+    for (int k = 0; k < len; ++k)
+      {
+        double v[DD];
+#pragma unroll
+        for (int e = 0; e < DD; ++e)
+          v[e] = src[k * DD + e];
+#pragma unroll
+        for (int e = 0; e < DD; ++e)
+          dst[(int64_t(k) * DD + e) * 64] = v[e];
+      }
+  }
+
+  // one-off: sliced-ELL column indices from the block-CSR pattern (padding rows point at column 0)
+  __global__ __launch_bounds__(256) void sell_build_cols(SellParams prm, const int32_t *__restrict__ rowptr,
+                                                         const int32_t *__restrict__ bsr_col, int32_t *sell_col)
+  {
+    const int sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sl >= prm.nslices)
+      return;
+    const int     node = prm.perm[int64_t(sl) * 64 + lane];
+    const int     len  = prm.len[sl];
+    const int64_t off  = prm.off[sl];
+    for (int k = 0; k < len; ++k)
+      sell_col[(off + k) * 64 + lane] = node >= 0 ? bsr_col[rowptr[node] + k] : 0;
+  }
+
+  // timing-only: stream the value array with W-byte loads per lane (W = 8 or 16), one partial per workgroup
+  template <int W>
+  __global__ __launch_bounds__(256) void stream_read(const double *__restrict__ v, int64_t n, double *partials)
+  {
+    __shared__ double s_red[4];
+    const int64_t per = ((n / gridDim.x) / 512) * 512;
+    const int64_t i0  = int64_t(blockIdx.x) * per;
+    double        s   = 0.0;
+    if constexpr (W == 16)
+      {
+        const double2 *__restrict__ p = reinterpret_cast<const double2 *>(v + i0);
+        for (int64_t i = threadIdx.x; i < per / 2; i += 1024)
+          {
+            const double2 a = p[i], b = (i + 256 < per / 2) ? p[i + 256] : make_double2(0, 0);
+            const double2 c = (i + 512 < per / 2) ? p[i + 512] : make_double2(0, 0);
+            const double2 d = (i + 768 < per / 2) ? p[i + 768] : make_double2(0, 0);
+            s += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
+          }
+      }
+    else
+      {
+        const double *__restrict__ p = v + i0;
+        for (int64_t i = threadIdx.x; i < per; i += 1024)
+          {
+            const double a = p[i], b = (i + 256 < per) ? p[i + 256] : 0.0;
+            const double c = (i + 512 < per) ? p[i + 512] : 0.0, d = (i + 768 < per) ? p[i + 768] : 0.0;
+            s += a + b + c + d;
+          }
+      }
+    s = block_sum<256>(s, s_red);
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = s;
   }
 
   // ------------------------------------------------------------------ CG vector kernels (Jacobi-PCG)
@@ -1085,12 +1286,86 @@ namespace mi
     return -1;
   }
 
-  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s)
+  template <int D>
+  static void launch_spmv_d(const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow)
+  {
+    constexpr int DD = D * D, BPW = 64 / DD;
+    if (variant == 1)
+      {
+        const int steps = (maxrow + BPW - 1) / BPW;
+#define MI_MLP(N_)                                                                                   \
+  if (steps <= N_)                                                                                   \
+    {                                                                                                \
+      hipLaunchKernelGGL((bsr_spmv_mlp<D, N_>), dim3(grid), dim3(256), 0, s, p);                     \
+      return;                                                                                        \
+    }
+        MI_MLP(1) MI_MLP(2) MI_MLP(4) MI_MLP(6) MI_MLP(10) MI_MLP(18)
+#undef MI_MLP
+        hipLaunchKernelGGL((bsr_spmv_mlp<D, 18>), dim3(grid), dim3(256), 0, s, p);
+        return;
+      }
+    if (variant == 11 || variant == 12) // ablations of the mlp kernel (timing only)
+      {
+        if (variant == 11)
+          hipLaunchKernelGGL((bsr_spmv_mlp<D, 18, 1>), dim3(grid), dim3(256), 0, s, p);
+        else
+          hipLaunchKernelGGL((bsr_spmv_mlp<D, 18, 2>), dim3(grid), dim3(256), 0, s, p);
+        return;
+      }
+    if (variant == 13 || variant == 14) // pure streaming read of the value array, 8- / 16-byte loads
+      {
+        const int64_t nvals = int64_t(p.rowptr_host_nnzb) * DD;
+        if (variant == 13)
+          hipLaunchKernelGGL((stream_read<8>), dim3(grid), dim3(256), 0, s, p.vals, nvals, p.y);
+        else
+          hipLaunchKernelGGL((stream_read<16>), dim3(grid), dim3(256), 0, s, p.vals, nvals, p.y);
+        return;
+      }
+    hipLaunchKernelGGL((bsr_spmv_mlp<D, 18>), dim3(grid), dim3(256), 0, s, p);
+  }
+
+  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow)
   {
     if (dim == 3)
-      hipLaunchKernelGGL((bsr_spmv<3>), dim3(grid), dim3(256), 0, s, p);
+      launch_spmv_d<3>(p, grid, s, variant, maxrow);
     else
-      hipLaunchKernelGGL((bsr_spmv<2>), dim3(grid), dim3(256), 0, s, p);
+      launch_spmv_d<2>(p, grid, s, variant, maxrow);
+  }
+
+  void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
+  {
+    if (dim == 3)
+      {
+        if (unroll >= 4)
+          hipLaunchKernelGGL((sell_spmv<3, 4>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == 3)
+          hipLaunchKernelGGL((sell_spmv<3, 3>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == 2)
+          hipLaunchKernelGGL((sell_spmv<3, 2>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == -1)
+          hipLaunchKernelGGL((sell_spmv<3, 2, 1>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == -2)
+          hipLaunchKernelGGL((sell_spmv<3, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+
+        else
+          hipLaunchKernelGGL((sell_spmv<3, 1>), dim3(grid), dim3(256), 0, s, p);
+      }
+    else
+      hipLaunchKernelGGL((sell_spmv<2, 4>), dim3(grid), dim3(256), 0, s, p);
+  }
+  void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
+                          double *sell_vals, hipStream_t s)
+  {
+    const int grid = (p.nslices + 3) / 4;
+    if (dim == 3)
+      hipLaunchKernelGGL((bsr_to_sell<3>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals);
+    else
+      hipLaunchKernelGGL((bsr_to_sell<2>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals);
+  }
+  void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
+                              hipStream_t s)
+  {
+    hipLaunchKernelGGL(sell_build_cols, dim3((p.nslices + 3) / 4), dim3(256), 0, s, p, rowptr, bsr_col, sell_col);
   }
 
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s)

@@ -185,6 +185,13 @@ namespace mi
     std::vector<InterfaceFace> iface_faces;         // sorted by colour
     std::vector<int64_t>       iface_colour_begin;  // [ncolours+1]
 
+    // sliced-ELL view of the block pattern for the SpMV: rows grouped by length (a box mesh has at most
+    // 2^dim... in fact dim+1 distinct lengths), 64 rows per slice, lane = row, no padding inside a slice
+    int64_t              sell_nslices = 0, sell_nblk64 = 0; // sum over slices of their length (units of 64 blocks)
+    std::vector<int32_t> sell_perm;                         // [nslices*64] node of a slot, -1 = padding row
+    std::vector<int32_t> sell_len;                          // [nslices] blocks per row in the slice
+    std::vector<int64_t> sell_off;                          // [nslices+1] prefix sum of sell_len
+
     static void split(int64_t id, const int *ext, int dim, int *out)
     {
       for (int d = 0; d < 3; ++d)
@@ -430,6 +437,41 @@ namespace mi
           iface_faces.insert(iface_faces.end(), faces_by_colour[c].begin(), faces_by_colour[c].end());
           iface_colour_begin.push_back(int64_t(iface_faces.size()));
         }
+      build_sell();
+    }
+
+    void build_sell()
+    {
+      std::vector<int32_t> lens;
+      for (int64_t n = 0; n < nnodes; ++n)
+        lens.push_back(rowptr[size_t(n) + 1] - rowptr[size_t(n)]);
+      std::vector<int32_t> classes(lens);
+      std::sort(classes.begin(), classes.end());
+      classes.erase(std::unique(classes.begin(), classes.end()), classes.end());
+      sell_perm.clear();
+      sell_len.clear();
+      for (int32_t L : classes)
+        {
+          int64_t cnt = 0;
+          for (int64_t n = 0; n < nnodes; ++n)
+            if (lens[size_t(n)] == L)
+              {
+                sell_perm.push_back(int32_t(n));
+                ++cnt;
+              }
+          while (cnt % 64)
+            {
+              sell_perm.push_back(-1);
+              ++cnt;
+            }
+          for (int64_t sl = 0; sl < cnt / 64; ++sl)
+            sell_len.push_back(L);
+        }
+      sell_nslices = int64_t(sell_len.size());
+      sell_off.assign(size_t(sell_nslices) + 1, 0);
+      for (int64_t sl = 0; sl < sell_nslices; ++sl)
+        sell_off[size_t(sl) + 1] = sell_off[size_t(sl)] + sell_len[size_t(sl)];
+      sell_nblk64 = sell_off[size_t(sell_nslices)];
     }
   };
 } // namespace mi

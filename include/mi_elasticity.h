@@ -169,6 +169,9 @@ typedef struct
   int64_t count[MI_T_COUNT]; /* launches / calls           */
 } mi_timings;
 int mi_set_profiling(mi_ctx *ctx, int enable);
+/* kernel selection for A/B timing: "spmv_variant" 3 sliced-ELL (default), 1 block-CSR; "spmv_grid" workgroups;
+ * "sell_unroll" 1..4; "xcd_remap" 0/1 */
+int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 int mi_reset_timings(mi_ctx *ctx);
 int mi_get_timings(mi_ctx *ctx, mi_timings *out);
 /* isolated kernel benches on the current matrix/state: average ms per launch over reps */

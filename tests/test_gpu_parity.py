@@ -139,6 +139,27 @@ def test_spmv_matches_reference_matrix(dim, p, reps):
     assert abs(z @ G.spmv(x) - x @ G.spmv(z)) / abs(z @ y) < 1e-12
 
 
+def test_spmv_kernel_variants_agree():
+    """sliced-ELL (production) and block-CSR (cross-check) kernels on the same matrix, several grids"""
+    P, G = _pair(3, 2, (5, 4, 3), perturb_amp=0.05, seed=11)
+    _randomise_state(P, G, seed=12)
+    G.update_acceleration()
+    G.assemble()
+    x = np.random.default_rng(7).standard_normal(P.n)
+    ys = {}
+    for variant in (3, 1):
+        for grid in (1, 7, 64):
+            G.set_tuning("spmv_variant", variant)
+            G.set_tuning("spmv_grid", grid)
+            ys[(variant, grid)] = G.spmv(x)
+    ref = ys[(3, 64)]
+    for k, y in ys.items():
+        assert _relmax(y, ref) < 1e-14, k
+    P.update_acceleration()
+    P.assemble()
+    assert _relmax(ref, P.csr() @ x) < 1e-13
+
+
 @pytest.mark.parametrize("dim,p,reps", [(3, 2, (3, 3, 3)), (2, 2, (18, 3))])
 def test_cg_solution_and_iteration_count(dim, p, reps):
     """Jacobi-PCG on the device vs the oracle's Jacobi-PCG: same stopping rule, same iterate count (+-1 from
