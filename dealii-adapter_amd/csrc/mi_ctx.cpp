@@ -15,75 +15,16 @@
 #include <string>
 #include <vector>
 
-#include "../../include/mi_elasticity.h"
-#include "mi_kernels.h"
-#include "mi_mesh.hpp"
+#include "mi_internal.h"
 
-namespace
+namespace mi_detail
 {
   std::string g_create_error;
+} // namespace mi_detail
+using namespace mi_detail;
 
-  constexpr int MAX_PART = 16384; // upper bound of per-workgroup reduction partials
-  constexpr int CG_BATCH = 16;   // CG iterations enqueued between two host polls of the convergence flag
 
-  enum
-  {
-    W_R = 0, // CG residual
-    W_P,     // CG search direction
-    W_Q,     // CG A*p
-    W_DINV,  // Jacobi
-    W_COUNT
-  };
-} // namespace
-
-struct mi_ctx
-{
-  std::string   err;
-  int           device = 0;
-  hipStream_t   stream = nullptr;
-  mi::HostMesh  mesh;
-  mi::Tables1D  tab;
-  int           dim = 0, degree = 0;
-  int64_t       n = 0; // dofs
-  mi_material_desc mat{};
-  mi_newmark_desc  nm{};
-  double        kappa = 0;
-  double        alpha[7] = {0, 0, 0, 0, 0, 0, 0};
-
-  // device memory
-  int32_t  *d_conn = nullptr, *d_rowptr = nullptr, *d_col = nullptr, *d_diagpos = nullptr, *d_iface_nodes = nullptr,
-          *d_faces = nullptr, *d_flags = nullptr;
-  double   *d_cverts = nullptr, *d_tab = nullptr, *d_vals = nullptr, *d_vecs = nullptr, *d_work = nullptr,
-         *d_saved = nullptr, *d_part = nullptr, *d_sc = nullptr, *d_iface_buf = nullptr;
-  int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr;
-  int64_t  *d_sell_off = nullptr;
-  double   *d_sell_vals = nullptr;
-  uint16_t *d_off   = nullptr;
-  uint8_t  *d_cmask = nullptr;
-  double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
-  size_t    h_pinned_doubles = 0;
-  bool      have_saved = false;
-
-  int grid_vec = 0, grid_spmv = 0;
-  int spmv_variant = 3, maxrow = 0, sell_unroll = 2, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
-
-  // profiling
-  bool profiling = false;
-  struct Stamp
-  {
-    hipEvent_t a, b;
-    int        cls;
-  };
-  std::vector<Stamp> stamps;
-  size_t             stamps_used = 0;
-  mi_timings         timings{};
-
-  double *vec(int which) { return d_vecs + size_t(which) * size_t(n); }
-  double *work(int which) { return d_work + size_t(which) * size_t(n); }
-  double *part(int which) { return d_part + size_t(which) * MAX_PART; }
-};
-
-namespace
+namespace mi_detail
 {
   int fail(mi_ctx *c, int code, const char *fmt, ...)
   {
@@ -97,26 +38,6 @@ namespace
     else
       g_create_error = buf;
     return code;
-  }
-
-#define HIPCHK(ctx, call)                                                                             \
-  do                                                                                                  \
-    {                                                                                                 \
-      hipError_t e_ = (call);                                                                         \
-      if (e_ != hipSuccess)                                                                           \
-        return fail(ctx, MI_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__,   \
-                    __LINE__);                                                                        \
-    }                                                                                                 \
-  while (0)
-
-  template <typename T>
-  int upload(mi_ctx *c, T **dst, const std::vector<T> &src)
-  {
-    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-    HIPCHK(c, hipMalloc((void **)dst, bytes));
-    if (!src.empty())
-      HIPCHK(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
-    return MI_OK;
   }
 
   // ---- profiling stamps: HIP events on the context's stream, resolved after a synchronize
@@ -231,7 +152,7 @@ namespace
     p.len      = c->d_sell_len;
     p.off      = c->d_sell_off;
     p.col      = c->d_sell_col;
-    p.vals     = c->d_sell_vals;
+    p.vals     = c->active_sell_vals ? c->active_sell_vals : c->d_sell_vals;
     p.x        = x;
     p.y        = y;
     p.dotv     = dotv;
@@ -245,7 +166,7 @@ namespace
   // y = K x (+ optional fused dot partials) with the selected kernel variant
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done)
   {
-    if (c->spmv_variant == 3)
+    if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
       mi::launch_sell_spmv(c->dim, sell_params(c, x, y, dotv, partials, done), c->grid_spmv, c->stream,
                            c->sell_unroll);
     else
@@ -280,7 +201,85 @@ namespace
     HIPCHK(c, hipGetLastError());
     return MI_OK;
   }
-} // namespace
+  // Jacobi-PCG (deal.II SolverCG semantics: start from x, stop when ||r||_2 <= tolerance) on the active matrix;
+  // followed by constraints.distribute (x[constrained] = 0)
+  int cg_run(mi_ctx *c, double *x, const double *b, double tol, int64_t max_it, int *its, double *res)
+  {
+  const int tt = tic(c, MI_T_CG_TOTAL);
+  mi::CgParams cg{};
+  cg.x        = x;
+  cg.r        = c->work(W_R);
+  cg.p        = c->work(W_P);
+  cg.q        = c->work(W_Q);
+  cg.dinv     = c->active_dinv ? c->active_dinv : c->work(W_DINV);
+  cg.part_rr  = c->part(0);
+  cg.part_rz  = c->part(1);
+  cg.part_pq  = c->part(2);
+  cg.sc       = c->d_sc;
+  cg.flags    = c->d_flags;
+  cg.n        = c->n;
+  cg.npart    = c->grid_vec;
+  cg.npart_pq = c->grid_spmv;
+
+  // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
+  {
+    const int t = tic(c, MI_T_SPMV);
+    enqueue_spmv(c, x, cg.q, nullptr, nullptr, nullptr);
+    toc(c, t);
+  }
+  mi::launch_cg_init_residual(cg, b, c->part(4), c->grid_vec, c->stream);
+  mi::launch_cg_set_tolerance(cg, c->part(4), tol, c->stream);
+
+  int32_t *h_flags = reinterpret_cast<int32_t *>(c->h_pinned + 8);
+  int64_t  it      = 0;
+  bool     done    = false;
+  while (!done && it < max_it)
+    {
+      const int64_t stop = std::min<int64_t>(max_it, it + CG_BATCH);
+      for (; it < stop;)
+        {
+          ++it;
+          int t = tic(c, MI_T_CG_VECTOR);
+          mi::launch_cg_update_p(cg, int(it), c->grid_vec, c->stream);
+          toc(c, t);
+          t = tic(c, MI_T_SPMV);
+          enqueue_spmv(c, cg.p, cg.q, cg.p, cg.part_pq, cg.flags);
+          toc(c, t);
+          t = tic(c, MI_T_CG_VECTOR);
+          mi::launch_cg_update_xr(cg, int(it), c->grid_vec, c->stream);
+          toc(c, t);
+        }
+      mi::launch_cg_final_check(cg, int(it), c->stream);
+      HIPCHK(c, hipGetLastError());
+      HIPCHK(c, hipMemcpyAsync(h_flags, c->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      done = h_flags[0] != 0;
+    }
+  if (max_it <= 0)
+    {
+      mi::launch_cg_final_check(cg, 0, c->stream);
+      HIPCHK(c, hipMemcpyAsync(h_flags, c->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      done = h_flags[0] != 0;
+    }
+  mi::launch_zero_constrained(c->dim, x, c->d_cmask, c->n, c->stream); // constraints.distribute (:1208)
+  toc(c, tt);
+  HIPCHK(c, hipGetLastError());
+  int rc = sync(c);
+  if (rc)
+    return rc;
+  if (its)
+    *its = h_flags[1];
+  if (res)
+    *res = c->h_pinned[3];
+  if (!done)
+    return fail(c, MI_ENOCONV_LIN, "CG did not reach tolerance %.3e within %lld iterations (residual %.3e)", std::fabs(tol),
+                (long long)max_it, c->h_pinned[3]);
+  return MI_OK;
+}
+} // namespace mi_detail
 
 extern "C" {
 
@@ -296,6 +295,7 @@ void mi_ctx_destroy(mi_ctx *c)
   hipSetDevice(c->device);
   if (c->stream)
     hipStreamSynchronize(c->stream);
+  linear_destroy(c);
   for (auto &s : c->stamps)
     {
       hipEventDestroy(s.a);
@@ -510,6 +510,7 @@ int mi_set_interface_traction(mi_ctx *c, int n, const double *vals)
   if (n == 0)
     return MI_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  c->h_iface.assign(vals, vals + size_t(n) * c->dim);
   std::memcpy(c->h_pinned + 64, vals, size_t(n) * c->dim * sizeof(double));
   HIPCHK(c, hipMemcpyAsync(c->d_iface_buf, c->h_pinned + 64, size_t(n) * c->dim * sizeof(double),
                            hipMemcpyHostToDevice, c->stream));
@@ -577,80 +578,12 @@ int mi_assemble(mi_ctx *c, double *res_norm)
 int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res)
 {
   HIPCHK(c, hipSetDevice(c->device));
-  const int tt = tic(c, MI_T_CG_TOTAL);
-  double   *x  = c->vec(MI_V_NEWTON_UPDATE); // warm start: SolverCG starts from the passed vector (:1184-1187)
-  mi::CgParams cg{};
-  cg.x        = x;
-  cg.r        = c->work(W_R);
-  cg.p        = c->work(W_P);
-  cg.q        = c->work(W_Q);
-  cg.dinv     = c->work(W_DINV);
-  cg.part_rr  = c->part(0);
-  cg.part_rz  = c->part(1);
-  cg.part_pq  = c->part(2);
-  cg.sc       = c->d_sc;
-  cg.flags    = c->d_flags;
-  cg.n        = c->n;
-  cg.npart    = c->grid_vec;
-  cg.npart_pq = c->grid_spmv;
-
-  // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
-  {
-    const int t = tic(c, MI_T_SPMV);
-    enqueue_spmv(c, x, cg.q, nullptr, nullptr, nullptr);
-    toc(c, t);
-  }
-  mi::launch_cg_init_residual(cg, c->vec(MI_V_SYSTEM_RHS), c->part(4), c->grid_vec, c->stream);
-  mi::launch_cg_set_tolerance(cg, c->part(4), rel_tol, c->stream);
-
-  int32_t *h_flags = reinterpret_cast<int32_t *>(c->h_pinned + 8);
-  int64_t  it      = 0;
-  bool     done    = false;
-  while (!done && it < max_it)
-    {
-      const int64_t stop = std::min<int64_t>(max_it, it + CG_BATCH);
-      for (; it < stop;)
-        {
-          ++it;
-          int t = tic(c, MI_T_CG_VECTOR);
-          mi::launch_cg_update_p(cg, int(it), c->grid_vec, c->stream);
-          toc(c, t);
-          t = tic(c, MI_T_SPMV);
-          enqueue_spmv(c, cg.p, cg.q, cg.p, cg.part_pq, cg.flags);
-          toc(c, t);
-          t = tic(c, MI_T_CG_VECTOR);
-          mi::launch_cg_update_xr(cg, int(it), c->grid_vec, c->stream);
-          toc(c, t);
-        }
-      mi::launch_cg_final_check(cg, int(it), c->stream);
-      HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipMemcpyAsync(h_flags, c->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      done = h_flags[0] != 0;
-    }
-  if (max_it <= 0)
-    {
-      mi::launch_cg_final_check(cg, 0, c->stream);
-      HIPCHK(c, hipMemcpyAsync(h_flags, c->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      done = h_flags[0] != 0;
-    }
-  mi::launch_zero_constrained(c->dim, x, c->d_cmask, c->n, c->stream); // constraints.distribute (:1208)
-  toc(c, tt);
-  HIPCHK(c, hipGetLastError());
-  int rc = sync(c);
-  if (rc)
-    return rc;
-  if (its)
-    *its = h_flags[1];
-  if (res)
-    *res = c->h_pinned[3];
-  if (!done)
-    return fail(c, MI_ENOCONV_LIN, "CG did not reach %.3e * ||rhs|| within %lld iterations (residual %.3e)", rel_tol,
-                (long long)max_it, c->h_pinned[3]);
-  return MI_OK;
+  if (rel_tol < 0)
+    return fail(c, MI_EINVAL, "negative tolerance");
+  c->active_sell_vals = nullptr; // tangent
+  c->active_dinv      = nullptr;
+  // warm start: SolverCG starts from the passed vector (:1184-1187)
+  return cg_run(c, c->vec(MI_V_NEWTON_UPDATE), c->vec(MI_V_SYSTEM_RHS), rel_tol, max_it, its, res);
 }
 
 int mi_apply_newton_update(mi_ctx *c, double *upd_norm)
@@ -763,6 +696,52 @@ int mi_state_restore(mi_ctx *c)
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipMemcpyAsync(c->d_vecs, c->d_saved, size_t(6) * size_t(c->n) * sizeof(double),
                            hipMemcpyDeviceToDevice, c->stream));
+  return MI_OK;
+}
+
+struct mi_snapshot
+{
+  double *d = nullptr;
+};
+
+int mi_snapshot_create(mi_ctx *c, mi_snapshot **out)
+{
+  if (!out)
+    return fail(c, MI_EINVAL, "null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  mi_snapshot *s = new mi_snapshot;
+  hipError_t   e = hipMalloc((void **)&s->d, size_t(c->n) * sizeof(double));
+  if (e != hipSuccess)
+    {
+      delete s;
+      return fail(c, MI_EHIP, "hipMalloc of a snapshot failed: %s", hipGetErrorString(e));
+    }
+  *out = s;
+  return MI_OK;
+}
+void mi_snapshot_destroy(mi_ctx *c, mi_snapshot *s)
+{
+  if (!s)
+    return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  hipFree(s->d);
+  delete s;
+}
+int mi_snapshot_store(mi_ctx *c, mi_snapshot *s, int which)
+{
+  if (!s || which < 0 || which >= MI_V_COUNT)
+    return fail(c, MI_EINVAL, "bad snapshot or vector id");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(s->d, c->vec(which), size_t(c->n) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  return MI_OK;
+}
+int mi_snapshot_load(mi_ctx *c, const mi_snapshot *s, int which)
+{
+  if (!s || which < 0 || which >= MI_V_COUNT)
+    return fail(c, MI_EINVAL, "bad snapshot or vector id");
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipMemcpyAsync(c->vec(which), s->d, size_t(c->n) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
   return MI_OK;
 }
 

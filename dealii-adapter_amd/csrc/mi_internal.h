@@ -1,0 +1,115 @@
+// mi_internal.h -- context object shared by the translation units of the library (not part of the C-ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/mi_elasticity.h"
+#include "mi_kernels.h"
+#include "mi_mesh.hpp"
+
+namespace mi_detail
+{
+  constexpr int MAX_PART = 16384; // upper bound of per-workgroup reduction partials
+  constexpr int CG_BATCH = 16;    // CG iterations enqueued between two host polls of the convergence flag
+
+  enum
+  {
+    W_R = 0, // CG residual
+    W_P,     // CG search direction
+    W_Q,     // CG A*p
+    W_DINV,  // Jacobi
+    W_COUNT
+  };
+  struct LinearModel; // mi_linear.cpp
+} // namespace mi_detail
+
+struct mi_ctx
+{
+  std::string   err;
+  int           device = 0;
+  hipStream_t   stream = nullptr;
+  mi::HostMesh  mesh;
+  mi::Tables1D  tab;
+  int           dim = 0, degree = 0;
+  int64_t       n = 0; // dofs
+  mi_material_desc mat{};
+  mi_newmark_desc  nm{};
+  double        kappa = 0;
+  double        alpha[7] = {0, 0, 0, 0, 0, 0, 0};
+
+  // device memory
+  int32_t  *d_conn = nullptr, *d_rowptr = nullptr, *d_col = nullptr, *d_diagpos = nullptr, *d_iface_nodes = nullptr,
+          *d_faces = nullptr, *d_flags = nullptr;
+  double   *d_cverts = nullptr, *d_tab = nullptr, *d_vals = nullptr, *d_vecs = nullptr, *d_work = nullptr,
+         *d_saved = nullptr, *d_part = nullptr, *d_sc = nullptr, *d_iface_buf = nullptr;
+  int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr;
+  int64_t  *d_sell_off = nullptr;
+  double   *d_sell_vals = nullptr;
+  uint16_t *d_off   = nullptr;
+  uint8_t  *d_cmask = nullptr;
+  double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
+  size_t    h_pinned_doubles = 0;
+  bool      have_saved = false;
+
+  int grid_vec = 0, grid_spmv = 0;
+  int spmv_variant = 3, maxrow = 0, sell_unroll = 2, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
+
+  // profiling
+  bool profiling = false;
+  struct Stamp
+  {
+    hipEvent_t a, b;
+    int        cls;
+  };
+  std::vector<Stamp> stamps;
+  size_t             stamps_used = 0;
+  mi_timings         timings{};
+
+  // matrix / diagonal the SpMV and CG currently act on (tangent by default, linear-model operators otherwise)
+  const double *active_sell_vals = nullptr;
+  const double *active_dinv      = nullptr;
+  std::vector<double> h_iface;   // host copy of the last interface values (linear model: consistent loading)
+  mi_detail::LinearModel *linear = nullptr;
+
+  double *vec(int which) { return d_vecs + size_t(which) * size_t(n); }
+  double *work(int which) { return d_work + size_t(which) * size_t(n); }
+  double *part(int which) { return d_part + size_t(which) * mi_detail::MAX_PART; }
+};
+
+namespace mi_detail
+{
+  int  fail(mi_ctx *c, int code, const char *fmt, ...);
+  int  tic(mi_ctx *c, int cls);
+  void toc(mi_ctx *c, int id);
+  int  sync(mi_ctx *c);
+  mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
+                             const int32_t *done);
+  void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done);
+  // Jacobi-PCG on the active matrix: x warm start, tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
+  int  cg_run(mi_ctx *c, double *x, const double *b, double tol, int64_t max_it, int *its, double *res);
+  void linear_destroy(mi_ctx *c);
+
+#define HIPCHK(ctx, call)                                                                                   \
+  do                                                                                                        \
+    {                                                                                                       \
+      hipError_t e_ = (call);                                                                               \
+      if (e_ != hipSuccess)                                                                                 \
+        return mi_detail::fail(ctx, MI_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                               __LINE__);                                                                   \
+    }                                                                                                       \
+  while (0)
+
+  template <typename T>
+  int upload(mi_ctx *c, T **dst, const std::vector<T> &src)
+  {
+    const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIPCHK(c, hipMalloc((void **)dst, bytes));
+    if (!src.empty())
+      HIPCHK(c, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return MI_OK;
+  }
+} // namespace mi_detail

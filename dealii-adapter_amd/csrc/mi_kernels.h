@@ -73,6 +73,18 @@ namespace mi
     int64_t n;
   };
 
+  struct LinearParams
+  {
+    const double *load, *body;
+    double       *f_old, *v, *d, *v_old, *d_old, *rhs, *w;
+    double        theta, dt;
+    int64_t       n;
+  };
+
+  void launch_linear_rhs_prepare(const LinearParams &p, hipStream_t s);
+  void launch_linear_rhs_finish(int dim, const LinearParams &p, const double *mv, const double *kw,
+                                const uint8_t *cmask, hipStream_t s);
+  void launch_linear_update_displacement(const LinearParams &p, hipStream_t s);
   int  launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s);
   int  launch_neumann_faces(int dim, int degree, const AsmParams &p, const int32_t *faces, int face_begin,
                             int face_count, hipStream_t s);

@@ -1093,14 +1093,14 @@ namespace mi
       }
   }
 
-  // tol = rel_tol * ||b||  (:1171-1172); reset flags
+  // tol = rel_tol * ||b||  (:1171-1172), or the absolute value -rel_tol when negative; reset flags
   __global__ __launch_bounds__(256) void cg_set_tolerance(CgParams c, const double *part_bb, double rel_tol)
   {
     __shared__ double s_red[4];
     const double bb = reduce_partials<256>(part_bb, c.npart, s_red);
     if (threadIdx.x == 0)
       {
-        c.sc[2]    = rel_tol * sqrt(bb);
+        c.sc[2]    = rel_tol >= 0.0 ? rel_tol * sqrt(bb) : -rel_tol;
         c.sc[3]    = 0.0;
         c.sc[4]    = sqrt(bb);
         c.flags[0] = 0;
@@ -1216,6 +1216,54 @@ namespace mi
         p.v[i]     = v;
         p.v_old[i] = v;
       }
+  }
+
+  // ---- linear model (linear_elasticity.cc:378-454, :579-586)
+  // f = F + body; rhs = theta dt f + (1-theta) dt F_old; F_old = f; v_old = v; d_old = d;
+  // w = theta (1-theta) dt^2 v + dt d      (so that  M v - K w  completes the right-hand side with 2 SpMVs)
+  __global__ __launch_bounds__(256) void linear_rhs_prepare(LinearParams p)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.n)
+      return;
+    const double f = p.load[i] + (p.body ? p.body[i] : 0.0);
+    const double v = p.v[i], d = p.d[i];
+    double       r = f * (p.dt * p.theta);
+    r += p.dt * (1 - p.theta) * p.f_old[i];
+    p.rhs[i]   = r;
+    p.f_old[i] = f;
+    p.v_old[i] = v;
+    p.d_old[i] = d;
+    p.w[i]     = p.theta * p.dt * p.dt * (1 - p.theta) * v + p.dt * d;
+  }
+  // rhs += M v_old - K w; boundary values (zero): rhs = 0 and v = 0 on constrained dofs (:426-451)
+  template <int D>
+  __global__ __launch_bounds__(256) void linear_rhs_finish(LinearParams p, const double *__restrict__ mv,
+                                                           const double *__restrict__ kw,
+                                                           const uint8_t *__restrict__ cmask)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.n)
+      return;
+    const int64_t nd = i / D;
+    if ((cmask[nd] >> int(i - nd * D)) & 1)
+      {
+        p.rhs[i] = 0.0;
+        p.v[i]   = 0.0;
+      }
+    else
+      p.rhs[i] += mv[i] - kw[i];
+  }
+  // D_n+1 = D_n + dt theta V_n+1 + dt (1-theta) V_n
+  __global__ __launch_bounds__(256) void linear_update_displacement(LinearParams p)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= p.n)
+      return;
+    double d = p.d[i];
+    d += p.dt * p.theta * p.v[i];
+    d += p.dt * (1 - p.theta) * p.v_old[i];
+    p.d[i] = d;
   }
 
   // interface gather / scatter (adapter.h:389-443)
@@ -1425,6 +1473,23 @@ namespace mi
   void launch_vec_add(double *y, const double *x, int64_t n, hipStream_t s)
   {
     hipLaunchKernelGGL(vec_add, dim3(int((n + 255) / 256)), dim3(256), 0, s, y, x, n);
+  }
+  void launch_linear_rhs_prepare(const LinearParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL(linear_rhs_prepare, dim3(int((p.n + 255) / 256)), dim3(256), 0, s, p);
+  }
+  void launch_linear_rhs_finish(int dim, const LinearParams &p, const double *mv, const double *kw,
+                                const uint8_t *cmask, hipStream_t s)
+  {
+    const int grid = int((p.n + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((linear_rhs_finish<3>), dim3(grid), dim3(256), 0, s, p, mv, kw, cmask);
+    else
+      hipLaunchKernelGGL((linear_rhs_finish<2>), dim3(grid), dim3(256), 0, s, p, mv, kw, cmask);
+  }
+  void launch_linear_update_displacement(const LinearParams &p, hipStream_t s)
+  {
+    hipLaunchKernelGGL(linear_update_displacement, dim3(int((p.n + 255) / 256)), dim3(256), 0, s, p);
   }
   void launch_gather_nodes(int dim, const double *v, const int32_t *nodes, int n, double *out, hipStream_t s)
   {

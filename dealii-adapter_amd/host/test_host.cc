@@ -1,0 +1,287 @@
+// CPU-only unit tests of the host-side boundary code (no device calls): parameter file reader, Adapter::Time,
+// replay participant, Adapter call sequence with a mock vector type.  Run by tests/test_host_cpu.py.
+#include <cassert>
+#include <cmath>
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include <adapter/adapter.h>
+#include <adapter/parameters.h>
+#include <adapter/time_handler.h>
+
+static int g_fail = 0;
+#define CHECK(cond)                                                          \
+  do                                                                         \
+    {                                                                        \
+      if (!(cond))                                                           \
+        {                                                                    \
+          std::printf("CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+          ++g_fail;                                                          \
+        }                                                                    \
+    }                                                                        \
+  while (0)
+
+static void write_file(const std::string &name, const std::string &txt)
+{
+  std::ofstream f(name);
+  f << txt;
+}
+
+template <typename F>
+static bool throws(F f, const std::string &needle = "")
+{
+  try
+    {
+      f();
+    }
+  catch (const std::exception &e)
+    {
+      return needle.empty() || std::string(e.what()).find(needle) != std::string::npos;
+    }
+  return false;
+}
+
+// mock of the device vector: a host array, "interface" = first n*dim entries
+struct MockVector
+{
+  std::vector<double> v = std::vector<double>(12, 0.0);
+  void gather_interface(std::vector<double> &out, int n) const
+  {
+    for (size_t i = 0; i < out.size(); ++i)
+      out[i] = v[i];
+    (void)n;
+  }
+  void scatter_interface(const std::vector<double> &in, int n)
+  {
+    for (size_t i = 0; i < in.size(); ++i)
+      v[i] = in[i];
+    (void)n;
+  }
+};
+struct MockDofs
+{
+  int  n_interface_nodes() const { return 3; }
+  void interface_nodes(int *ids, double *xyz) const
+  {
+    for (int i = 0; i < 3; ++i)
+      {
+        ids[i]         = 10 + i;
+        xyz[2 * i]     = 0.1 * i;
+        xyz[2 * i + 1] = 1.0;
+      }
+  }
+};
+
+static const char *PRM = R"(# test file
+subsection Time
+  set End time              = 10
+  set Time step size        = 0.005   # trailing comment
+  set Output interval       = 10
+   set Output folder   = dealii-output
+end
+subsection Discretization
+  set Polynomial degree   = 3
+end
+subsection System properties
+  set Poisson's ratio = 0.4
+  set Shear modulus   = 0.5e6
+  set rho	      = 1000
+  set body forces     = 0.0,-9.81,0.0
+end
+subsection Solver
+  set Model                     = linear
+  set Solver type               = Direct
+  set Max iteration multiplier  = 1
+  set Residual                  = 1e-6
+  set Max iterations Newton-Raphson = 10
+  set Tolerance displacement        = 1.0e-6
+  set Tolerance force               = 1.0e-9
+end
+subsection precice configuration
+  set Scenario            = FSI3
+  set precice config-file = precice-config.xml
+  set Participant name    = Solid
+  set Mesh name           = Solid-Mesh
+  set Read data name      = Stress
+  set Write data name     = Displacement
+end
+)";
+
+int main()
+{
+  // ---------------- Adapter::Time (time_handler.h:21-84)
+  {
+    Adapter::Time t(10.0, 0.005);
+    for (int i = 0; i < 7; ++i)
+      t.increment();
+    CHECK(t.get_timestep() == 7 && std::abs(t.current() - 0.035) < 1e-15);
+    t.set_absolute_time(0.015);
+    CHECK(t.get_timestep() == 3 && t.current() == 0.015);
+    t.set_absolute_time(0.005 * 2.9999999999); // rounds at 1e-10, then truncates
+    CHECK(t.get_timestep() == 2);
+    t.set_absolute_time(0.005 * 2.99999999999);
+    CHECK(t.get_timestep() == 3);
+    CHECK(t.end() == 10.0 && t.get_delta_t() == 0.005);
+  }
+  // ---------------- parameter files (parameters.cc:8-205)
+  {
+    write_file("t_ok.prm", PRM);
+    Parameters::AllParameters p("t_ok.prm");
+    CHECK(p.end_time == 10 && p.delta_t == 0.005 && p.output_interval == 10 && p.output_folder == "dealii-output");
+    CHECK(p.poly_degree == 3 && p.theta == 0.5 && p.beta == 0.25 && p.gamma == 0.5); // defaults kept
+    CHECK(p.nu == 0.4 && p.mu == 0.5e6 && p.rho == 1000 && p.body_force[1] == -9.81);
+    CHECK(std::abs(p.lambda - 2 * 0.5e6 * 0.4 / (1 - 0.8)) < 1e-6); // :189
+    CHECK(p.model == "linear" && p.type_lin == "Direct" && p.max_iterations_NR == 10);
+    CHECK(p.scenario == "FSI3" && p.participant_name == "Solid" && p.mesh_name == "Solid-Mesh");
+    CHECK(p.data_consistent);
+    // "Force..." read data -> conservative (:194-195); anything else is an error (:196-200)
+    std::string s = PRM;
+    s.replace(s.find("= Stress"), 8, "= Force-Data");
+    write_file("t_force.prm", s);
+    CHECK(!Parameters::AllParameters("t_force.prm").data_consistent);
+    s = PRM;
+    s.replace(s.find("= Stress"), 8, "= Pressure");
+    write_file("t_bad.prm", s);
+    CHECK(throws([] { Parameters::AllParameters("t_bad.prm"); }, "Unknown read data type"));
+    // strict parse: unknown key / subsection, pattern violations
+    s = PRM;
+    s.replace(s.find("set rho"), 7, "set rhx");
+    write_file("t_key.prm", s);
+    CHECK(throws([] { Parameters::AllParameters("t_key.prm"); }, "No entry with name"));
+    s = std::string(PRM) + "subsection Linear solver\n  set x = 1\nend\n";
+    write_file("t_sec.prm", s);
+    CHECK(throws([] { Parameters::AllParameters("t_sec.prm"); }, "no such subsection"));
+    s = PRM;
+    s.replace(s.find("= 0.4"), 5, "= 0.6");
+    write_file("t_nu.prm", s);
+    CHECK(throws([] { Parameters::AllParameters("t_nu.prm"); }, "does not match its pattern"));
+    s = PRM;
+    s.replace(s.find("= linear"), 8, "= plastic");
+    write_file("t_model.prm", s);
+    CHECK(throws([] { Parameters::AllParameters("t_model.prm"); }, "pattern"));
+    CHECK(throws([] { Parameters::AllParameters("does-not-exist.prm"); }, "Cannot open"));
+    // lenient partial parse (elasticity.cc:51-55, :84-86): foreign sections and keys are skipped
+    prm::Handler     h;
+    Parameters::Time time;
+    time.add_output_parameters(h);
+    h.parse_input("t_ok.prm", "", true);
+    CHECK(time.output_folder == "dealii-output" && time.delta_t == 0.005);
+    // additive Block scenario
+    s = PRM;
+    s.replace(s.find("= FSI3"), 6, "= Block");
+    s += "subsection Block\n  set Repetitions = 4, 5, 6\n  set Upper corner = 2,1,1\nend\n";
+    write_file("t_block.prm", s);
+    Parameters::AllParameters pb("t_block.prm");
+    CHECK(pb.scenario == "Block" && pb.repetitions[0] == 4 && pb.repetitions[2] == 6 && pb.upper[0] == 2.0);
+  }
+  // ---------------- replay participant + Adapter call order (adapter.h:229-489)
+  {
+    write_file("t_explicit.xml", R"(<precice-configuration dimensions="2">
+  <!-- replay: read-data = ramp 4 0 -40 0 -->
+  <!-- replay: write-log = t_explicit.log -->
+  <coupling-scheme:serial-explicit>
+    <max-time value="0.03" /> <time-window-size value="0.01" />
+  </coupling-scheme:serial-explicit>
+</precice-configuration>)");
+    struct P
+    {
+      std::string participant_name = "Solid", config_file = "t_explicit.xml", mesh_name = "Solid-Mesh",
+                  read_data_name = "Stress", write_data_name = "Displacement";
+    } par;
+    Adapter::Adapter<2, MockVector, P> ad(par, 7);
+    CHECK(ad.deal_boundary_interface_id == 7);
+    MockVector   u, stress;
+    Adapter::Time time(1.0, 0.01);
+    ad.initialize(MockDofs(), u);
+    std::vector<MockVector *> state = {&u};
+    int                       steps = 0;
+    while (ad.precice.isCouplingOngoing())
+      {
+        ad.save_current_state_if_required(state, time);
+        time.increment();
+        CHECK(std::abs(ad.precice.getMaxTimeStepSize() - 0.01) < 1e-15);
+        ad.read_data(0.01, stress);
+        // ramp over 4 windows, read at the END of the window: y traction = -40 * (k+1)/4
+        CHECK(std::abs(stress.v[1] - (-40.0 * std::min(1.0, (steps + 1) / 4.0))) < 1e-12 && stress.v[0] == 0.0);
+        CHECK(stress.v[3] == stress.v[1] && stress.v[5] == stress.v[1]);
+        u.v[0] = 1.0 + steps;
+        ad.advance(u, 0.01);
+        ad.reload_old_state_if_required(state, time);
+        CHECK(ad.precice.isTimeWindowComplete());
+        ++steps;
+      }
+    ad.precice.finalize();
+    CHECK(steps == 3 && time.get_timestep() == 3);
+    std::ifstream log("t_explicit.log");
+    std::string   line;
+    int           rows = 0;
+    while (std::getline(log, line))
+      if (!line.empty() && line[0] != '#')
+        ++rows;
+    CHECK(rows == 3);
+    // wrong dimension is rejected at initialize (:235-242)
+    Adapter::Adapter<3, MockVector, P> ad3(par, 7);
+    CHECK(throws([&] { ad3.initialize(MockDofs(), u); }, "dimension"));
+  }
+  {
+    write_file("t_implicit.xml", R"(<precice-configuration dimensions="2">
+  <!-- replay: read-data = constant 0 -8 0 -->
+  <coupling-scheme:serial-implicit>
+    <max-time-windows value="2" /> <time-window-size value="0.01" /> <max-iterations value="3" />
+  </coupling-scheme:serial-implicit>
+</precice-configuration>)");
+    struct P
+    {
+      std::string participant_name = "Solid", config_file = "t_implicit.xml", mesh_name = "m", read_data_name = "Stress",
+                  write_data_name = "Displacement";
+    } par;
+    Adapter::Adapter<2, MockVector, P> ad(par, 7);
+    MockVector   u, stress;
+    Adapter::Time time(1.0, 0.01);
+    ad.initialize(MockDofs(), u);
+    std::vector<MockVector *> state = {&u};
+    int                       calls = 0, completed = 0;
+    std::vector<double>       seen;
+    while (ad.precice.isCouplingOngoing())
+      {
+        ad.save_current_state_if_required(state, time);
+        time.increment();
+        ad.read_data(0.01, stress);
+        seen.push_back(stress.v[1]);
+        u.v[0] += 1.0; // "solve": the state advances every call ...
+        ad.advance(u, 0.01);
+        ad.reload_old_state_if_required(state, time); // ... and is rewound unless the window converged
+        if (ad.precice.isTimeWindowComplete())
+          ++completed;
+        ++calls;
+        CHECK(calls < 50);
+      }
+    CHECK(calls == 6 && completed == 2);
+    CHECK(time.get_timestep() == 2 && std::abs(time.current() - 0.02) < 1e-15); // set_absolute_time rewinds
+    CHECK(std::abs(u.v[0] - 2.0) < 1e-15); // one net advance per window: checkpoints restored twice per window
+    CHECK(std::abs(seen[0] + 4.0) < 1e-12 && std::abs(seen[1] + 6.0) < 1e-12 && std::abs(seen[2] + 8.0) < 1e-12);
+  }
+  // vector count mismatch between save and reload is an error (:478-480)
+  {
+    struct P
+    {
+      std::string participant_name = "Solid", config_file = "t_implicit.xml", mesh_name = "m", read_data_name = "Stress",
+                  write_data_name = "Displacement";
+    } par;
+    Adapter::Adapter<2, MockVector, P> ad(par, 7);
+    MockVector   u, w;
+    Adapter::Time time(1.0, 0.01);
+    ad.initialize(MockDofs(), u);
+    std::vector<MockVector *> one = {&u}, two = {&u, &w};
+    ad.save_current_state_if_required(one, time);
+    time.increment();
+    ad.advance(u, 0.01);
+    CHECK(throws([&] { ad.reload_old_state_if_required(two, time); }, "not the same as previously saved"));
+  }
+  std::printf(g_fail ? "HOST TESTS FAILED (%d)\n" : "HOST TESTS OK\n", g_fail);
+  return g_fail ? 1 : 0;
+}

@@ -130,6 +130,36 @@ int mi_newmark_step(mi_ctx *ctx, const mi_solver_desc *s, mi_step_info *info);
 int mi_state_save(mi_ctx *ctx);
 int mi_state_restore(mi_ctx *ctx);
 
+/* ---- linear model: ElastoDynamics (source/linear_elasticity/linear_elasticity.cc) -------------------------- */
+/* state vectors of the linear model live in the same slots as the nonlinear ones */
+enum
+{
+  MI_L_DISPLACEMENT     = 0, /* MI_V_TOTAL_DISPLACEMENT      */
+  MI_L_OLD_DISPLACEMENT = 1, /* MI_V_TOTAL_DISPLACEMENT_OLD  */
+  MI_L_VELOCITY         = 2,
+  MI_L_OLD_VELOCITY     = 3,
+  MI_L_OLD_STRESS       = 4, /* load vector F_n (assemble_rhs :402-409) */
+  MI_L_STRESS           = 6, /* MI_V_EXTERNAL_STRESS: coupling data at the interface dofs */
+  MI_L_SYSTEM_RHS       = 9
+};
+/* assemble_system (:248-374): K, M (QGauss(p+1)) once; stepping matrix M + theta^2 dt^2 K with the zero
+ * boundary values of :426-451 eliminated; consistent-load operator of :458-521; body-force vector (:358-373) */
+int mi_linear_setup(mi_ctx *ctx, double theta);
+/* one pass of the time loop body (:676-684): assemble_rhs (:378-454, data_consistent: 1 "Stress" face integral,
+ * 0 "Force" nodal forces), solve (:525-575; Jacobi-PCG, absolute tolerance, warm start from the previous
+ * velocity), update_displacement (:579-586) */
+int mi_linear_step(mi_ctx *ctx, int data_consistent, double abs_tol, int64_t max_it, int *its, double *res);
+/* K (0), M (1) or the constrained stepping matrix (2) as scalar CSR, for parity tests */
+int mi_linear_matrix_get_csr(mi_ctx *ctx, int which, int64_t *rowptr, int32_t *col, double *val);
+
+/* per-vector device snapshots: what `old_state_data[i] = *state_variables[i]` (adapter.h:457-460) and its
+ * inverse (:481-482) become when VectorType is a handle to a device-resident vector */
+typedef struct mi_snapshot mi_snapshot;
+int  mi_snapshot_create(mi_ctx *ctx, mi_snapshot **out);
+void mi_snapshot_destroy(mi_ctx *ctx, mi_snapshot *s);
+int  mi_snapshot_store(mi_ctx *ctx, mi_snapshot *s, int which); /* snapshot := vector `which` (MI_V_*) */
+int  mi_snapshot_load(mi_ctx *ctx, const mi_snapshot *s, int which); /* vector `which` := snapshot   */
+
 /* ---- inspection hooks (tests, bench) ------------------------------------------------------ */
 enum
 {

@@ -1,0 +1,210 @@
+"""GPU tests of the drop-in boundary: the `elasticity` executables (parameters.prm + replayed coupling partner)
+against the CPU oracle driven through the same coupling script, and the linear model through the C-ABI.
+
+Interface displacements are compared per completed window, matched by vertex coordinate order (both sides use
+ascending x-dof order, adapter.h:313-321).  Tolerance 1e-8 relative (linear tolerance tightened to 1e-12).
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg
+
+M = load_pkg()
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "dealii-adapter_amd", "host")
+CASES = os.path.join(ROOT, "tests", "cases")
+TOL = 1e-8
+
+
+def _run_case(name, exe, tmp_path):
+    for f in ("parameters.prm", "precice-config.xml"):
+        (tmp_path / f).write_text(open(os.path.join(CASES, name, f)).read())
+    out = subprocess.run([os.path.join(HOST, exe)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    rows = [np.array(l.split(), dtype=float) for l in open(tmp_path / "displacement.log") if not l.startswith("#")]
+    return out.stdout, rows
+
+
+def _prm(name):
+    txt = open(os.path.join(CASES, name, "parameters.prm")).read()
+
+    def get(key):
+        return re.search(r"set\s+" + re.escape(key) + r"\s*=\s*(.+)", txt).group(1).strip()
+
+    return get
+
+
+def _scenario_desc(get, dim, **kw):
+    sc = get("Scenario")
+    common = dict(degree=int(get("Polynomial degree")), mu=float(get("Shear modulus")), nu=float(get("Poisson's ratio")),
+                  rho=float(get("rho")), delta_t=float(get("Time step size")),
+                  body_force=tuple(float(x) for x in get("body forces").split(",")), **kw)
+    if sc in ("FSI3", "PF"):
+        return O.scenario_desc(sc, dim, **common)
+    reps = tuple(int(x) for x in get("Repetitions").split(","))
+    lo = tuple(float(x) for x in get("Lower corner").split(","))
+    hi = tuple(float(x) for x in get("Upper corner").split(","))
+    return O.make_desc(dim=dim, reps=reps[:dim], lo=lo[:dim], hi=hi[:dim], **common)
+
+
+def _check_rows(rows, expected, dim):
+    assert len(rows) == len(expected)
+    for r, (t, u) in zip(rows, expected):
+        assert abs(r[0] - t) < 1e-12
+        got = r[1:].reshape(-1, dim)
+        assert got.shape == u.shape
+        assert np.abs(got - u).max() / np.abs(u).max() < TOL
+
+
+def test_executable_nonlinear_explicit_2d(tmp_path):
+    name = "fsi3_neo_2d_explicit"
+    stdout, rows = _run_case(name, "elasticity", tmp_path)
+    get = _prm(name)
+    P = O.Problem(_scenario_desc(get, 2))
+    ids = P.interface_nodes
+    dt, exp = float(get("Time step size")), []
+    for k in range(4):
+        P.set_interface_traction((0.0, -40.0 * min(1.0, (k + 1) / 4.0)))
+        rc, info = P.newmark_step(O.SOLVER_CG_SSOR, tol_lin=1e-12, max_it_mult=2.0)
+        assert rc == 0
+        exp.append(((k + 1) * dt, P.vec(O.V_U).reshape(-1, 2)[ids].copy()))
+    _check_rows(rows, exp, 2)
+    # console contract: banner, mesh statistics, Newton table, timer sections
+    assert "Number of coupling nodes:" in stdout and "Number of degrees of freedom: %d" % P.n in stdout
+    assert "SOLVER STEP" in stdout and "CONVERGED!" in stdout and "Timestep 4 @" in stdout
+    for section in ("Setup system", "Assemble linear system", "Linear solver", "Advance adapter", "Output results"):
+        assert section in stdout
+    assert os.path.exists(tmp_path / "out" / "solution-000.vtk")
+
+
+def test_executable_nonlinear_implicit_checkpointing(tmp_path):
+    """implicit coupling: 3 coupling iterations per window with save/reload of the 6 state vectors on the device"""
+    name = "fsi3_neo_2d_implicit"
+    _, rows = _run_case(name, "elasticity", tmp_path)
+    get = _prm(name)
+    P = O.Problem(_scenario_desc(get, 2))
+    ids = P.interface_nodes
+    dt, exp = float(get("Time step size")), []
+    state_ids = (O.V_U, O.V_U_OLD, O.V_V, O.V_V_OLD, O.V_A, O.V_A_OLD)
+    for w in range(2):
+        saved = [P.vec(k).copy() for k in state_ids]  # requiresWritingCheckpoint at the window start
+        for it in range(3):
+            scale = 1.0 - 0.5 ** (it + 1) if it < 2 else 1.0
+            P.set_interface_traction((0.0, -30.0 * scale))
+            rc, _ = P.newmark_step(O.SOLVER_CG_SSOR, tol_lin=1e-12, max_it_mult=2.0)
+            assert rc == 0
+            if it < 2:  # requiresReadingCheckpoint
+                for k, v in zip(state_ids, saved):
+                    P.vec(k)[:] = v
+        exp.append(((w + 1) * dt, P.vec(O.V_U).reshape(-1, 2)[ids].copy()))
+    _check_rows(rows, exp, 2)
+
+
+@pytest.mark.parametrize("name,windows,traction", [("pf_neo_3d_direct", 2, lambda k: (25.0, 0.0, 0.0)),
+                                                   ("block_neo_3d_q2", 2, lambda k: (0.0, -2e3 * (k + 1) / 10.0, 0.0))])
+def test_executable_nonlinear_3d(tmp_path, name, windows, traction):
+    _, rows = _run_case(name, "elasticity3d", tmp_path)
+    get = _prm(name)
+    P = O.Problem(_scenario_desc(get, 3))
+    ids = P.interface_nodes
+    dt, exp = float(get("Time step size")), []
+    for k in range(windows):
+        P.set_interface_traction(traction(k))
+        rc, _ = P.newmark_step(O.SOLVER_DIRECT if get("Solver type") == "Direct" and P.n < 3000 else O.SOLVER_CG_SSOR,
+                               tol_lin=1e-12, max_it_mult=2.0)
+        assert rc == 0
+        exp.append(((k + 1) * dt, P.vec(O.V_U).reshape(-1, 3)[ids].copy()))
+    _check_rows(rows, exp, 3)
+
+
+def _linear_pair(desc):
+    P = O.LinearProblem(desc)
+    G = M.Context(dim=desc.dim, degree=desc.degree, reps=tuple(desc.reps)[:desc.dim], lo=tuple(desc.lo)[:desc.dim],
+                  hi=tuple(desc.hi)[:desc.dim], face_role=list(desc.face_role), mu=desc.mu, nu=desc.nu, rho=desc.rho,
+                  body_force=tuple(desc.body_force), delta_t=desc.delta_t)
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.mi_linear_matrix_get_csr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, desc.theta) == 0, L.mi_last_error(G.h)
+    return P, G
+
+
+def _linear_matrix(G, which):
+    import scipy.sparse as sp
+    rp = np.zeros(G.n + 1, dtype=np.int64)
+    col = np.zeros(G.nnz, dtype=np.int32)
+    val = np.zeros(G.nnz)
+    assert M.lib().mi_linear_matrix_get_csr(G.h, which, rp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                            col.ctypes.data_as(C.POINTER(C.c_int32)), M._dp(val)) == 0
+    return sp.csr_matrix((val, col, rp), shape=(G.n, G.n))
+
+
+@pytest.mark.parametrize("dim,p,reps", [(2, 3, (6, 2)), (3, 1, (5, 3, 2)), (3, 2, (2, 2, 2))])
+def test_linear_model_matrices_and_steps(dim, p, reps):
+    """K, M, stepping matrix against the oracle (1e-12), then 5 theta-steps incl. consistent loading, body force,
+    warm-started CG; both the 'Stress' and the 'Force' read-data paths"""
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_ZCLAMP]
+    desc = O.make_desc(dim=dim, degree=p, reps=reps, hi=tuple(0.2 * r for r in reps), face_role=roles, mu=0.5e6, nu=0.4,
+                       rho=1000.0, body_force=(0.0, -9.81, 0.0), delta_t=0.005, theta=0.6)
+    P, G = _linear_pair(desc)
+    for which in (0, 1):
+        A_o, A_g = P.matrix(which), _linear_matrix(G, which)
+        assert np.array_equal(A_o.indices, A_g.indices)
+        assert np.abs(A_g.data - A_o.data).max() / np.abs(A_o.data).max() < 1e-12
+    ids = P.interface_nodes
+    rng = np.random.default_rng(5)
+    for step in range(5):
+        consistent = step != 3
+        t = 100.0 * rng.standard_normal((len(ids), dim))
+        P.vec(O.L_STRESS)[:] = 0
+        for c in range(dim):
+            P.vec(O.L_STRESS)[ids * dim + c] = t[:, c]
+        G.set_interface_traction(t)
+        rc, its_o, res_o = P.step(O.SOLVER_DIRECT, consistent)
+        assert rc == 0
+        its, res = C.c_int(0), C.c_double(0)
+        rc = M.lib().mi_linear_step(G.h, int(consistent), 1e-12, G.n * 4, C.byref(its), C.byref(res))
+        assert rc == 0, M.lib().mi_last_error(G.h)
+        assert res.value <= 1e-12 and its.value > 0
+        if step == 0:
+            A_o, A_g = P.matrix(3), _linear_matrix(G, 2)  # system matrix with boundary values applied
+            assert np.abs(A_g.data - A_o.data).max() / np.abs(A_o.data).max() < 1e-12
+        for vo, vg in ((O.L_D, 0), (O.L_V, 2), (O.L_V_OLD, 3), (O.L_STRESS_OLD, 4)):
+            ref = P.vec(vo)
+            assert np.abs(G.get(vg) - ref).max() / max(np.abs(ref).max(), 1e-300) < TOL
+    assert np.all(G.get(2)[P.constrained] == 0)
+
+
+@pytest.mark.parametrize("name,exe,dim", [("fsi3_linear_2d_shipped", "elasticity", 2),
+                                          ("block_linear_3d_q1_cg", "elasticity3d", 3)])
+def test_executable_linear(tmp_path, name, exe, dim):
+    """config 1 (shipped settings: linear, Direct, degree 3, 2D FSI3) and a small config 2 (3D Q1 block, CG)"""
+    stdout, rows = _run_case(name, exe, tmp_path)
+    get = _prm(name)
+    P = O.LinearProblem(_scenario_desc(get, dim, theta=0.5))
+    ids = P.interface_nodes
+    dt, exp = float(get("Time step size")), []
+    for k in range(len(rows)):
+        t = (0.0, -40.0 * min(1.0, (k + 1) / 2.0)) if dim == 2 else (0.0, -200.0, 0.0)
+        P.vec(O.L_STRESS)[:] = 0
+        for c in range(dim):
+            P.vec(O.L_STRESS)[ids * dim + c] = t[c]
+        rc, _, _ = P.step(O.SOLVER_DIRECT if P.n < 4000 else O.SOLVER_CG_SSOR, True)
+        assert rc == 0
+        exp.append(((k + 1) * dt, P.vec(O.L_D).reshape(-1, dim)[ids].copy()))
+    assert len(rows) >= 3
+    # CG with the reference's absolute tolerance 1e-10 on both sides: velocities agree to ~1e-10/|A|, so compare at 1e-6
+    for r, (t, u) in zip(rows, exp):
+        got = r[1:].reshape(-1, dim)
+        assert np.abs(got - u).max() / np.abs(u).max() < (1e-8 if get("Solver type") == "Direct" else 1e-6)
+    assert "No of iterations" in stdout and "Solve system" in stdout
