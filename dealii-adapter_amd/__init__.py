@@ -39,6 +39,15 @@ class CommDesc(C.Structure):
     _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("nccl_unique_id", C.c_void_p)]
 
 
+class PartitionInfo(C.Structure):
+    _fields_ = [("z0", C.c_int32), ("z1", C.c_int32), ("local_layers", C.c_int32), ("plane_nodes", C.c_int64),
+                ("node_offset", C.c_int64), ("nnodes_global", C.c_int64), ("nnodes_local", C.c_int64),
+                ("own_begin", C.c_int64), ("own_end", C.c_int64), ("up_send", C.c_int64), ("up_send_n", C.c_int64),
+                ("up_recv", C.c_int64), ("up_recv_n", C.c_int64), ("down_send", C.c_int64), ("down_send_n", C.c_int64),
+                ("down_recv", C.c_int64), ("down_recv_n", C.c_int64), ("local_reps", C.c_int32 * 3),
+                ("local_lo", C.c_double * 3), ("local_hi", C.c_double * 3), ("local_face_role", C.c_int32 * 6)]
+
+
 class SolverDesc(C.Structure):
     _fields_ = [("tol_lin", C.c_double), ("max_iterations_lin", C.c_double), ("max_iterations_NR", C.c_int32),
                 ("tol_f", C.c_double), ("tol_u", C.c_double)]
@@ -107,6 +116,10 @@ def lib():
         L.mi_spmv.argtypes = [vp, dp, dp]
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
+        L.mi_partition_describe.restype = C.c_int
+        L.mi_partition_describe.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(PartitionInfo)]
+        L.mi_comm_unique_id.restype = C.c_int
+        L.mi_comm_unique_id.argtypes = [C.c_void_p]
         L.mi_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
         L.mi_set_tuning.restype = C.c_int
         L.mi_bench_spmv.argtypes = [vp, C.c_int, dp]
@@ -131,11 +144,44 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def mesh_desc(dim, degree, reps, lo, hi, face_role):
+    md = MeshDesc()
+    md.dim, md.degree = dim, degree
+    reps = tuple(reps) + (1,) * (3 - len(reps))
+    lo = tuple(lo) + (0.0,) * (3 - len(lo))
+    hi = tuple(hi) + (0.0,) * (3 - len(hi))
+    for i in range(3):
+        md.reps[i], md.lo[i], md.hi[i] = reps[i], lo[i], hi[i]
+    for i in range(6):
+        md.face_role[i] = face_role[i]
+    return md
+
+
+def partition_describe(md, rank, size):
+    """host-only slab description (works without a GPU)"""
+    info = PartitionInfo()
+    rc = lib().mi_partition_describe(C.byref(md), rank, size, C.byref(info))
+    if rc != MI_OK:
+        raise MiError(rc, lib().mi_last_error(None).decode())
+    return info
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(128)
+    rc = lib().mi_comm_unique_id(buf)
+    if rc != MI_OK:
+        raise MiError(rc, lib().mi_last_error(None).decode())
+    return buf.raw
+
+
 class Context:
     """one device context = one (sub)domain of the structural problem on one GPU"""
 
     def __init__(self, dim=3, degree=2, reps=(4, 4, 4), lo=(0, 0, 0), hi=(1, 1, 1), face_role=None, mu=0.5e6, nu=0.4,
-                 rho=1000.0, body_force=(0, 0, 0), beta=0.25, gamma=0.5, delta_t=0.005, device=0, perturb=None):
+                 rho=1000.0, body_force=(0, 0, 0), beta=0.25, gamma=0.5, delta_t=0.005, device=0, perturb=None,
+                 slabs=1, rank=None, world=1, unique_id=None):
+        """slabs > 1: that many z-slabs inside this process (test mode); rank/world/unique_id: one slab per process
+        over RCCL"""
         L = lib()
         md, mat, nm = MeshDesc(), MaterialDesc(), NewmarkDesc()
         md.dim, md.degree = dim, degree
@@ -155,7 +201,14 @@ class Context:
         mat.mu, mat.nu, mat.rho = mu, nu, rho
         nm.beta, nm.gamma, nm.delta_t = beta, gamma, delta_t
         self.h = C.c_void_p()
-        rc = L.mi_ctx_create(C.byref(md), C.byref(mat), C.byref(nm), device, None, C.byref(self.h))
+        comm = None
+        if slabs > 1:
+            comm = CommDesc(-1, slabs, None)
+        elif world > 1 or unique_id is not None:
+            self._uid = C.create_string_buffer(unique_id, 128)
+            comm = CommDesc(rank or 0, world, C.cast(self._uid, C.c_void_p))
+        rc = L.mi_ctx_create(C.byref(md), C.byref(mat), C.byref(nm), device, C.byref(comm) if comm else None,
+                             C.byref(self.h))
         if rc != MI_OK:
             self.h = None
             raise MiError(rc, L.mi_last_error(None).decode())

@@ -4,14 +4,25 @@
 // solve_linear_system (nonlinear_elasticity.cc:410-499, :1044-1087, :1153-1211): it owns the device
 // state, orders the kernel launches on one HIP stream and turns HIP failures into status codes.
 // There is no CPU fallback: every entry point needs a working HIP device.
+//
+// Domain decomposition: the mesh is cut into z-slabs (mi_mesh.hpp SlabPartition).  The slab contexts that
+// advance together form a Team with one of three communication modes:
+//   single   one slab = the whole mesh (no communication; fused reductions)
+//   RCCL     one slab per process/GPU; ghost planes by ncclSend/ncclRecv, scalars by ncclAllReduce over xGMI
+//   emulated several slabs inside ONE process on one GPU sharing a stream; copies and a sum kernel stand in for
+//            the collectives.  Exists so that the decomposition can be parity-tested on a single-GPU box.
+// All entry points speak GLOBAL arrays (dofs, interface nodes), whatever the mode.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -20,12 +31,42 @@
 namespace mi_detail
 {
   std::string g_create_error;
-} // namespace mi_detail
-using namespace mi_detail;
 
+  // slots of the per-context device scalar block d_sc[16]
+  enum
+  {
+    SC_RZ0 = 0, // r.z ping-pong
+    SC_RZ1 = 1,
+    SC_TOL = 2,
+    SC_RES = 3,
+    SC_BNORM = 4,
+    SC_NORM_RHS = 8,
+    SC_NORM_UPD = 9,
+    SC_TOT = 10 // [rr, rz, pq, bb] all-reduced totals of the distributed CG
+  };
 
-namespace mi_detail
-{
+  struct Team
+  {
+    std::vector<mi_ctx *> members; // local slab contexts (1 unless emulated)
+    int                   size     = 1;
+    bool                  emulated = false;
+    ncclComm_t            nccl     = nullptr;
+    hipStream_t           stream   = nullptr;
+    int                   device   = 0;
+    int                   dim      = 0;
+    int64_t               n_global = 0, nnodes_global = 0;
+    std::vector<int64_t>  iface_global; // ascending global node ids
+    std::vector<double>   iface_xyz;    // their coordinates
+    double               *d_gbuf  = nullptr; // global-vector scratch (n_global doubles), on demand
+    double               *d_ifbuf = nullptr; // global interface scratch (n_if * dim doubles)
+    double              **d_sc_ptrs = nullptr; // emulated all-reduce: the members' scalar blocks
+  };
+
+  int team_size(const mi_ctx *c)
+  {
+    return c->team ? c->team->size : 1;
+  }
+
   int fail(mi_ctx *c, int code, const char *fmt, ...)
   {
     char    buf[512];
@@ -34,11 +75,24 @@ namespace mi_detail
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     if (c)
-      c->err = buf;
+      {
+        c->err = buf;
+        if (c->team && !c->team->members.empty())
+          c->team->members[0]->err = buf;
+      }
     else
       g_create_error = buf;
     return code;
   }
+
+#define NCCLCHK(ctx, call)                                                                                  \
+  do                                                                                                        \
+    {                                                                                                       \
+      ncclResult_t r_ = (call);                                                                             \
+      if (r_ != ncclSuccess)                                                                                \
+        return fail(ctx, MI_ECOMM, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    }                                                                                                       \
+  while (0)
 
   // ---- profiling stamps: HIP events on the context's stream, resolved after a synchronize
   int tic(mi_ctx *c, int cls)
@@ -78,7 +132,7 @@ namespace mi_detail
   int sync(mi_ctx *c)
   {
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    resolve_stamps(c);
+    resolve_stamps(c->team ? c->team->members[0] : c);
     return MI_OK;
   }
 
@@ -122,7 +176,7 @@ namespace mi_detail
     p.alpha4 = c->alpha[4];
     p.alpha5 = c->alpha[5];
     p.alpha6 = c->alpha[6];
-    p.n      = c->n;
+    p.n      = c->n; // whole local vector: pointwise updates keep the ghost copies consistent without communication
     return p;
   }
 
@@ -130,16 +184,16 @@ namespace mi_detail
                              const int32_t *done)
   {
     mi::SpmvParams p{};
-    p.rowptr   = c->d_rowptr;
-    p.col      = c->d_col;
-    p.vals     = c->d_vals;
-    p.x        = x;
-    p.y        = y;
-    p.dotv     = dotv;
-    p.partials = partials;
-    p.done     = done;
-    p.row0     = 0;
-    p.nrows    = c->mesh.nnodes;
+    p.rowptr           = c->d_rowptr;
+    p.col              = c->d_col;
+    p.vals             = c->d_vals;
+    p.x                = x;
+    p.y                = y;
+    p.dotv             = dotv;
+    p.partials         = partials;
+    p.done             = done;
+    p.row0             = c->slab.own_begin;
+    p.nrows            = c->slab.own_end - c->slab.own_begin;
     p.rowptr_host_nnzb = c->mesh.nnzb;
     return p;
   }
@@ -148,22 +202,22 @@ namespace mi_detail
                              const int32_t *done)
   {
     mi::SellParams p{};
-    p.perm     = c->d_sell_perm;
-    p.len      = c->d_sell_len;
-    p.off      = c->d_sell_off;
-    p.col      = c->d_sell_col;
-    p.vals     = c->active_sell_vals ? c->active_sell_vals : c->d_sell_vals;
-    p.x        = x;
-    p.y        = y;
-    p.dotv     = dotv;
-    p.partials = partials;
-    p.done     = done;
-    p.nslices  = int32_t(c->mesh.sell_nslices);
+    p.perm      = c->d_sell_perm;
+    p.len       = c->d_sell_len;
+    p.off       = c->d_sell_off;
+    p.col       = c->d_sell_col;
+    p.vals      = c->active_sell_vals ? c->active_sell_vals : c->d_sell_vals;
+    p.x         = x;
+    p.y         = y;
+    p.dotv      = dotv;
+    p.partials  = partials;
+    p.done      = done;
+    p.nslices   = int32_t(c->mesh.sell_nslices);
     p.xcd_remap = c->xcd_remap;
     return p;
   }
 
-  // y = K x (+ optional fused dot partials) with the selected kernel variant
+  // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done)
   {
     if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
@@ -174,14 +228,80 @@ namespace mi_detail
                       c->maxrow);
   }
 
-  // the enqueue part of assemble_system (no host synchronisation)
+  // ---- team collectives (no-ops for a single slab) -------------------------------------------------------
+  // sum over all slabs of d_sc[off .. off+cnt) in place
+  int team_allreduce(Team &T, int off, int cnt)
+  {
+    if (T.size == 1)
+      return MI_OK;
+    mi_ctx *c0 = T.members[0];
+    if (T.nccl)
+      NCCLCHK(c0, ncclAllReduce(c0->d_sc + off, c0->d_sc + off, size_t(cnt), ncclDouble, ncclSum, T.nccl, T.stream));
+    else
+      mi::launch_team_sum(T.d_sc_ptrs, int(T.members.size()), off, cnt, T.stream);
+    return MI_OK;
+  }
+
+  // ghost planes of a local vector from the neighbouring slabs
+  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec)
+  {
+    if (T.size == 1)
+      return MI_OK;
+    const int D = T.dim;
+    if (T.nccl)
+      {
+        mi_ctx                  *c = T.members[0];
+        const mi::SlabPartition &s = c->slab;
+        double                  *v = vec(c);
+        NCCLCHK(c, ncclGroupStart());
+        if (s.up_send_n)
+          {
+            NCCLCHK(c, ncclSend(v + s.up_send * D, size_t(s.up_send_n) * D, ncclDouble, s.rank + 1, T.nccl, T.stream));
+            NCCLCHK(c, ncclRecv(v + s.up_recv * D, size_t(s.up_recv_n) * D, ncclDouble, s.rank + 1, T.nccl, T.stream));
+          }
+        if (s.down_send_n)
+          {
+            NCCLCHK(c, ncclSend(v + s.down_send * D, size_t(s.down_send_n) * D, ncclDouble, s.rank - 1, T.nccl, T.stream));
+            NCCLCHK(c, ncclRecv(v + s.down_recv * D, size_t(s.down_recv_n) * D, ncclDouble, s.rank - 1, T.nccl, T.stream));
+          }
+        NCCLCHK(c, ncclGroupEnd());
+        return MI_OK;
+      }
+    for (size_t r = 0; r + 1 < T.members.size(); ++r)
+      {
+        mi_ctx *a = T.members[r], *b = T.members[r + 1];
+        HIPCHK(a, hipMemcpyAsync(vec(b) + b->slab.down_recv * D, vec(a) + a->slab.up_send * D,
+                                 size_t(a->slab.up_send_n) * D * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
+        HIPCHK(a, hipMemcpyAsync(vec(a) + a->slab.up_recv * D, vec(b) + b->slab.down_send * D,
+                                 size_t(a->slab.up_recv_n) * D * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
+      }
+    return MI_OK;
+  }
+
+  // sum over all ranks of a device buffer that every rank holds in full (global vector / interface scratch)
+  int team_allreduce_buffer(Team &T, double *buf, size_t n)
+  {
+    if (T.nccl)
+      NCCLCHK(T.members[0], ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, T.nccl, T.stream));
+    return MI_OK; // emulated / single: all slabs wrote into the same buffer already
+  }
+
+  int ensure_gbuf(Team &T)
+  {
+    if (!T.d_gbuf)
+      HIPCHK(T.members[0], hipMalloc((void **)&T.d_gbuf, size_t(T.n_global) * sizeof(double)));
+    return MI_OK;
+  }
+
+  // the enqueue part of assemble_system for one slab (no host synchronisation)
   int enqueue_assembly(mi_ctx *c)
   {
     const int64_t dd = int64_t(c->dim) * c->dim;
     HIPCHK(c, hipMemsetAsync(c->d_vals, 0, size_t(c->mesh.nnzb) * dd * sizeof(double), c->stream)); // :1054
     HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SYSTEM_RHS), 0, size_t(c->n) * sizeof(double), c->stream)); // :1055
     mi::AsmParams p  = asm_params(c);
-    const int     t0 = tic(c, MI_T_ASSEMBLE_CELLS);
+    mi_ctx       *c0 = c->team->members[0];
+    const int     t0 = tic(c0, MI_T_ASSEMBLE_CELLS);
     for (int col = 0; col < c->mesh.ncolours; ++col)
       {
         p.cell_begin = c->mesh.colour_begin[col];
@@ -193,93 +313,344 @@ namespace mi_detail
         if (mi::launch_neumann_faces(c->dim, c->degree, p, c->d_faces, fb, fc, c->stream))
           return fail(c, MI_EINVAL, "no face kernel for dim=%d degree=%d", c->dim, c->degree);
       }
-    toc(c, t0);
+    toc(c0, t0);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
-    // SpMV-side copy of the tangent in sliced-ELL order
+    // SpMV-side copy of the tangent (owned rows) in sliced-ELL order
     mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
                            c->d_sell_vals, c->stream);
     HIPCHK(c, hipGetLastError());
     return MI_OK;
   }
-  // Jacobi-PCG (deal.II SolverCG semantics: start from x, stop when ||r||_2 <= tolerance) on the active matrix;
-  // followed by constraints.distribute (x[constrained] = 0)
-  int cg_run(mi_ctx *c, double *x, const double *b, double tol, int64_t max_it, int *its, double *res)
-  {
-  const int tt = tic(c, MI_T_CG_TOTAL);
-  mi::CgParams cg{};
-  cg.x        = x;
-  cg.r        = c->work(W_R);
-  cg.p        = c->work(W_P);
-  cg.q        = c->work(W_Q);
-  cg.dinv     = c->active_dinv ? c->active_dinv : c->work(W_DINV);
-  cg.part_rr  = c->part(0);
-  cg.part_rz  = c->part(1);
-  cg.part_pq  = c->part(2);
-  cg.sc       = c->d_sc;
-  cg.flags    = c->d_flags;
-  cg.n        = c->n;
-  cg.npart    = c->grid_vec;
-  cg.npart_pq = c->grid_spmv;
 
-  // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
+  // l2 norm over the unconstrained owned dofs of vector `which`, summed over the team (:549-576)
+  int team_masked_norm(Team &T, int which, int slot, double *out)
   {
-    const int t = tic(c, MI_T_SPMV);
-    enqueue_spmv(c, x, cg.q, nullptr, nullptr, nullptr);
-    toc(c, t);
+    mi_ctx *c0 = T.members[0];
+    for (mi_ctx *m : T.members)
+      mi::launch_masked_norm(m->dim, m->vec(which) + m->own0, m->d_cmask + m->slab.own_begin, m->own_n, m->part(3),
+                             m->grid_vec, m->d_sc + slot, m->stream);
+    int rc = team_allreduce(T, slot, 1);
+    if (rc)
+      return rc;
+    HIPCHK(c0, hipGetLastError());
+    HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc + slot, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+    if ((rc = sync(c0)))
+      return rc;
+    *out = std::sqrt(c0->h_pinned[0]);
+    return MI_OK;
   }
-  mi::launch_cg_init_residual(cg, b, c->part(4), c->grid_vec, c->stream);
-  mi::launch_cg_set_tolerance(cg, c->part(4), tol, c->stream);
 
-  int32_t *h_flags = reinterpret_cast<int32_t *>(c->h_pinned + 8);
-  int64_t  it      = 0;
-  bool     done    = false;
-  while (!done && it < max_it)
+  // Jacobi-PCG (deal.II SolverCG semantics: start from x, stop when ||r||_2 <= tolerance) on the active matrix of
+  // every slab of the team; followed by constraints.distribute (x[constrained] = 0)
+  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res)
+  {
+    Team      &T    = *c->team;
+    mi_ctx    *c0   = T.members[0];
+    const bool dist = T.size > 1;
+    const int  tt   = tic(c0, MI_T_CG_TOTAL);
+    std::vector<mi::CgParams> cgs;
+    for (mi_ctx *m : T.members)
+      {
+        mi::CgParams cg{};
+        cg.x        = m->vec(x_id) + m->own0;
+        cg.r        = m->work(W_R) + m->own0;
+        cg.p        = m->work(W_P) + m->own0;
+        cg.q        = m->work(W_Q) + m->own0;
+        cg.dinv     = (m->active_dinv ? m->active_dinv : m->work(W_DINV)) + m->own0;
+        cg.part_rr  = m->part(0);
+        cg.part_rz  = m->part(1);
+        cg.part_pq  = m->part(2);
+        cg.sc       = m->d_sc;
+        cg.flags    = m->d_flags;
+        cg.n        = m->own_n;
+        cg.npart    = m->grid_vec;
+        cg.npart_pq = m->grid_spmv;
+        cg.totals   = dist ? m->d_sc + SC_TOT : nullptr;
+        cgs.push_back(cg);
+      }
+    const size_t R = T.members.size();
+    int          rc;
+    auto         x_of = [x_id](mi_ctx *m) { return m->vec(x_id); };
+    auto         p_of = [](mi_ctx *m) { return m->work(W_P); };
+
+    // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
+    if ((rc = team_halo(T, x_of)))
+      return rc;
     {
-      const int64_t stop = std::min<int64_t>(max_it, it + CG_BATCH);
-      for (; it < stop;)
-        {
-          ++it;
-          int t = tic(c, MI_T_CG_VECTOR);
-          mi::launch_cg_update_p(cg, int(it), c->grid_vec, c->stream);
-          toc(c, t);
-          t = tic(c, MI_T_SPMV);
-          enqueue_spmv(c, cg.p, cg.q, cg.p, cg.part_pq, cg.flags);
-          toc(c, t);
-          t = tic(c, MI_T_CG_VECTOR);
-          mi::launch_cg_update_xr(cg, int(it), c->grid_vec, c->stream);
-          toc(c, t);
-        }
-      mi::launch_cg_final_check(cg, int(it), c->stream);
-      HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipMemcpyAsync(h_flags, c->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      done = h_flags[0] != 0;
+      const int t = tic(c0, MI_T_SPMV);
+      for (mi_ctx *m : T.members)
+        enqueue_spmv(m, m->vec(x_id), m->work(W_Q), nullptr, nullptr, nullptr);
+      toc(c0, t);
     }
-  if (max_it <= 0)
-    {
-      mi::launch_cg_final_check(cg, 0, c->stream);
-      HIPCHK(c, hipMemcpyAsync(h_flags, c->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t k = 0; k < R; ++k)
+      {
+        mi_ctx *m = T.members[k];
+        mi::launch_cg_init_residual(cgs[k], m->vec(b_id) + m->own0, m->part(4), m->grid_vec, m->stream);
+        if (dist)
+          {
+            mi::launch_reduce_to_totals(cgs[k].part_rr, m->grid_vec, m->d_sc + SC_TOT, cgs[k].part_rz, m->grid_vec,
+                                        m->d_sc + SC_TOT + 1, nullptr, m->stream);
+            mi::launch_reduce_to_totals(m->part(4), m->grid_vec, m->d_sc + SC_TOT + 3, nullptr, 0, nullptr, nullptr,
+                                        m->stream);
+          }
+      }
+    if ((rc = team_allreduce(T, SC_TOT, 4)))
+      return rc;
+    for (size_t k = 0; k < R; ++k)
+      mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
+
+    int32_t *h_flags = reinterpret_cast<int32_t *>(c0->h_pinned + 8);
+    int64_t  it      = 0;
+    bool     done    = false;
+    auto     poll    = [&]() -> int {
+      HIPCHK(c0, hipGetLastError());
+      HIPCHK(c0, hipMemcpyAsync(h_flags, c0->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c0->stream));
+      HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+      HIPCHK(c0, hipStreamSynchronize(c0->stream));
       done = h_flags[0] != 0;
-    }
-  mi::launch_zero_constrained(c->dim, x, c->d_cmask, c->n, c->stream); // constraints.distribute (:1208)
-  toc(c, tt);
-  HIPCHK(c, hipGetLastError());
-  int rc = sync(c);
-  if (rc)
+      return MI_OK;
+    };
+    while (!done && it < max_it)
+      {
+        const int64_t stop = std::min<int64_t>(max_it, it + CG_BATCH);
+        for (; it < stop;)
+          {
+            ++it;
+            int t = tic(c0, MI_T_CG_VECTOR);
+            for (size_t k = 0; k < R; ++k)
+              mi::launch_cg_update_p(cgs[k], int(it), T.members[k]->grid_vec, T.members[k]->stream);
+            toc(c0, t);
+            if ((rc = team_halo(T, p_of)))
+              return rc;
+            t = tic(c0, MI_T_SPMV);
+            for (size_t k = 0; k < R; ++k)
+              enqueue_spmv(T.members[k], T.members[k]->work(W_P), T.members[k]->work(W_Q), T.members[k]->work(W_P),
+                           cgs[k].part_pq, cgs[k].flags);
+            toc(c0, t);
+            if (dist)
+              {
+                for (size_t k = 0; k < R; ++k)
+                  mi::launch_reduce_to_totals(cgs[k].part_pq, T.members[k]->grid_spmv, T.members[k]->d_sc + SC_TOT + 2,
+                                              nullptr, 0, nullptr, cgs[k].flags, T.members[k]->stream);
+                if ((rc = team_allreduce(T, SC_TOT + 2, 1)))
+                  return rc;
+              }
+            t = tic(c0, MI_T_CG_VECTOR);
+            for (size_t k = 0; k < R; ++k)
+              mi::launch_cg_update_xr(cgs[k], int(it), T.members[k]->grid_vec, T.members[k]->stream);
+            toc(c0, t);
+            if (dist)
+              {
+                for (size_t k = 0; k < R; ++k)
+                  mi::launch_reduce_to_totals(cgs[k].part_rr, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT,
+                                              cgs[k].part_rz, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT + 1,
+                                              cgs[k].flags, T.members[k]->stream);
+                if ((rc = team_allreduce(T, SC_TOT, 2)))
+                  return rc;
+              }
+          }
+        for (size_t k = 0; k < R; ++k)
+          mi::launch_cg_final_check(cgs[k], int(it), T.members[k]->stream);
+        if ((rc = poll()))
+          return rc;
+      }
+    if (max_it <= 0)
+      {
+        for (size_t k = 0; k < R; ++k)
+          mi::launch_cg_final_check(cgs[k], 0, T.members[k]->stream);
+        if ((rc = poll()))
+          return rc;
+      }
+    for (mi_ctx *m : T.members) // constraints.distribute (:1208)
+      mi::launch_zero_constrained(m->dim, m->vec(x_id), m->d_cmask, m->n, m->stream);
+    if ((rc = team_halo(T, x_of))) // ghost copies of the solution
+      return rc;
+    toc(c0, tt);
+    HIPCHK(c0, hipGetLastError());
+    if ((rc = sync(c0)))
+      return rc;
+    if (its)
+      *its = h_flags[1];
+    if (res)
+      *res = c0->h_pinned[SC_RES];
+    if (!done)
+      return fail(c0, MI_ENOCONV_LIN, "CG did not reach tolerance %.3e within %lld iterations (residual %.3e)",
+                  std::fabs(tol), (long long)max_it, c0->h_pinned[SC_RES]);
+    return MI_OK;
+  }
+
+  void destroy_member(mi_ctx *c)
+  {
+    if (!c)
+      return;
+    linear_destroy(c);
+    for (auto &s : c->stamps)
+      {
+        hipEventDestroy(s.a);
+        hipEventDestroy(s.b);
+      }
+    void *ptrs[] = {c->d_conn,      c->d_rowptr,    c->d_col,         c->d_diagpos,     c->d_iface_nodes, c->d_faces,
+                    c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
+                    c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
+                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
+                    c->d_own_if_nodes, c->d_own_if_slots};
+    for (void *p : ptrs)
+      if (p)
+        hipFree(p);
+    if (c->h_pinned)
+      hipHostFree(c->h_pinned);
+    delete c;
+  }
+
+  // one slab context: local box mesh (own layers + ghost layer), device arrays, launch geometry
+  int create_member(Team &T, const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int rank,
+                    mi_ctx **out)
+  {
+    mi_ctx *c = new mi_ctx;
+    *out      = c;
+    c->team   = &T;
+    c->device = T.device;
+    c->stream = T.stream;
+    c->dim    = md->dim;
+    c->degree = md->degree;
+    c->mat    = *mat;
+    c->nm     = *nm;
+    try
+      {
+        c->slab = mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, T.size);
+        const mi::SlabPartition &s = c->slab;
+        const double *perturb = md->vertex_perturbation ? md->vertex_perturbation + s.vertex_offset * md->dim : nullptr;
+        if (T.size == 1)
+          c->mesh.build(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, perturb);
+        else
+          c->mesh.build(md->dim, md->degree, s.local_reps, md->lo, md->hi, s.local_face_role, perturb, s.z0,
+                        md->reps[md->dim - 1], s.own_begin, s.own_end);
+        c->tab.build(md->degree, md->degree + 2); // qf_cell(p+2), qf_face(p+2): nonlinear_elasticity.cc:74-75
+      }
+    catch (const std::exception &e)
+      {
+        return fail(c, MI_EINVAL, "%s", e.what());
+      }
+    if (md->dim == 3 && md->degree > 2)
+      return fail(c, MI_EINVAL, "3D elements above degree 2 are not supported by the device kernels");
+    const mi::HostMesh &m = c->mesh;
+    c->n     = m.ndofs;
+    c->own0  = c->slab.own_begin * c->dim;
+    c->own_n = (c->slab.own_end - c->slab.own_begin) * c->dim;
+    c->kappa = (2.0 * mat->mu * (1.0 + mat->nu)) / (3.0 * (1.0 - 2.0 * mat->nu)); // neo_hook_material.h:20
+    // nonlinear_elasticity.h:242-250
+    c->alpha[1] = 1. / (nm->beta * std::pow(nm->delta_t, 2));
+    c->alpha[2] = 1. / (nm->beta * nm->delta_t);
+    c->alpha[3] = (1 - (2 * nm->beta)) / (2 * nm->beta);
+    c->alpha[4] = nm->gamma / (nm->beta * nm->delta_t);
+    c->alpha[5] = 1 - (nm->gamma / nm->beta);
+    c->alpha[6] = (1 - (nm->gamma / (2 * nm->beta))) * nm->delta_t;
+
+    int rc;
+#define UP(dst, src)                    \
+  if ((rc = upload(c, &(dst), (src))))  \
     return rc;
-  if (its)
-    *its = h_flags[1];
-  if (res)
-    *res = c->h_pinned[3];
-  if (!done)
-    return fail(c, MI_ENOCONV_LIN, "CG did not reach tolerance %.3e within %lld iterations (residual %.3e)", std::fabs(tol),
-                (long long)max_it, c->h_pinned[3]);
-  return MI_OK;
-}
+    UP(c->d_conn, m.conn)
+    UP(c->d_cverts, m.cverts)
+    UP(c->d_off, m.off)
+    UP(c->d_rowptr, m.rowptr)
+    UP(c->d_col, m.colidx)
+    UP(c->d_diagpos, m.diagpos)
+    UP(c->d_cmask, m.cmask)
+    UP(c->d_iface_nodes, m.iface_nodes)
+    {
+      std::vector<int32_t> f;
+      for (const auto &x : m.iface_faces)
+        {
+          f.push_back(x.cell);
+          f.push_back(x.face);
+        }
+      UP(c->d_faces, f)
+    }
+    UP(c->d_tab, c->tab.packed())
+    UP(c->d_sell_perm, m.sell_perm)
+    UP(c->d_sell_len, m.sell_len)
+    UP(c->d_sell_off, m.sell_off)
+    // local interface nodes -> slots of the global interface list; owned ones feed the displacement gather
+    {
+      std::vector<int32_t> own_nodes, own_slots;
+      for (int32_t ln : m.iface_nodes)
+        {
+          const int64_t g  = ln + c->slab.node_offset;
+          const auto    it = std::lower_bound(T.iface_global.begin(), T.iface_global.end(), g);
+          if (it == T.iface_global.end() || *it != g)
+            return fail(c, MI_EINVAL, "internal error: interface node %lld missing from the global list", (long long)g);
+          const int32_t slot = int32_t(it - T.iface_global.begin());
+          c->iface_slot.push_back(slot);
+          if (ln >= c->slab.own_begin && ln < c->slab.own_end)
+            {
+              own_nodes.push_back(ln);
+              own_slots.push_back(slot);
+            }
+        }
+      c->n_own_if = int(own_nodes.size());
+      UP(c->d_own_if_nodes, own_nodes)
+      UP(c->d_own_if_slots, own_slots)
+    }
+#undef UP
+    const size_t dd = size_t(c->dim) * c->dim;
+    HIPCHK(c, hipMalloc((void **)&c->d_sell_col, std::max<size_t>(1, size_t(m.sell_nblk64) * 64) * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc((void **)&c->d_sell_vals, std::max<size_t>(1, size_t(m.sell_nblk64) * 64 * dd) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_vals, (size_t(m.nnzb) * dd + 2) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_vecs, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_work, size_t(W_COUNT) * size_t(c->n) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_saved, size_t(6) * size_t(c->n) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_part, size_t(8) * MAX_PART * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_sc, 16 * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_flags, 4 * sizeof(int32_t)));
+    const size_t nif = std::max<size_t>(m.iface_nodes.size(), 1) * size_t(c->dim);
+    HIPCHK(c, hipMalloc((void **)&c->d_iface_buf, nif * sizeof(double)));
+    c->h_pinned_doubles = std::max(nif, T.iface_global.size() * size_t(c->dim)) + 64;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_pinned, c->h_pinned_doubles * sizeof(double), hipHostMallocDefault));
+    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, size_t(m.nnzb) * dd * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_work, 0, size_t(W_COUNT) * size_t(c->n) * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_sc, 0, 16 * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_sell_vals, 0, std::max<size_t>(1, size_t(m.sell_nblk64) * 64 * dd) * sizeof(double),
+                             c->stream));
+    mi::launch_sell_build_cols(sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_col,
+                               c->d_sell_col, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+
+    // launch geometry: vector kernels use a fixed grid so that reduction partials are deterministic;
+    // SpMV: one wavefront per 64-row slice (measured best), grid-stride above MAX_PART workgroups
+    c->grid_vec  = int(std::max<int64_t>(1, std::min<int64_t>(1024, (c->own_n + 255) / 256)));
+    c->grid_spmv = int(std::max<int64_t>(1, std::min<int64_t>(MAX_PART, (m.sell_nslices + 3) / 4)));
+    for (int64_t nd = 0; nd < m.nnodes; ++nd)
+      c->maxrow = std::max(c->maxrow, int(m.rowptr[size_t(nd) + 1] - m.rowptr[size_t(nd)]));
+    if (const char *v = getenv("MI_SPMV_VARIANT"))
+      c->spmv_variant = atoi(v);
+    return MI_OK;
+  }
+
+  void destroy_team(Team *T)
+  {
+    if (!T)
+      return;
+    hipSetDevice(T->device);
+    if (T->stream)
+      hipStreamSynchronize(T->stream);
+    for (mi_ctx *m : T->members)
+      destroy_member(m);
+    if (T->nccl)
+      ncclCommDestroy(T->nccl);
+    for (void *p : {(void *)T->d_gbuf, (void *)T->d_ifbuf, (void *)T->d_sc_ptrs})
+      if (p)
+        hipFree(p);
+    if (T->stream)
+      hipStreamDestroy(T->stream);
+    delete T;
+  }
 } // namespace mi_detail
+
+using namespace mi_detail;
 
 extern "C" {
 
@@ -290,29 +661,18 @@ const char *mi_last_error(const mi_ctx *ctx)
 
 void mi_ctx_destroy(mi_ctx *c)
 {
-  if (!c)
-    return;
-  hipSetDevice(c->device);
-  if (c->stream)
-    hipStreamSynchronize(c->stream);
-  linear_destroy(c);
-  for (auto &s : c->stamps)
-    {
-      hipEventDestroy(s.a);
-      hipEventDestroy(s.b);
-    }
-  void *ptrs[] = {c->d_conn, c->d_rowptr, c->d_col,  c->d_diagpos, c->d_iface_nodes, c->d_faces, c->d_flags,
-                  c->d_cverts, c->d_tab, c->d_vals, c->d_vecs, c->d_work, c->d_saved, c->d_part,
-                  c->d_sc, c->d_iface_buf, c->d_off, c->d_cmask, c->d_sell_perm, c->d_sell_len, c->d_sell_col,
-                  c->d_sell_off, c->d_sell_vals};
-  for (void *p : ptrs)
-    if (p)
-      hipFree(p);
-  if (c->h_pinned)
-    hipHostFree(c->h_pinned);
-  if (c->stream)
-    hipStreamDestroy(c->stream);
-  delete c;
+  if (c)
+    destroy_team(c->team);
+}
+
+int mi_comm_unique_id(void *out128)
+{
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess)
+    return fail(nullptr, MI_ECOMM, "ncclGetUniqueId failed");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  std::memcpy(out128, &id, sizeof(id));
+  return MI_OK;
 }
 
 int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int device_id,
@@ -321,236 +681,274 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   if (!md || !mat || !nm || !out)
     return fail(nullptr, MI_EINVAL, "null argument");
   *out = nullptr;
-  if (comm && comm->size > 1)
-    return fail(nullptr, MI_EINVAL, "domain decomposition is not available in this build (comm size %d)", comm->size);
+  if (md->dim != 2 && md->dim != 3)
+    return fail(nullptr, MI_EINVAL, "dim must be 2 or 3");
   if (!(mat->nu > -1.0 && mat->nu < 0.5) || !(mat->mu > 0.0) || mat->rho < 0.0)
     return fail(nullptr, MI_EINVAL, "material out of range (mu>0, -1<nu<0.5, rho>=0)");
   if (!(nm->beta > 0.0) || !(nm->delta_t > 0.0))
     return fail(nullptr, MI_EINVAL, "Newmark beta and time step must be positive");
+  const int  nranks   = comm ? comm->size : 1;
+  const bool emulated = comm && comm->size > 1 && comm->rank < 0;
+  if (nranks < 1 || (comm && !emulated && (comm->rank < 0 || comm->rank >= nranks)))
+    return fail(nullptr, MI_EINVAL, "bad communicator description (rank %d of %d)", comm ? comm->rank : 0, nranks);
+  if (nranks > 1 && !emulated && !comm->nccl_unique_id)
+    return fail(nullptr, MI_EINVAL, "a ncclUniqueId is required for %d ranks", nranks);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(nullptr, MI_EHIP, "no HIP device available (the hot path has no CPU fallback)");
   if (device_id < 0 || device_id >= ndev)
     return fail(nullptr, MI_EINVAL, "device %d out of range (%d devices)", device_id, ndev);
 
-  mi_ctx *c = new mi_ctx;
-  c->device = device_id;
-  c->dim    = md->dim;
-  c->degree = md->degree;
-  c->mat    = *mat;
-  c->nm     = *nm;
-  auto bail = [&](int code) {
-    g_create_error = c->err;
-    mi_ctx_destroy(c);
+  Team *T     = new Team;
+  T->size     = nranks;
+  T->emulated = emulated;
+  T->device   = device_id;
+  T->dim      = md->dim;
+  auto bail   = [&](int code, const std::string &msg) {
+    g_create_error = msg;
+    destroy_team(T);
     return code;
   };
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&T->stream, hipStreamNonBlocking) != hipSuccess)
+    return bail(MI_EHIP, "cannot create a HIP stream on the selected device");
   try
     {
-      c->mesh.build(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, md->vertex_perturbation);
-      c->tab.build(md->degree, md->degree + 2); // qf_cell(p+2), qf_face(p+2): nonlinear_elasticity.cc:74-75
+      if (md->degree < 1 || md->degree > 4)
+        throw std::invalid_argument("polynomial degree must be in 1..4");
+      for (int d = 0; d < md->dim; ++d)
+        if (md->reps[d] < 1)
+          throw std::invalid_argument("repetitions must be >= 1");
+      T->iface_global = mi::global_interface_nodes(md->dim, md->degree, md->reps, md->face_role);
+      const mi::SlabPartition s0 =
+        mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, 0, nranks);
+      T->nnodes_global = s0.nnodes_global;
+      T->n_global      = s0.nnodes_global * md->dim;
     }
   catch (const std::exception &e)
     {
-      c->err = e.what();
-      return bail(MI_EINVAL);
+      return bail(MI_EINVAL, e.what());
     }
-  if (md->dim == 3 && md->degree > 2)
+  if (comm && !emulated && comm->nccl_unique_id) // also for one rank: exercises communicator + all-reduce
     {
-      c->err = "3D elements above degree 2 are not supported by the device kernels";
-      return bail(MI_EINVAL);
+      ncclUniqueId id;
+      std::memcpy(&id, comm->nccl_unique_id, sizeof(id));
+      const ncclResult_t r = ncclCommInitRank(&T->nccl, nranks, id, comm->rank);
+      if (r != ncclSuccess)
+        return bail(MI_ECOMM, std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
     }
-  c->n     = c->mesh.ndofs;
-  c->kappa = (2.0 * mat->mu * (1.0 + mat->nu)) / (3.0 * (1.0 - 2.0 * mat->nu)); // neo_hook_material.h:20
-  // nonlinear_elasticity.h:242-250
-  c->alpha[1] = 1. / (nm->beta * std::pow(nm->delta_t, 2));
-  c->alpha[2] = 1. / (nm->beta * nm->delta_t);
-  c->alpha[3] = (1 - (2 * nm->beta)) / (2 * nm->beta);
-  c->alpha[4] = nm->gamma / (nm->beta * nm->delta_t);
-  c->alpha[5] = 1 - (nm->gamma / nm->beta);
-  c->alpha[6] = (1 - (nm->gamma / (2 * nm->beta))) * nm->delta_t;
-
-#define CREATE_CHK(call)                  \
-  do                                      \
-    {                                     \
-      int rc_ = (call);                   \
-      if (rc_ != MI_OK)                   \
-        return bail(rc_);                 \
-    }                                     \
-  while (0)
-#define CREATE_HIP(call)                                                                         \
-  do                                                                                             \
-    {                                                                                            \
-      hipError_t e_ = (call);                                                                    \
-      if (e_ != hipSuccess)                                                                      \
-        {                                                                                        \
-          fail(c, MI_EHIP, "%s failed: %s", #call, hipGetErrorString(e_));                       \
-          return bail(MI_EHIP);                                                                  \
-        }                                                                                        \
-    }                                                                                            \
-  while (0)
-
-  CREATE_HIP(hipSetDevice(device_id));
-  CREATE_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  const mi::HostMesh &m = c->mesh;
-  CREATE_CHK(upload(c, &c->d_conn, m.conn));
-  CREATE_CHK(upload(c, &c->d_cverts, m.cverts));
-  CREATE_CHK(upload(c, &c->d_off, m.off));
-  CREATE_CHK(upload(c, &c->d_rowptr, m.rowptr));
-  CREATE_CHK(upload(c, &c->d_col, m.colidx));
-  CREATE_CHK(upload(c, &c->d_diagpos, m.diagpos));
-  CREATE_CHK(upload(c, &c->d_cmask, m.cmask));
-  CREATE_CHK(upload(c, &c->d_iface_nodes, m.iface_nodes));
+  const int first = emulated ? 0 : (comm ? comm->rank : 0), count = emulated ? nranks : 1;
+  for (int r = first; r < first + count; ++r)
+    {
+      mi_ctx   *m  = nullptr;
+      const int rc = create_member(*T, md, mat, nm, r, &m);
+      T->members.push_back(m);
+      if (rc != MI_OK)
+        return bail(rc, m->err);
+    }
+  mi_ctx *c0 = T->members[0];
+  // global interface scratch + coordinates of the global interface nodes (summed over the owners)
   {
-    std::vector<int32_t> f;
-    for (const auto &x : m.iface_faces)
+    const size_t nifg = std::max<size_t>(1, T->iface_global.size() * size_t(md->dim));
+    if (hipMalloc((void **)&T->d_ifbuf, nifg * sizeof(double)) != hipSuccess)
+      return bail(MI_EHIP, "hipMalloc of the interface scratch failed");
+    std::vector<double> xyz(nifg, 0.0);
+    for (mi_ctx *m : T->members)
+      for (size_t i = 0; i < m->mesh.iface_nodes.size(); ++i)
+        {
+          const int32_t ln = m->mesh.iface_nodes[i];
+          if (ln >= m->slab.own_begin && ln < m->slab.own_end)
+            for (int k = 0; k < md->dim; ++k)
+              xyz[size_t(m->iface_slot[i]) * md->dim + k] = m->mesh.node_xyz[size_t(ln) * md->dim + k];
+        }
+    if (T->nccl)
       {
-        f.push_back(x.cell);
-        f.push_back(x.face);
+        if (hipMemcpy(T->d_ifbuf, xyz.data(), nifg * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            ncclAllReduce(T->d_ifbuf, T->d_ifbuf, nifg, ncclDouble, ncclSum, T->nccl, T->stream) != ncclSuccess ||
+            hipStreamSynchronize(T->stream) != hipSuccess ||
+            hipMemcpy(xyz.data(), T->d_ifbuf, nifg * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+          return bail(MI_ECOMM, "exchange of the interface coordinates failed");
       }
-    CREATE_CHK(upload(c, &c->d_faces, f));
+    T->iface_xyz = xyz;
   }
-  CREATE_CHK(upload(c, &c->d_tab, c->tab.packed()));
-  const size_t dd = size_t(c->dim) * c->dim;
-  CREATE_HIP(hipMalloc((void **)&c->d_vals, (size_t(m.nnzb) * dd + 2) * sizeof(double))); // +2: 16-byte row reads
-  CREATE_CHK(upload(c, &c->d_sell_perm, m.sell_perm));
-  CREATE_CHK(upload(c, &c->d_sell_len, m.sell_len));
-  CREATE_CHK(upload(c, &c->d_sell_off, m.sell_off));
-  CREATE_HIP(hipMalloc((void **)&c->d_sell_col, size_t(m.sell_nblk64) * 64 * sizeof(int32_t)));
-  CREATE_HIP(hipMalloc((void **)&c->d_sell_vals, size_t(m.sell_nblk64) * 64 * dd * sizeof(double)));
-  CREATE_HIP(hipMalloc((void **)&c->d_vecs, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double)));
-  CREATE_HIP(hipMalloc((void **)&c->d_work, size_t(W_COUNT) * size_t(c->n) * sizeof(double)));
-  CREATE_HIP(hipMalloc((void **)&c->d_saved, size_t(6) * size_t(c->n) * sizeof(double)));
-  CREATE_HIP(hipMalloc((void **)&c->d_part, size_t(8) * MAX_PART * sizeof(double)));
-  CREATE_HIP(hipMalloc((void **)&c->d_sc, 16 * sizeof(double)));
-  CREATE_HIP(hipMalloc((void **)&c->d_flags, 4 * sizeof(int32_t)));
-  const size_t nif = std::max<size_t>(m.iface_nodes.size(), 1) * size_t(c->dim);
-  CREATE_HIP(hipMalloc((void **)&c->d_iface_buf, nif * sizeof(double)));
-  c->h_pinned_doubles = nif + 64;
-  CREATE_HIP(hipHostMalloc((void **)&c->h_pinned, c->h_pinned_doubles * sizeof(double), hipHostMallocDefault));
-  CREATE_HIP(hipMemsetAsync(c->d_vals, 0, size_t(m.nnzb) * dd * sizeof(double), c->stream));
-  CREATE_HIP(hipMemsetAsync(c->d_vecs, 0, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double), c->stream));
-  CREATE_HIP(hipMemsetAsync(c->d_work, 0, size_t(W_COUNT) * size_t(c->n) * sizeof(double), c->stream));
-  CREATE_HIP(hipMemsetAsync(c->d_sc, 0, 16 * sizeof(double), c->stream));
-  CREATE_HIP(hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int32_t), c->stream));
-  CREATE_HIP(hipMemsetAsync(c->d_sell_vals, 0, size_t(m.sell_nblk64) * 64 * dd * sizeof(double), c->stream));
-  mi::launch_sell_build_cols(sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_col,
-                             c->d_sell_col, c->stream);
-  CREATE_HIP(hipGetLastError());
-  CREATE_HIP(hipStreamSynchronize(c->stream));
-
-  // launch geometry: vector kernels and SpMV use fixed grids so that reduction partials are deterministic
-  c->grid_vec = int(std::min<int64_t>(1024, (c->n + 255) / 256));
-  // SpMV: one wavefront per 64-row slice (measured best), grid-stride above MAX_PART workgroups
-  c->grid_spmv = int(std::max<int64_t>(1, std::min<int64_t>(MAX_PART, (m.sell_nslices + 3) / 4)));
-  for (int64_t nd = 0; nd < m.nnodes; ++nd)
-    c->maxrow = std::max(c->maxrow, int(m.rowptr[size_t(nd) + 1] - m.rowptr[size_t(nd)]));
-  if (const char *v = getenv("MI_SPMV_VARIANT"))
-    c->spmv_variant = atoi(v);
-  *out = c;
+  if (emulated)
+    {
+      std::vector<double *> ptrs;
+      for (mi_ctx *m : T->members)
+        ptrs.push_back(m->d_sc);
+      if (hipMalloc((void **)&T->d_sc_ptrs, ptrs.size() * sizeof(double *)) != hipSuccess ||
+          hipMemcpy(T->d_sc_ptrs, ptrs.data(), ptrs.size() * sizeof(double *), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(MI_EHIP, "hipMalloc of the team pointer table failed");
+    }
+  *out = c0;
   return MI_OK;
-#undef CREATE_CHK
-#undef CREATE_HIP
 }
 
 int64_t mi_n_dofs(const mi_ctx *c)
 {
-  return c->n;
+  return c->team->n_global;
 }
 int64_t mi_n_nodes(const mi_ctx *c)
 {
-  return c->mesh.nnodes;
+  return c->team->nnodes_global;
 }
 int64_t mi_n_cells(const mi_ctx *c)
 {
-  return c->mesh.ncells;
+  // cells of the undecomposed box
+  const mi::SlabPartition &s = c->slab;
+  int64_t                  n = (s.nnodes_global / s.plane_nodes - 1) / s.p; // layers in the decomposed direction
+  for (int d = 0; d + 1 < c->dim; ++d)
+    n *= c->mesh.reps[d];
+  return n;
 }
 int64_t mi_nnz(const mi_ctx *c)
 {
-  return c->mesh.nnzb * c->dim * c->dim;
+  // scalar non-zeros of the undecomposed tangent: sum of (coupled box size) over all lattice nodes, closed form
+  int64_t prod = int64_t(c->dim) * c->dim;
+  int     reps[3] = {1, 1, 1};
+  for (int d = 0; d + 1 < c->dim; ++d)
+    reps[d] = c->mesh.reps[d];
+  reps[c->dim - 1] = int((c->slab.nnodes_global / c->slab.plane_nodes - 1) / c->slab.p);
+  const int p      = c->degree;
+  for (int d = 0; d < c->dim; ++d)
+    {
+      // along one direction: interior cell-boundary nodes couple 2p+1, the two end nodes and cell-interior nodes p+1
+      const int64_t n = reps[d];
+      prod *= (n - 1) * (2 * p + 1) + 2 * (p + 1) + n * (p - 1) * (p + 1);
+    }
+  return prod;
 }
 int mi_n_colours(const mi_ctx *c)
 {
   return c->mesh.ncolours;
 }
-int mi_get_node_coords(const mi_ctx *c, double *xyz)
-{
-  std::memcpy(xyz, c->mesh.node_xyz.data(), c->mesh.node_xyz.size() * sizeof(double));
-  return MI_OK;
-}
-int mi_get_constrained(const mi_ctx *c, uint8_t *flags)
-{
-  for (int64_t nd = 0; nd < c->mesh.nnodes; ++nd)
-    for (int k = 0; k < c->dim; ++k)
-      flags[nd * c->dim + k] = (c->mesh.cmask[size_t(nd)] >> k) & 1;
-  return MI_OK;
-}
 int mi_n_interface_nodes(const mi_ctx *c)
 {
-  return int(c->mesh.iface_nodes.size());
+  return int(c->team->iface_global.size());
 }
 int mi_get_interface_nodes(const mi_ctx *c, int32_t *node_ids, double *coords)
 {
-  const int dim = c->dim;
-  for (size_t i = 0; i < c->mesh.iface_nodes.size(); ++i)
+  const Team &T = *c->team;
+  for (size_t i = 0; i < T.iface_global.size(); ++i)
     {
-      const int32_t nd = c->mesh.iface_nodes[i];
       if (node_ids)
-        node_ids[i] = nd;
+        node_ids[i] = int32_t(T.iface_global[i]);
       if (coords)
-        for (int k = 0; k < dim; ++k)
-          coords[i * dim + k] = c->mesh.node_xyz[size_t(nd) * dim + k];
+        for (int k = 0; k < c->dim; ++k)
+          coords[i * c->dim + k] = T.iface_xyz[i * c->dim + k];
     }
   return MI_OK;
 }
 
+// global <- owned parts of a per-node host quantity (dim values per node), summed over ranks when needed
+static int gather_global_host(mi_ctx *c, const std::function<double(mi_ctx *, int64_t, int)> &val, double *out)
+{
+  Team &T = *c->team;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::fill(out, out + T.n_global, 0.0);
+  for (mi_ctx *m : T.members)
+    for (int64_t ln = m->slab.own_begin; ln < m->slab.own_end; ++ln)
+      for (int k = 0; k < m->dim; ++k)
+        out[(ln + m->slab.node_offset) * m->dim + k] = val(m, ln, k);
+  if (T.nccl)
+    {
+      int rc = ensure_gbuf(T);
+      if (rc)
+        return rc;
+      HIPCHK(c, hipMemcpy(T.d_gbuf, out, size_t(T.n_global) * sizeof(double), hipMemcpyHostToDevice));
+      if ((rc = team_allreduce_buffer(T, T.d_gbuf, size_t(T.n_global))))
+        return rc;
+      HIPCHK(c, hipStreamSynchronize(T.stream));
+      HIPCHK(c, hipMemcpy(out, T.d_gbuf, size_t(T.n_global) * sizeof(double), hipMemcpyDeviceToHost));
+    }
+  return MI_OK;
+}
+
+int mi_get_node_coords(const mi_ctx *cc, double *xyz)
+{
+  mi_ctx *c = const_cast<mi_ctx *>(cc);
+  return gather_global_host(
+    c, [](mi_ctx *m, int64_t ln, int k) { return m->mesh.node_xyz[size_t(ln) * m->dim + k]; }, xyz);
+}
+int mi_get_constrained(const mi_ctx *cc, uint8_t *flags)
+{
+  mi_ctx             *c = const_cast<mi_ctx *>(cc);
+  std::vector<double> tmp(size_t(c->team->n_global));
+  const int           rc = gather_global_host(
+    c, [](mi_ctx *m, int64_t ln, int k) { return double((m->mesh.cmask[size_t(ln)] >> k) & 1); }, tmp.data());
+  for (int64_t i = 0; i < c->team->n_global; ++i)
+    flags[i] = tmp[size_t(i)] != 0.0;
+  return rc;
+}
+
 int mi_set_interface_traction(mi_ctx *c, int n, const double *vals)
 {
-  if (n != int(c->mesh.iface_nodes.size()))
-    return fail(c, MI_EINVAL, "expected %d interface nodes, got %d", int(c->mesh.iface_nodes.size()), n);
+  Team &T = *c->team;
+  if (n != int(T.iface_global.size()))
+    return fail(c, MI_EINVAL, "expected %d interface nodes, got %d", int(T.iface_global.size()), n);
   if (n == 0)
     return MI_OK;
   HIPCHK(c, hipSetDevice(c->device));
   c->h_iface.assign(vals, vals + size_t(n) * c->dim);
-  std::memcpy(c->h_pinned + 64, vals, size_t(n) * c->dim * sizeof(double));
-  HIPCHK(c, hipMemcpyAsync(c->d_iface_buf, c->h_pinned + 64, size_t(n) * c->dim * sizeof(double),
-                           hipMemcpyHostToDevice, c->stream));
-  mi::launch_scatter_nodes(c->dim, c->vec(MI_V_EXTERNAL_STRESS), c->d_iface_nodes, n, c->d_iface_buf, c->stream);
+  for (mi_ctx *m : T.members)
+    {
+      const int nl = int(m->mesh.iface_nodes.size());
+      if (nl == 0)
+        continue;
+      double *stage = m->h_pinned + 64;
+      for (int i = 0; i < nl; ++i)
+        for (int k = 0; k < m->dim; ++k)
+          stage[i * m->dim + k] = vals[size_t(m->iface_slot[size_t(i)]) * m->dim + k];
+      HIPCHK(m, hipMemcpyAsync(m->d_iface_buf, stage, size_t(nl) * m->dim * sizeof(double), hipMemcpyHostToDevice,
+                               m->stream));
+      mi::launch_scatter_nodes(m->dim, m->vec(MI_V_EXTERNAL_STRESS), m->d_iface_nodes, nl, m->d_iface_buf, m->stream);
+    }
   HIPCHK(c, hipGetLastError());
-  return sync(c); // the pinned staging buffer is reused by the next call
+  return sync(c); // the pinned staging buffers are reused by the next call
 }
 
 int mi_get_interface_displacement(mi_ctx *c, int n, double *vals)
 {
-  if (n != int(c->mesh.iface_nodes.size()))
-    return fail(c, MI_EINVAL, "expected %d interface nodes, got %d", int(c->mesh.iface_nodes.size()), n);
+  Team &T = *c->team;
+  if (n != int(T.iface_global.size()))
+    return fail(c, MI_EINVAL, "expected %d interface nodes, got %d", int(T.iface_global.size()), n);
   if (n == 0)
     return MI_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  mi::launch_gather_nodes(c->dim, c->vec(MI_V_TOTAL_DISPLACEMENT), c->d_iface_nodes, n, c->d_iface_buf, c->stream);
+  const size_t bytes = size_t(n) * c->dim * sizeof(double);
+  HIPCHK(c, hipMemsetAsync(T.d_ifbuf, 0, bytes, T.stream));
+  for (mi_ctx *m : T.members)
+    mi::launch_gather_to_slots(m->dim, m->vec(MI_V_TOTAL_DISPLACEMENT), m->d_own_if_nodes, m->d_own_if_slots, m->n_own_if,
+                               T.d_ifbuf, T.stream);
   HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned + 64, c->d_iface_buf, size_t(n) * c->dim * sizeof(double),
-                           hipMemcpyDeviceToHost, c->stream));
-  int rc = sync(c);
+  int rc = team_allreduce_buffer(T, T.d_ifbuf, size_t(n) * c->dim);
   if (rc)
     return rc;
-  std::memcpy(vals, c->h_pinned + 64, size_t(n) * c->dim * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(c->h_pinned + 64, T.d_ifbuf, bytes, hipMemcpyDeviceToHost, T.stream));
+  if ((rc = sync(c)))
+    return rc;
+  std::memcpy(vals, c->h_pinned + 64, bytes);
   return MI_OK;
 }
 
 int mi_newton_begin_step(mi_ctx *c)
 {
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SOLUTION_DELTA), 0, size_t(c->n) * sizeof(double), c->stream));
-  HIPCHK(c, hipMemsetAsync(c->vec(MI_V_NEWTON_UPDATE), 0, size_t(c->n) * sizeof(double), c->stream));
+  for (mi_ctx *m : c->team->members)
+    {
+      HIPCHK(m, hipMemsetAsync(m->vec(MI_V_SOLUTION_DELTA), 0, size_t(m->n) * sizeof(double), m->stream));
+      HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
+    }
   return MI_OK;
 }
 
 int mi_update_acceleration(mi_ctx *c)
 {
   HIPCHK(c, hipSetDevice(c->device));
-  const int t = tic(c, MI_T_NEWMARK);
-  mi::launch_newmark_acceleration(newmark_params(c), c->stream);
-  toc(c, t);
+  mi_ctx   *c0 = c->team->members[0];
+  const int t  = tic(c0, MI_T_NEWMARK);
+  for (mi_ctx *m : c->team->members)
+    mi::launch_newmark_acceleration(newmark_params(m), m->stream);
+  toc(c0, t);
   HIPCHK(c, hipGetLastError());
   return MI_OK;
 }
@@ -558,21 +956,21 @@ int mi_update_acceleration(mi_ctx *c)
 int mi_assemble(mi_ctx *c, double *res_norm)
 {
   HIPCHK(c, hipSetDevice(c->device));
-  const int t = tic(c, MI_T_ASSEMBLE_TOTAL);
-  int       rc = enqueue_assembly(c);
-  if (rc)
-    return rc;
-  mi::launch_masked_norm(c->dim, c->vec(MI_V_SYSTEM_RHS), c->d_cmask, c->n, c->part(3), c->grid_vec, c->d_sc + 8,
-                         c->stream);
-  toc(c, t);
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc + 8, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  rc = sync(c);
-  if (rc)
-    return rc;
+  Team     &T  = *c->team;
+  mi_ctx   *c0 = T.members[0];
+  const int t  = tic(c0, MI_T_ASSEMBLE_TOTAL);
+  for (mi_ctx *m : T.members)
+    {
+      const int rc = enqueue_assembly(m);
+      if (rc)
+        return rc;
+    }
+  toc(c0, t);
+  double    nrm = 0;
+  const int rc  = team_masked_norm(T, MI_V_SYSTEM_RHS, SC_NORM_RHS, &nrm);
   if (res_norm)
-    *res_norm = c->h_pinned[0];
-  return MI_OK;
+    *res_norm = nrm;
+  return rc;
 }
 
 int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res)
@@ -580,34 +978,39 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   HIPCHK(c, hipSetDevice(c->device));
   if (rel_tol < 0)
     return fail(c, MI_EINVAL, "negative tolerance");
-  c->active_sell_vals = nullptr; // tangent
-  c->active_dinv      = nullptr;
+  for (mi_ctx *m : c->team->members)
+    {
+      m->active_sell_vals = nullptr; // tangent
+      m->active_dinv      = nullptr;
+    }
   // warm start: SolverCG starts from the passed vector (:1184-1187)
-  return cg_run(c, c->vec(MI_V_NEWTON_UPDATE), c->vec(MI_V_SYSTEM_RHS), rel_tol, max_it, its, res);
+  return cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res);
 }
 
 int mi_apply_newton_update(mi_ctx *c, double *upd_norm)
 {
   HIPCHK(c, hipSetDevice(c->device));
-  mi::launch_masked_norm(c->dim, c->vec(MI_V_NEWTON_UPDATE), c->d_cmask, c->n, c->part(3), c->grid_vec, c->d_sc + 9,
-                         c->stream);
-  mi::launch_vec_add(c->vec(MI_V_SOLUTION_DELTA), c->vec(MI_V_NEWTON_UPDATE), c->n, c->stream); // :487
-  HIPCHK(c, hipGetLastError());
-  HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc + 9, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-  int rc = sync(c);
+  Team     &T   = *c->team;
+  double    nrm = 0;
+  const int rc  = team_masked_norm(T, MI_V_NEWTON_UPDATE, SC_NORM_UPD, &nrm);
   if (rc)
     return rc;
+  for (mi_ctx *m : T.members) // :487, on the whole local vector (ghost copies of the update are consistent)
+    mi::launch_vec_add(m->vec(MI_V_SOLUTION_DELTA), m->vec(MI_V_NEWTON_UPDATE), m->n, m->stream);
+  HIPCHK(c, hipGetLastError());
   if (upd_norm)
-    *upd_norm = c->h_pinned[0];
+    *upd_norm = nrm;
   return MI_OK;
 }
 
 int mi_newmark_finish_step(mi_ctx *c)
 {
   HIPCHK(c, hipSetDevice(c->device));
-  const int t = tic(c, MI_T_NEWMARK);
-  mi::launch_newmark_finish(newmark_params(c), c->stream);
-  toc(c, t);
+  mi_ctx   *c0 = c->team->members[0];
+  const int t  = tic(c0, MI_T_NEWMARK);
+  for (mi_ctx *m : c->team->members)
+    mi::launch_newmark_finish(newmark_params(m), m->stream);
+  toc(c0, t);
   HIPCHK(c, hipGetLastError());
   return MI_OK;
 }
@@ -646,7 +1049,7 @@ int mi_newmark_step(mi_ctx *c, const mi_solver_desc *s, mi_step_info *info)
         }
       int    its = 0;
       double res = 0;
-      rc         = mi_cg_solve(c, s->tol_lin, int64_t(double(c->n) * s->max_iterations_lin), &its, &res); // :472
+      rc = mi_cg_solve(c, s->tol_lin, int64_t(double(mi_n_dofs(c)) * s->max_iterations_lin), &its, &res); // :472
       if (info->newton_iterations < 16)
         {
           info->lin_its[info->newton_iterations] = its;
@@ -674,9 +1077,10 @@ int mi_newmark_step(mi_ctx *c, const mi_solver_desc *s, mi_step_info *info)
     return rc;
   if ((rc = sync(c)))
     return rc;
-  c->timings.ms[MI_T_STEP] +=
+  mi_ctx *c0 = c->team->members[0];
+  c0->timings.ms[MI_T_STEP] +=
     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
-  c->timings.count[MI_T_STEP] += 1;
+  c0->timings.count[MI_T_STEP] += 1;
   return MI_OK;
 }
 
@@ -684,9 +1088,12 @@ int mi_state_save(mi_ctx *c)
 {
   HIPCHK(c, hipSetDevice(c->device));
   // the six state vectors are the first six of the vector block (nonlinear_elasticity.cc:370-375)
-  HIPCHK(c, hipMemcpyAsync(c->d_saved, c->d_vecs, size_t(6) * size_t(c->n) * sizeof(double),
-                           hipMemcpyDeviceToDevice, c->stream));
-  c->have_saved = true;
+  for (mi_ctx *m : c->team->members)
+    {
+      HIPCHK(m, hipMemcpyAsync(m->d_saved, m->d_vecs, size_t(6) * size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
+                               m->stream));
+      m->have_saved = true;
+    }
   return MI_OK;
 }
 int mi_state_restore(mi_ctx *c)
@@ -694,14 +1101,15 @@ int mi_state_restore(mi_ctx *c)
   if (!c->have_saved)
     return fail(c, MI_EINVAL, "state_variables are not the same as previously saved.");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(c->d_vecs, c->d_saved, size_t(6) * size_t(c->n) * sizeof(double),
-                           hipMemcpyDeviceToDevice, c->stream));
+  for (mi_ctx *m : c->team->members)
+    HIPCHK(m, hipMemcpyAsync(m->d_vecs, m->d_saved, size_t(6) * size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
+                             m->stream));
   return MI_OK;
 }
 
 struct mi_snapshot
 {
-  double *d = nullptr;
+  std::vector<double *> d; // one buffer per slab of the team
 };
 
 int mi_snapshot_create(mi_ctx *c, mi_snapshot **out)
@@ -710,11 +1118,18 @@ int mi_snapshot_create(mi_ctx *c, mi_snapshot **out)
     return fail(c, MI_EINVAL, "null argument");
   HIPCHK(c, hipSetDevice(c->device));
   mi_snapshot *s = new mi_snapshot;
-  hipError_t   e = hipMalloc((void **)&s->d, size_t(c->n) * sizeof(double));
-  if (e != hipSuccess)
+  for (mi_ctx *m : c->team->members)
     {
-      delete s;
-      return fail(c, MI_EHIP, "hipMalloc of a snapshot failed: %s", hipGetErrorString(e));
+      double    *p = nullptr;
+      hipError_t e = hipMalloc((void **)&p, size_t(m->n) * sizeof(double));
+      if (e != hipSuccess)
+        {
+          for (double *q : s->d)
+            hipFree(q);
+          delete s;
+          return fail(c, MI_EHIP, "hipMalloc of a snapshot failed: %s", hipGetErrorString(e));
+        }
+      s->d.push_back(p);
     }
   *out = s;
   return MI_OK;
@@ -725,7 +1140,8 @@ void mi_snapshot_destroy(mi_ctx *c, mi_snapshot *s)
     return;
   hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
-  hipFree(s->d);
+  for (double *p : s->d)
+    hipFree(p);
   delete s;
 }
 int mi_snapshot_store(mi_ctx *c, mi_snapshot *s, int which)
@@ -733,7 +1149,11 @@ int mi_snapshot_store(mi_ctx *c, mi_snapshot *s, int which)
   if (!s || which < 0 || which >= MI_V_COUNT)
     return fail(c, MI_EINVAL, "bad snapshot or vector id");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(s->d, c->vec(which), size_t(c->n) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (size_t k = 0; k < c->team->members.size(); ++k)
+    {
+      mi_ctx *m = c->team->members[k];
+      HIPCHK(m, hipMemcpyAsync(s->d[k], m->vec(which), size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
+    }
   return MI_OK;
 }
 int mi_snapshot_load(mi_ctx *c, const mi_snapshot *s, int which)
@@ -741,31 +1161,56 @@ int mi_snapshot_load(mi_ctx *c, const mi_snapshot *s, int which)
   if (!s || which < 0 || which >= MI_V_COUNT)
     return fail(c, MI_EINVAL, "bad snapshot or vector id");
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, hipMemcpyAsync(c->vec(which), s->d, size_t(c->n) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  for (size_t k = 0; k < c->team->members.size(); ++k)
+    {
+      mi_ctx *m = c->team->members[k];
+      HIPCHK(m, hipMemcpyAsync(m->vec(which), s->d[k], size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice, m->stream));
+    }
   return MI_OK;
 }
 
 int mi_vec_get(mi_ctx *c, int which, double *host, int64_t n)
 {
-  if (which < 0 || which >= MI_V_COUNT || n != c->n)
+  Team &T = *c->team;
+  if (which < 0 || which >= MI_V_COUNT || n != T.n_global)
     return fail(c, MI_EINVAL, "bad vector id or length");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(host, c->vec(which), size_t(n) * sizeof(double), hipMemcpyDeviceToHost));
+  if (T.size == 1)
+    {
+      HIPCHK(c, hipMemcpy(host, c->vec(which), size_t(n) * sizeof(double), hipMemcpyDeviceToHost));
+      return MI_OK;
+    }
+  int rc = ensure_gbuf(T);
+  if (rc)
+    return rc;
+  HIPCHK(c, hipMemsetAsync(T.d_gbuf, 0, size_t(n) * sizeof(double), T.stream));
+  for (mi_ctx *m : T.members)
+    HIPCHK(m, hipMemcpyAsync(T.d_gbuf + (m->slab.node_offset + m->slab.own_begin) * m->dim, m->vec(which) + m->own0,
+                             size_t(m->own_n) * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
+  if ((rc = team_allreduce_buffer(T, T.d_gbuf, size_t(n))))
+    return rc;
+  HIPCHK(c, hipStreamSynchronize(T.stream));
+  HIPCHK(c, hipMemcpy(host, T.d_gbuf, size_t(n) * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OK;
 }
 int mi_vec_set(mi_ctx *c, int which, const double *host, int64_t n)
 {
-  if (which < 0 || which >= MI_V_COUNT || n != c->n)
+  Team &T = *c->team;
+  if (which < 0 || which >= MI_V_COUNT || n != T.n_global)
     return fail(c, MI_EINVAL, "bad vector id or length");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->vec(which), host, size_t(n) * sizeof(double), hipMemcpyHostToDevice));
+  for (mi_ctx *m : T.members) // every slab takes its local range (ghost planes included) from the global array
+    HIPCHK(m, hipMemcpy(m->vec(which), host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
+                        hipMemcpyHostToDevice));
   return MI_OK;
 }
 
 int mi_matrix_get_csr(mi_ctx *c, int64_t *rowptr, int32_t *col, double *val)
 {
+  if (c->team->size != 1)
+    return fail(c, MI_EINVAL, "matrix export is only available on an undecomposed mesh");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int           D = c->dim, DD = D * D;
@@ -789,49 +1234,72 @@ int mi_matrix_get_csr(mi_ctx *c, int64_t *rowptr, int32_t *col, double *val)
   return MI_OK;
 }
 
+// y = K x through the device kernels (global arrays)
 int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
 {
+  Team &T = *c->team;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(c->work(W_P), x_host, size_t(c->n) * sizeof(double), hipMemcpyHostToDevice));
-  enqueue_spmv(c, c->work(W_P), c->work(W_Q), nullptr, nullptr, nullptr);
+  for (mi_ctx *m : T.members)
+    HIPCHK(m, hipMemcpy(m->work(W_P), x_host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
+                        hipMemcpyHostToDevice));
+  for (mi_ctx *m : T.members)
+    enqueue_spmv(m, m->work(W_P), m->work(W_Q), nullptr, nullptr, nullptr);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(y_host, c->work(W_Q), size_t(c->n) * sizeof(double), hipMemcpyDeviceToHost));
+  if (T.size == 1)
+    {
+      HIPCHK(c, hipMemcpy(y_host, c->work(W_Q), size_t(c->n) * sizeof(double), hipMemcpyDeviceToHost));
+      return MI_OK;
+    }
+  int rc = ensure_gbuf(T);
+  if (rc)
+    return rc;
+  HIPCHK(c, hipMemsetAsync(T.d_gbuf, 0, size_t(T.n_global) * sizeof(double), T.stream));
+  for (mi_ctx *m : T.members)
+    HIPCHK(m, hipMemcpyAsync(T.d_gbuf + (m->slab.node_offset + m->slab.own_begin) * m->dim, m->work(W_Q) + m->own0,
+                             size_t(m->own_n) * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
+  if ((rc = team_allreduce_buffer(T, T.d_gbuf, size_t(T.n_global))))
+    return rc;
+  HIPCHK(c, hipStreamSynchronize(T.stream));
+  HIPCHK(c, hipMemcpy(y_host, T.d_gbuf, size_t(T.n_global) * sizeof(double), hipMemcpyDeviceToHost));
   return MI_OK;
 }
 
 int mi_set_tuning(mi_ctx *c, const char *key, int value)
 {
   const std::string k(key ? key : "");
-  if (k == "spmv_variant" && (value == 1 || value == 3 || (value >= 11 && value <= 14)))
-    c->spmv_variant = value;
-  else if (k == "xcd_remap" && (value == 0 || value == 1))
-    c->xcd_remap = value;
-  else if (k == "sell_unroll" && value >= -2 && value <= 4 && value != 0)
-    c->sell_unroll = value;
-  else if (k == "spmv_grid" && value >= 1 && value <= MAX_PART)
-    c->grid_spmv = value;
-  else
-    return fail(c, MI_EINVAL, "unknown tuning key '%s' or value %d out of range", k.c_str(), value);
+  for (mi_ctx *m : c->team->members)
+    {
+      if (k == "spmv_variant" && (value == 1 || value == 3 || (value >= 11 && value <= 14)))
+        m->spmv_variant = value;
+      else if (k == "xcd_remap" && (value == 0 || value == 1))
+        m->xcd_remap = value;
+      else if (k == "sell_unroll" && value >= -2 && value <= 4 && value != 0)
+        m->sell_unroll = value;
+      else if (k == "spmv_grid" && value >= 1 && value <= MAX_PART)
+        m->grid_spmv = value;
+      else
+        return fail(c, MI_EINVAL, "unknown tuning key '%s' or value %d out of range", k.c_str(), value);
+    }
   return MI_OK;
 }
 
 int mi_set_profiling(mi_ctx *c, int enable)
 {
-  c->profiling = enable != 0;
+  c->team->members[0]->profiling = enable != 0;
   return MI_OK;
 }
 int mi_reset_timings(mi_ctx *c)
 {
   int rc = sync(c);
-  std::memset(&c->timings, 0, sizeof(c->timings));
+  std::memset(&c->team->members[0]->timings, 0, sizeof(mi_timings));
   return rc;
 }
 int mi_get_timings(mi_ctx *c, mi_timings *out)
 {
   int rc = sync(c);
-  *out   = c->timings;
+  *out   = c->team->members[0]->timings;
   return rc;
 }
 
@@ -841,10 +1309,14 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
   hipEvent_t a, b;
   HIPCHK(c, hipEventCreate(&a));
   HIPCHK(c, hipEventCreate(&b));
-  enqueue_spmv(c, c->work(W_P), c->work(W_Q), c->work(W_P), c->part(2), nullptr); // warm-up
+  auto once = [&]() {
+    for (mi_ctx *m : c->team->members)
+      enqueue_spmv(m, m->work(W_P), m->work(W_Q), m->work(W_P), m->part(2), nullptr);
+  };
+  once(); // warm-up
   HIPCHK(c, hipEventRecord(a, c->stream));
   for (int i = 0; i < reps; ++i)
-    enqueue_spmv(c, c->work(W_P), c->work(W_Q), c->work(W_P), c->part(2), nullptr);
+    once();
   HIPCHK(c, hipEventRecord(b, c->stream));
   HIPCHK(c, hipEventSynchronize(b));
   float ms = 0;
@@ -861,13 +1333,18 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEvent_t a, b;
   HIPCHK(c, hipEventCreate(&a));
   HIPCHK(c, hipEventCreate(&b));
-  int rc = enqueue_assembly(c); // warm-up
-  if (rc)
-    return rc;
+  int  rc   = MI_OK;
+  auto once = [&]() {
+    for (mi_ctx *m : c->team->members)
+      if (rc == MI_OK)
+        rc = enqueue_assembly(m);
+  };
+  once(); // warm-up
   HIPCHK(c, hipEventRecord(a, c->stream));
   for (int i = 0; i < reps; ++i)
-    if ((rc = enqueue_assembly(c)))
-      return rc;
+    once();
+  if (rc)
+    return rc;
   HIPCHK(c, hipEventRecord(b, c->stream));
   HIPCHK(c, hipEventSynchronize(b));
   float ms = 0;
@@ -876,6 +1353,48 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEventDestroy(b);
   *ms_per_assembly = double(ms) / std::max(1, reps);
   return sync(c);
+}
+
+// host-only description of slab `rank` of `size` (no device needed): z-range, owned node range, halo ranges
+int mi_partition_describe(const mi_mesh_desc *md, int rank, int size, mi_partition_info *out)
+{
+  if (!md || !out)
+    return fail(nullptr, MI_EINVAL, "null argument");
+  try
+    {
+      const mi::SlabPartition s =
+        mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, size);
+      out->z0            = s.z0;
+      out->z1            = s.z1;
+      out->local_layers  = s.local_layers;
+      out->plane_nodes   = s.plane_nodes;
+      out->node_offset   = s.node_offset;
+      out->nnodes_global = s.nnodes_global;
+      out->nnodes_local  = s.nnodes_local;
+      out->own_begin     = s.own_begin;
+      out->own_end       = s.own_end;
+      out->up_send       = s.up_send;
+      out->up_send_n     = s.up_send_n;
+      out->up_recv       = s.up_recv;
+      out->up_recv_n     = s.up_recv_n;
+      out->down_send     = s.down_send;
+      out->down_send_n   = s.down_send_n;
+      out->down_recv     = s.down_recv;
+      out->down_recv_n   = s.down_recv_n;
+      for (int d = 0; d < 3; ++d)
+        {
+          out->local_reps[d] = s.local_reps[d];
+          out->local_lo[d]   = s.local_lo[d];
+          out->local_hi[d]   = s.local_hi[d];
+        }
+      for (int f = 0; f < 6; ++f)
+        out->local_face_role[f] = s.local_face_role[f];
+    }
+  catch (const std::exception &e)
+    {
+      return fail(nullptr, MI_EINVAL, "%s", e.what());
+    }
+  return MI_OK;
 }
 
 } // extern "C"

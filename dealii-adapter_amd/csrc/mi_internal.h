@@ -25,6 +25,7 @@ namespace mi_detail
     W_COUNT
   };
   struct LinearModel; // mi_linear.cpp
+  struct Team;        // mi_ctx.cpp: the slab contexts that advance together (1 unless decomposed)
 } // namespace mi_detail
 
 struct mi_ctx
@@ -75,6 +76,14 @@ struct mi_ctx
   std::vector<double> h_iface;   // host copy of the last interface values (linear model: consistent loading)
   mi_detail::LinearModel *linear = nullptr;
 
+  // domain decomposition (z-slabs, mi_mesh.hpp SlabPartition); single rank: part.size == 1, everything is owned
+  mi_detail::Team     *team = nullptr;
+  mi::SlabPartition    slab;
+  int64_t              own0 = 0, own_n = 0; // owned dof offset / count inside the local vectors
+  std::vector<int32_t> iface_slot;          // global interface slot of every local interface node
+  int32_t             *d_own_if_nodes = nullptr, *d_own_if_slots = nullptr; // owned interface nodes -> global slots
+  int                  n_own_if = 0;
+
   double *vec(int which) { return d_vecs + size_t(which) * size_t(n); }
   double *work(int which) { return d_work + size_t(which) * size_t(n); }
   double *part(int which) { return d_part + size_t(which) * mi_detail::MAX_PART; }
@@ -89,8 +98,10 @@ namespace mi_detail
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
                              const int32_t *done);
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done);
-  // Jacobi-PCG on the active matrix: x warm start, tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
-  int  cg_run(mi_ctx *c, double *x, const double *b, double tol, int64_t max_it, int *its, double *res);
+  // Jacobi-PCG on the active matrix (all slabs of the team): x = vector x_id (warm start), b = vector b_id;
+  // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
+  int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res);
+  int  team_size(const mi_ctx *c);
   void linear_destroy(mi_ctx *c);
 
 #define HIPCHK(ctx, call)                                                                                   \

@@ -63,6 +63,7 @@ namespace mi
     int32_t      *flags; // [2] done, iterations
     int64_t       n;
     int32_t       npart, npart_pq;
+    const double *totals; // distributed: all-reduced [rr, rz, pq, bb]; null -> consumers reduce the partials
   };
 
   struct NewmarkParams
@@ -103,6 +104,11 @@ namespace mi
                            hipStream_t s);
   void launch_masked_norm(int dim, const double *v, const uint8_t *cmask, int64_t n, double *part, int grid,
                           double *out, hipStream_t s);
+  void launch_reduce_to_totals(const double *pa, int na, double *oa, const double *pb, int nb, double *ob,
+                               const int32_t *done, hipStream_t s);
+  void launch_team_sum(double *const *bufs, int nranks, int off, int cnt, hipStream_t s);
+  void launch_gather_to_slots(int dim, const double *v, const int32_t *nodes, const int32_t *slots, int n, double *out,
+                              hipStream_t s);
   void launch_zero_constrained(int dim, double *x, const uint8_t *cmask, int64_t n, hipStream_t s);
   void launch_newmark_acceleration(const NewmarkParams &p, hipStream_t s);
   void launch_newmark_finish(const NewmarkParams &p, hipStream_t s);

@@ -1013,8 +1013,8 @@ namespace mi
     __shared__ double s_red[4];
     if (c.flags[0])
       return;
-    const double rr = reduce_partials<256>(c.part_rr, c.npart, s_red);
-    const double rz = reduce_partials<256>(c.part_rz, c.npart, s_red);
+    const double rr = c.totals ? c.totals[0] : reduce_partials<256>(c.part_rr, c.npart, s_red);
+    const double rz = c.totals ? c.totals[1] : reduce_partials<256>(c.part_rz, c.npart, s_red);
     const double res = sqrt(rr);
     if (res <= c.sc[2])
       {
@@ -1045,7 +1045,7 @@ namespace mi
     __shared__ double s_red[4];
     if (c.flags[0])
       return;
-    const double pq    = reduce_partials<256>(c.part_pq, c.npart_pq, s_red);
+    const double pq    = c.totals ? c.totals[2] : reduce_partials<256>(c.part_pq, c.npart_pq, s_red);
     const double alpha = c.sc[it & 1] / pq;
     const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
@@ -1097,7 +1097,7 @@ namespace mi
   __global__ __launch_bounds__(256) void cg_set_tolerance(CgParams c, const double *part_bb, double rel_tol)
   {
     __shared__ double s_red[4];
-    const double bb = reduce_partials<256>(part_bb, c.npart, s_red);
+    const double bb = c.totals ? c.totals[3] : reduce_partials<256>(part_bb, c.npart, s_red);
     if (threadIdx.x == 0)
       {
         c.sc[2]    = rel_tol >= 0.0 ? rel_tol * sqrt(bb) : -rel_tol;
@@ -1114,7 +1114,7 @@ namespace mi
     __shared__ double s_red[4];
     if (c.flags[0])
       return;
-    const double rr  = reduce_partials<256>(c.part_rr, c.npart, s_red);
+    const double rr  = c.totals ? c.totals[0] : reduce_partials<256>(c.part_rr, c.npart, s_red);
     const double res = sqrt(rr);
     if (threadIdx.x == 0)
       {
@@ -1159,12 +1159,57 @@ namespace mi
     if (threadIdx.x == 0)
       part[blockIdx.x] = s;
   }
-  __global__ __launch_bounds__(256) void finish_norm(const double *part, int n, double *out)
+  // total of a partial array (sum of squares for the norms; the square root is taken after the all-reduce)
+  __global__ __launch_bounds__(256) void finish_sum(const double *part, int n, double *out)
   {
     __shared__ double s_red[4];
+    if (!part || n <= 0)
+      return;
     const double s = reduce_partials<256>(part, n, s_red);
     if (threadIdx.x == 0)
-      *out = sqrt(s);
+      *out = s;
+  }
+  // up to three partial arrays -> totals (distributed CG: local sums that are all-reduced afterwards)
+  __global__ __launch_bounds__(256) void reduce_to_totals(const double *pa, int na, double *oa, const double *pb, int nb,
+                                                          double *ob, const int32_t *done)
+  {
+    __shared__ double s_red[4];
+    if (done && *done)
+      return;
+    if (pa)
+      {
+        const double s = reduce_partials<256>(pa, na, s_red);
+        if (threadIdx.x == 0)
+          *oa = s;
+      }
+    if (pb)
+      {
+        const double s = reduce_partials<256>(pb, nb, s_red);
+        if (threadIdx.x == 0)
+          *ob = s;
+      }
+  }
+  // emulated all-reduce(sum) over the slab contexts of one process: bufs[r][off..off+cnt) := sum over r
+  __global__ __launch_bounds__(64) void team_sum(double *const *bufs, int nranks, int off, int cnt)
+  {
+    const int k = threadIdx.x;
+    if (k >= cnt)
+      return;
+    double s = 0.0;
+    for (int r = 0; r < nranks; ++r)
+      s += bufs[r][off + k];
+    for (int r = 0; r < nranks; ++r)
+      bufs[r][off + k] = s;
+  }
+  // out[slot[i]*D + c] = v[node[i]*D + c]   (owned interface nodes into the global interface buffer)
+  template <int D>
+  __global__ __launch_bounds__(256) void gather_to_slots(const double *__restrict__ v,
+                                                         const int32_t *__restrict__ nodes,
+                                                         const int32_t *__restrict__ slots, int n, double *out)
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n * D)
+      out[int64_t(slots[i / D]) * D + i % D] = v[int64_t(nodes[i / D]) * D + i % D];
   }
 
   // constraints.distribute for homogeneous constraints (:1208): x[constrained] = 0
@@ -1452,7 +1497,27 @@ namespace mi
       hipLaunchKernelGGL((masked_norm_partials<3>), dim3(grid), dim3(256), 0, s, v, cmask, n, part);
     else
       hipLaunchKernelGGL((masked_norm_partials<2>), dim3(grid), dim3(256), 0, s, v, cmask, n, part);
-    hipLaunchKernelGGL(finish_norm, dim3(1), dim3(256), 0, s, part, grid, out);
+    hipLaunchKernelGGL(finish_sum, dim3(1), dim3(256), 0, s, part, grid, out);
+  }
+  void launch_reduce_to_totals(const double *pa, int na, double *oa, const double *pb, int nb, double *ob,
+                               const int32_t *done, hipStream_t s)
+  {
+    hipLaunchKernelGGL(reduce_to_totals, dim3(1), dim3(256), 0, s, pa, na, oa, pb, nb, ob, done);
+  }
+  void launch_team_sum(double *const *bufs, int nranks, int off, int cnt, hipStream_t s)
+  {
+    hipLaunchKernelGGL(team_sum, dim3(1), dim3(64), 0, s, bufs, nranks, off, cnt);
+  }
+  void launch_gather_to_slots(int dim, const double *v, const int32_t *nodes, const int32_t *slots, int n, double *out,
+                              hipStream_t s)
+  {
+    const int grid = (n * dim + 255) / 256;
+    if (grid == 0)
+      return;
+    if (dim == 3)
+      hipLaunchKernelGGL((gather_to_slots<3>), dim3(grid), dim3(256), 0, s, v, nodes, slots, n, out);
+    else
+      hipLaunchKernelGGL((gather_to_slots<2>), dim3(grid), dim3(256), 0, s, v, nodes, slots, n, out);
   }
   void launch_zero_constrained(int dim, double *x, const uint8_t *cmask, int64_t n, hipStream_t s)
   {

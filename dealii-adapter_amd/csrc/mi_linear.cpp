@@ -153,6 +153,8 @@ extern "C" {
 int mi_linear_setup(mi_ctx *c, double theta)
 {
   HIPCHK(c, hipSetDevice(c->device));
+  if (team_size(c) != 1)
+    return fail(c, MI_EINVAL, "the linear model is not available on a decomposed mesh");
   if (!(theta >= 0.0 && theta <= 1.0))
     return fail(c, MI_EINVAL, "theta must be in [0,1]");
   linear_destroy(c);
@@ -395,7 +397,7 @@ int mi_linear_step(mi_ctx *c, int data_consistent, double abs_tol, int64_t max_i
   // solve (:531-551): absolute tolerance, start vector = previous velocity
   c->active_sell_vals = L.d_A;
   c->active_dinv      = L.d_dinvA;
-  const int rc        = cg_run(c, p.v, p.rhs, -abs_tol, max_it, its, res);
+  const int rc        = cg_run(c, MI_L_VELOCITY, MI_L_SYSTEM_RHS, -abs_tol, max_it, its, res);
   c->active_sell_vals = nullptr;
   c->active_dinv      = nullptr;
   if (rc)

@@ -158,6 +158,117 @@ namespace mi
     }
   };
 
+  // ------------------------------------------------------------------ slab decomposition (host only)
+  // The last lattice direction (z in 3D, y in 2D) is the slowest in the node numbering, so a slab of cell layers
+  // owns a contiguous range of node planes.  Rank r works on the box of its own layers [z0, z1) plus one ghost
+  // layer above (if any); it owns the node planes (p*z0, p*z1] (rank 0 also owns plane 0).
+  struct SlabPartition
+  {
+    int     rank = 0, size = 1, dim = 0, p = 0;
+    int     z0 = 0, z1 = 0;          // owned cell layers [z0, z1)
+    int     local_layers = 0;        // z1 - z0 (+1 ghost layer if rank < size-1)
+    int64_t plane_nodes = 0;         // nodes per lattice plane
+    int64_t node_offset = 0;         // global id of local node 0
+    int64_t nnodes_global = 0, nnodes_local = 0;
+    int64_t own_begin = 0, own_end = 0; // owned LOCAL node range
+    // halo ranges in LOCAL nodes (count 0 = no neighbour)
+    int64_t up_send = 0, up_send_n = 0;     // my top owned plane           -> rank+1 (its plane 0)
+    int64_t up_recv = 0, up_recv_n = 0;     // ghost planes above           <- rank+1 (its first p owned planes)
+    int64_t down_send = 0, down_send_n = 0; // my first p owned planes      -> rank-1
+    int64_t down_recv = 0, down_recv_n = 0; // plane 0 (owned by rank-1)    <- rank-1
+    int     local_reps[3] = {1, 1, 1};
+    double  local_lo[3] = {0, 0, 0}, local_hi[3] = {0, 0, 0};
+    int     local_face_role[6] = {0, 0, 0, 0, 0, 0};
+    int64_t vertex_offset = 0; // global vertex id of local vertex 0 (for the perturbation array)
+  };
+
+  inline SlabPartition make_slab_partition(int dim, int p, const int *reps, const double *lo, const double *hi,
+                                           const int *face_role, int rank, int size)
+  {
+    if (size < 1 || rank < 0 || rank >= size)
+      throw std::invalid_argument("bad rank/size");
+    const int zd = dim - 1;
+    if (size > reps[zd])
+      throw std::invalid_argument("more ranks than cell layers in the decomposed direction");
+    SlabPartition s;
+    s.rank = rank;
+    s.size = size;
+    s.dim  = dim;
+    s.p    = p;
+    // balanced split of the layers
+    s.z0 = int((int64_t(reps[zd]) * rank) / size);
+    s.z1 = int((int64_t(reps[zd]) * (rank + 1)) / size);
+    const bool ghost_above = rank < size - 1;
+    s.local_layers         = s.z1 - s.z0 + (ghost_above ? 1 : 0);
+    s.plane_nodes          = 1;
+    int64_t plane_verts    = 1;
+    for (int d = 0; d < zd; ++d)
+      {
+        s.plane_nodes *= int64_t(p) * reps[d] + 1;
+        plane_verts *= reps[d] + 1;
+      }
+    s.nnodes_global = s.plane_nodes * (int64_t(p) * reps[zd] + 1);
+    s.nnodes_local  = s.plane_nodes * (int64_t(p) * s.local_layers + 1);
+    s.node_offset   = s.plane_nodes * int64_t(p) * s.z0;
+    s.vertex_offset = plane_verts * s.z0;
+    const int64_t own_lo_plane = rank == 0 ? 0 : 1, own_hi_plane = int64_t(p) * (s.z1 - s.z0);
+    s.own_begin = own_lo_plane * s.plane_nodes;
+    s.own_end   = (own_hi_plane + 1) * s.plane_nodes;
+    if (ghost_above)
+      {
+        s.up_send   = own_hi_plane * s.plane_nodes;
+        s.up_send_n = s.plane_nodes;
+        s.up_recv   = (own_hi_plane + 1) * s.plane_nodes;
+        s.up_recv_n = int64_t(p) * s.plane_nodes;
+      }
+    if (rank > 0)
+      {
+        s.down_send   = s.plane_nodes;
+        s.down_send_n = int64_t(p) * s.plane_nodes;
+        s.down_recv   = 0;
+        s.down_recv_n = s.plane_nodes;
+      }
+    for (int d = 0; d < 3; ++d)
+      {
+        s.local_reps[d] = d < dim ? reps[d] : 1;
+        s.local_lo[d]   = lo[d];
+        s.local_hi[d]   = hi[d];
+      }
+    s.local_reps[zd] = s.local_layers;
+    const double h   = (hi[zd] - lo[zd]) / reps[zd];
+    s.local_lo[zd]   = lo[zd] + h * s.z0;
+    s.local_hi[zd]   = lo[zd] + h * (s.z0 + s.local_layers);
+    for (int f = 0; f < 6; ++f)
+      s.local_face_role[f] = face_role[f];
+    if (rank > 0)
+      s.local_face_role[2 * zd] = 0; // interior cut, not a boundary
+    if (ghost_above)
+      s.local_face_role[2 * zd + 1] = 0;
+    return s;
+  }
+
+  // global interface nodes (ascending) of the undecomposed box: lattice nodes on sides with role 7
+  inline std::vector<int64_t> global_interface_nodes(int dim, int p, const int *reps, const int *face_role)
+  {
+    int64_t nn[3] = {1, 1, 1}, total = 1;
+    for (int d = 0; d < dim; ++d)
+      {
+        nn[d] = int64_t(p) * reps[d] + 1;
+        total *= nn[d];
+      }
+    std::vector<int64_t> out;
+    for (int64_t n = 0; n < total; ++n)
+      {
+        const int64_t i[3] = {n % nn[0], (n / nn[0]) % nn[1], n / (nn[0] * nn[1])};
+        bool          on   = false;
+        for (int d = 0; d < dim && !on; ++d)
+          on = (i[d] == 0 && face_role[2 * d] == 7) || (i[d] == nn[d] - 1 && face_role[2 * d + 1] == 7);
+        if (on)
+          out.push_back(n);
+      }
+    return out;
+  }
+
   struct InterfaceFace
   {
     int32_t cell; // colour-sorted cell position
@@ -218,8 +329,10 @@ namespace mi
         }
     }
 
+    // zoff / zreps_global / own range: slab of a decomposed box (see SlabPartition): `reps_` are the LOCAL
+    // repetitions, lo/hi the GLOBAL box, the last direction starts at global cell layer zoff
     void build(int dim_, int p_, const int *reps_, const double *lo, const double *hi, const int *face_role,
-               const double *perturb)
+               const double *perturb, int zoff = 0, int zreps_global = 0, int64_t own_begin = 0, int64_t own_end = -1)
     {
       dim = dim_;
       p   = p_;
@@ -253,8 +366,11 @@ namespace mi
           int vi[3];
           split(v, nvx, dim, vi);
           for (int d = 0; d < dim; ++d)
-            vx[size_t(v) * dim + d] =
-              lo[d] + (hi[d] - lo[d]) * vi[d] / reps[d] + (perturb ? perturb[size_t(v) * dim + d] : 0.0);
+            {
+              const bool cut = (d == dim - 1) && zreps_global > 0;
+              vx[size_t(v) * dim + d] = lo[d] + (hi[d] - lo[d]) * (vi[d] + (cut ? zoff : 0)) / (cut ? zreps_global : reps[d]) +
+                                        (perturb ? perturb[size_t(v) * dim + d] : 0.0);
+            }
         }
 
       // parity colouring, colour-sorted cell order
@@ -437,10 +553,11 @@ namespace mi
           iface_faces.insert(iface_faces.end(), faces_by_colour[c].begin(), faces_by_colour[c].end());
           iface_colour_begin.push_back(int64_t(iface_faces.size()));
         }
-      build_sell();
+      build_sell(own_begin, own_end < 0 ? nnodes : own_end);
     }
 
-    void build_sell()
+    // SpMV rows = the owned node range only
+    void build_sell(int64_t own_begin, int64_t own_end)
     {
       std::vector<int32_t> lens;
       for (int64_t n = 0; n < nnodes; ++n)
@@ -453,7 +570,7 @@ namespace mi
       for (int32_t L : classes)
         {
           int64_t cnt = 0;
-          for (int64_t n = 0; n < nnodes; ++n)
+          for (int64_t n = own_begin; n < own_end; ++n)
             if (lens[size_t(n)] == L)
               {
                 sell_perm.push_back(int32_t(n));

@@ -61,13 +61,32 @@ typedef struct
   double beta, gamma, delta_t;
 } mi_newmark_desc;
 
-/* domain decomposition over the GPUs of one node; size==1 -> single GPU, unique_id ignored.
- * The reference has no counterpart (adapter.h:152-154 hard-codes one rank). */
+/* domain decomposition into `size` z-slabs (last lattice direction), one slab per process/GPU with ghost planes
+ * exchanged by ncclSend/ncclRecv and scalars by ncclAllReduce (RCCL over xGMI).  size==1 (or a NULL descriptor):
+ * single GPU.  rank == -1: all `size` slabs are created inside this process on one device and advance in
+ * lockstep (test mode: lets the decomposition be checked on a single-GPU box).  All entry points keep speaking
+ * GLOBAL arrays in every mode.  The reference has no counterpart (adapter.h:152-154 hard-codes one rank). */
 typedef struct
 {
   int32_t     rank, size;
-  const void *nccl_unique_id; /* 128-byte ncclUniqueId shared by all ranks */
+  const void *nccl_unique_id; /* 128-byte ncclUniqueId from mi_comm_unique_id(), the same on all ranks */
 } mi_comm_desc;
+
+/* host-only description of one slab (no device needed; used by the multi-process CPU tests) */
+typedef struct
+{
+  int32_t z0, z1, local_layers;      /* owned cell layers [z0,z1); layers of the local box (incl. ghost layer) */
+  int64_t plane_nodes, node_offset;  /* nodes per lattice plane; global id of local node 0                    */
+  int64_t nnodes_global, nnodes_local;
+  int64_t own_begin, own_end;        /* owned LOCAL node range                                                */
+  int64_t up_send, up_send_n, up_recv, up_recv_n;         /* LOCAL node ranges exchanged with rank+1          */
+  int64_t down_send, down_send_n, down_recv, down_recv_n; /* ... and with rank-1                              */
+  int32_t local_reps[3];
+  double  local_lo[3], local_hi[3];
+  int32_t local_face_role[6];
+} mi_partition_info;
+int mi_partition_describe(const mi_mesh_desc *mesh, int rank, int size, mi_partition_info *out);
+int mi_comm_unique_id(void *out128); /* ncclGetUniqueId */
 
 /* parameters.cc:61-99 ("Solver" subsection) */
 typedef struct
