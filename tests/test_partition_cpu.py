@@ -1,0 +1,178 @@
+"""CPU tests of the multi-GPU path's host logic, including a world-size-2 run over gloo.
+
+The slab description comes from the product library (mi_partition_describe, pure host code).  Two processes
+then emulate what two GPUs do: each builds the local box of its slab (own layers + one ghost layer) with the CPU
+oracle as the local assembler, assembles redundantly, multiplies its OWNED rows after exchanging the halo planes
+over gloo, and runs a distributed Jacobi-PCG with all-reduced scalars.  Rank 0 checks against the undecomposed
+oracle.  This pins the ownership rule, the sufficiency of one ghost layer and the halo ranges the RCCL path uses.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg
+
+M = load_pkg()
+
+ROLES = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+
+
+def _md(dim, p, reps, hi):
+    return M.mesh_desc(dim, p, reps, (0.0,) * dim, hi, ROLES)
+
+
+@pytest.mark.parametrize("dim,p,reps,size", [(3, 2, (3, 2, 7), 3), (3, 1, (4, 4, 59), 8), (2, 3, (5, 9), 4)])
+def test_slabs_tile_the_mesh(dim, p, reps, size):
+    md = _md(dim, p, reps, tuple(0.1 * r for r in reps))
+    infos = [M.partition_describe(md, r, size) for r in range(size)]
+    plane = infos[0].plane_nodes
+    assert infos[0].nnodes_global == plane * (p * reps[-1] + 1)
+    covered = 0
+    for r, s in enumerate(infos):
+        assert s.z1 > s.z0 and (r == 0 or s.z0 == infos[r - 1].z1)
+        assert s.local_layers == s.z1 - s.z0 + (1 if r < size - 1 else 0)
+        assert s.node_offset == plane * p * s.z0
+        g0, g1 = s.node_offset + s.own_begin, s.node_offset + s.own_end
+        assert g0 == covered  # owned global ranges are contiguous and disjoint
+        covered = g1
+        if r < size - 1:  # what I send up is what the next rank receives from below, and vice versa
+            nxt = infos[r + 1]
+            assert s.up_send_n == nxt.down_recv_n == plane and s.up_recv_n == nxt.down_send_n == p * plane
+            assert s.node_offset + s.up_send == nxt.node_offset + nxt.down_recv
+            assert s.node_offset + s.up_recv == nxt.node_offset + nxt.down_send
+            assert s.local_face_role[2 * dim - 1] == 0
+        else:
+            assert s.up_send_n == 0 and s.local_face_role[2 * dim - 1] == ROLES[2 * dim - 1]
+        assert s.local_face_role[2 * dim - 2] == (ROLES[2 * dim - 2] if r == 0 else 0)
+    assert covered == infos[0].nnodes_global
+    assert infos[-1].z1 == reps[-1]
+    with pytest.raises(M.MiError):
+        M.partition_describe(md, 0, reps[-1] + 1)
+
+
+def _worker(rank, world, port, dim, p, reps, out_q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        hi = tuple(0.1 * r for r in reps)
+        md = _md(dim, p, reps, hi)
+        s = M.partition_describe(md, rank, world)
+        D = dim
+        loc = O.make_desc(dim=dim, degree=p, reps=tuple(s.local_reps)[:dim], lo=tuple(s.local_lo)[:dim],
+                          hi=tuple(s.local_hi)[:dim], face_role=list(s.local_face_role))
+        P = O.Problem(loc)
+        assert P.nnodes == s.nnodes_local
+        own = slice(s.own_begin * D, s.own_end * D)
+        glob = slice(s.node_offset * D, (s.node_offset + s.nnodes_local) * D)
+        # identical global state on every rank (seeded), each takes its local part incl. ghosts
+        rng = np.random.default_rng(7)
+        ng = s.nnodes_global * D
+        Pg = O.Problem(O.make_desc(dim=dim, degree=p, reps=reps, hi=hi, face_role=ROLES)) if rank == 0 else None
+        state = {k: rng.standard_normal(ng) * sc for k, sc in ((O.V_U, 1e-4), (O.V_V_OLD, 0.1), (O.V_A_OLD, 1.0))}
+        for k, v in state.items():
+            P.vec(k)[:] = v[glob]
+            if Pg:
+                Pg.vec(k)[:] = v
+        for prob in (P, Pg):
+            if prob:
+                prob.vec(O.V_U)[prob.constrained] = 0
+                prob.set_interface_traction((0.0, -2e3, 0.0)[:dim])
+                prob.update_acceleration()
+                prob.assemble()  # ghost cells are assembled redundantly, no matrix communication
+        A = P.csr()
+
+        def halo(v):  # same ranges as mi_ctx.cpp team_halo
+            reqs = []
+            if s.up_send_n:
+                up = torch.from_numpy(np.ascontiguousarray(v[s.up_send * D:(s.up_send + s.up_send_n) * D]))
+                rb = torch.zeros(s.up_recv_n * D, dtype=torch.float64)
+                reqs += [dist.isend(up, rank + 1), dist.irecv(rb, rank + 1)]
+            if s.down_send_n:
+                dn = torch.from_numpy(np.ascontiguousarray(v[s.down_send * D:(s.down_send + s.down_send_n) * D]))
+                rd = torch.zeros(s.down_recv_n * D, dtype=torch.float64)
+                reqs += [dist.isend(dn, rank - 1), dist.irecv(rd, rank - 1)]
+            for r in reqs:
+                r.wait()
+            if s.up_send_n:
+                v[s.up_recv * D:(s.up_recv + s.up_recv_n) * D] = rb.numpy()
+            if s.down_send_n:
+                v[s.down_recv * D:(s.down_recv + s.down_recv_n) * D] = rd.numpy()
+
+        def allsum(x):
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t)
+            return float(t[0])
+
+        def gather_owned(v):
+            full = torch.zeros(ng, dtype=torch.float64)
+            full[(s.node_offset + s.own_begin) * D:(s.node_offset + s.own_end) * D] = torch.from_numpy(v[own].copy())
+            dist.all_reduce(full)
+            return full.numpy()
+
+        # (1) right-hand side and SpMV on owned rows
+        rhs_g = gather_owned(P.vec(O.V_RHS))
+        x = np.random.default_rng(4321).standard_normal(ng)
+        xl = x[glob].copy()
+        halo(xl)  # no-op numerically (already consistent) but exercises the ranges
+        yl = A @ xl
+        y_g = gather_owned(yl)
+        # (2) distributed Jacobi-PCG, x0 = 0
+        b = P.vec(O.V_RHS).copy()
+        dinv = 1.0 / A.diagonal()
+        xs, r = np.zeros_like(b), b.copy()
+        bnorm = np.sqrt(allsum(b[own] @ b[own]))
+        pvec, rz_old, its = np.zeros_like(b), 0.0, 0
+        while True:
+            rr, rz = allsum(r[own] @ r[own]), allsum(r[own] @ (dinv[own] * r[own]))
+            if np.sqrt(rr) <= 1e-10 * bnorm or its > 5000:
+                break
+            its += 1
+            beta = 0.0 if its == 1 else rz / rz_old
+            rz_old = rz
+            pvec[own] = dinv[own] * r[own] + beta * pvec[own]
+            halo(pvec)
+            q = A @ pvec
+            alpha = rz / allsum(pvec[own] @ q[own])
+            xs[own] += alpha * pvec[own]
+            r[own] -= alpha * q[own]
+        x_g = gather_owned(xs)
+        if rank == 0:
+            errs = {
+                "rhs": np.abs(rhs_g - Pg.vec(O.V_RHS)).max() / np.abs(Pg.vec(O.V_RHS)).max(),
+                "spmv": np.abs(y_g - Pg.csr() @ x).max() / np.abs(Pg.csr() @ x).max(),
+            }
+            Pg.vec(O.V_NEWTON)[:] = 0
+            rc, its_ref, _ = Pg.solve_linear(O.SOLVER_CG_JACOBI, tol_lin=1e-10, max_it_mult=2.0)
+            ref = Pg.vec(O.V_NEWTON)
+            errs["cg"] = np.abs(x_g - ref).max() / np.abs(ref).max()
+            errs["its"] = abs(its - its_ref)
+            out_q.put(errs)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dim,p,reps", [(3, 2, (2, 2, 4)), (2, 2, (6, 7))])
+def test_two_rank_gloo_decomposition(dim, p, reps):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, dim, p, reps, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    errs = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert errs["rhs"] < 1e-12 and errs["spmv"] < 1e-12
+    assert errs["cg"] < 1e-7 and errs["its"] <= 1
