@@ -45,23 +45,6 @@ namespace mi_detail
     SC_TOT = 10 // [rr, rz, pq, bb] all-reduced totals of the distributed CG
   };
 
-  struct Team
-  {
-    std::vector<mi_ctx *> members; // local slab contexts (1 unless emulated)
-    int                   size     = 1;
-    bool                  emulated = false;
-    ncclComm_t            nccl     = nullptr;
-    hipStream_t           stream   = nullptr;
-    int                   device   = 0;
-    int                   dim      = 0;
-    int64_t               n_global = 0, nnodes_global = 0;
-    std::vector<int64_t>  iface_global; // ascending global node ids
-    std::vector<double>   iface_xyz;    // their coordinates
-    double               *d_gbuf  = nullptr; // global-vector scratch (n_global doubles), on demand
-    double               *d_ifbuf = nullptr; // global interface scratch (n_if * dim doubles)
-    double              **d_sc_ptrs = nullptr; // emulated all-reduce: the members' scalar blocks
-  };
-
   int team_size(const mi_ctx *c)
   {
     return c->team ? c->team->size : 1;
@@ -85,6 +68,7 @@ namespace mi_detail
     return code;
   }
 
+#define TNCCL(T) (static_cast<ncclComm_t>((T).nccl))
 #define NCCLCHK(ctx, call)                                                                                  \
   do                                                                                                        \
     {                                                                                                       \
@@ -213,6 +197,8 @@ namespace mi_detail
     p.partials  = partials;
     p.done      = done;
     p.nslices   = int32_t(c->mesh.sell_nslices);
+    p.own_begin = int32_t(c->slab.own_begin);
+    p.own_end   = int32_t(c->slab.own_end);
     p.xcd_remap = c->xcd_remap;
     return p;
   }
@@ -236,7 +222,7 @@ namespace mi_detail
       return MI_OK;
     mi_ctx *c0 = T.members[0];
     if (T.nccl)
-      NCCLCHK(c0, ncclAllReduce(c0->d_sc + off, c0->d_sc + off, size_t(cnt), ncclDouble, ncclSum, T.nccl, T.stream));
+      NCCLCHK(c0, ncclAllReduce(c0->d_sc + off, c0->d_sc + off, size_t(cnt), ncclDouble, ncclSum, TNCCL(T), T.stream));
     else
       mi::launch_team_sum(T.d_sc_ptrs, int(T.members.size()), off, cnt, T.stream);
     return MI_OK;
@@ -256,13 +242,13 @@ namespace mi_detail
         NCCLCHK(c, ncclGroupStart());
         if (s.up_send_n)
           {
-            NCCLCHK(c, ncclSend(v + s.up_send * D, size_t(s.up_send_n) * D, ncclDouble, s.rank + 1, T.nccl, T.stream));
-            NCCLCHK(c, ncclRecv(v + s.up_recv * D, size_t(s.up_recv_n) * D, ncclDouble, s.rank + 1, T.nccl, T.stream));
+            NCCLCHK(c, ncclSend(v + s.up_send * D, size_t(s.up_send_n) * D, ncclDouble, s.rank + 1, TNCCL(T), T.stream));
+            NCCLCHK(c, ncclRecv(v + s.up_recv * D, size_t(s.up_recv_n) * D, ncclDouble, s.rank + 1, TNCCL(T), T.stream));
           }
         if (s.down_send_n)
           {
-            NCCLCHK(c, ncclSend(v + s.down_send * D, size_t(s.down_send_n) * D, ncclDouble, s.rank - 1, T.nccl, T.stream));
-            NCCLCHK(c, ncclRecv(v + s.down_recv * D, size_t(s.down_recv_n) * D, ncclDouble, s.rank - 1, T.nccl, T.stream));
+            NCCLCHK(c, ncclSend(v + s.down_send * D, size_t(s.down_send_n) * D, ncclDouble, s.rank - 1, TNCCL(T), T.stream));
+            NCCLCHK(c, ncclRecv(v + s.down_recv * D, size_t(s.down_recv_n) * D, ncclDouble, s.rank - 1, TNCCL(T), T.stream));
           }
         NCCLCHK(c, ncclGroupEnd());
         return MI_OK;
@@ -282,7 +268,7 @@ namespace mi_detail
   int team_allreduce_buffer(Team &T, double *buf, size_t n)
   {
     if (T.nccl)
-      NCCLCHK(T.members[0], ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, T.nccl, T.stream));
+      NCCLCHK(T.members[0], ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, TNCCL(T), T.stream));
     return MI_OK; // emulated / single: all slabs wrote into the same buffer already
   }
 
@@ -319,6 +305,7 @@ namespace mi_detail
     mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
                            c->d_sell_vals, c->stream);
     HIPCHK(c, hipGetLastError());
+    c->mg_stale = true; // the coarse operators belong to an older state
     return MI_OK;
   }
 
@@ -370,6 +357,33 @@ namespace mi_detail
       }
     const size_t R = T.members.size();
     int          rc;
+    bool         use_mg = true;
+    for (mi_ctx *m : T.members)
+      use_mg = use_mg && mg_active(m);
+    if (use_mg)
+      for (size_t k = 0; k < R; ++k)
+        {
+          mi_ctx *m = T.members[k];
+          if (m->mg_stale && (rc = mg_update(m)))
+            return fail(c0, rc, "%s", m->err.c_str());
+          cgs[k].z = m->work(W_Z) + m->own0;
+        }
+    // z = M^-1 r by the slab-local V-cycle, then the partials of r.z (and their team totals)
+    auto precondition = [&]() -> int {
+      for (size_t k = 0; k < R; ++k)
+        {
+          mi_ctx *m = T.members[k];
+          int     e = mg_apply(m, m->work(W_R), m->work(W_Z));
+          if (e)
+            return e;
+          mi::launch_dot_partials(cgs[k].r, cgs[k].z, m->own_n, cgs[k].part_rz, m->grid_vec, m->stream);
+          if (dist)
+            mi::launch_reduce_to_totals(cgs[k].part_rz, m->grid_vec, m->d_sc + SC_TOT + 1, nullptr, 0, nullptr, nullptr,
+                                        m->stream);
+        }
+      return team_allreduce(T, SC_TOT + 1, 1);
+    };
+    const int64_t batch = use_mg ? 1 : CG_BATCH; // a V-cycle costs ~5 SpMVs: poll every iteration, never waste one
     auto         x_of = [x_id](mi_ctx *m) { return m->vec(x_id); };
     auto         p_of = [](mi_ctx *m) { return m->work(W_P); };
 
@@ -396,6 +410,8 @@ namespace mi_detail
       }
     if ((rc = team_allreduce(T, SC_TOT, 4)))
       return rc;
+    if (use_mg && (rc = precondition()))
+      return rc;
     for (size_t k = 0; k < R; ++k)
       mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
 
@@ -412,7 +428,7 @@ namespace mi_detail
     };
     while (!done && it < max_it)
       {
-        const int64_t stop = std::min<int64_t>(max_it, it + CG_BATCH);
+        const int64_t stop = std::min<int64_t>(max_it, it + batch);
         for (; it < stop;)
           {
             ++it;
@@ -443,15 +459,17 @@ namespace mi_detail
               {
                 for (size_t k = 0; k < R; ++k)
                   mi::launch_reduce_to_totals(cgs[k].part_rr, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT,
-                                              cgs[k].part_rz, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT + 1,
-                                              cgs[k].flags, T.members[k]->stream);
-                if ((rc = team_allreduce(T, SC_TOT, 2)))
+                                              use_mg ? nullptr : cgs[k].part_rz, T.members[k]->grid_vec,
+                                              T.members[k]->d_sc + SC_TOT + 1, cgs[k].flags, T.members[k]->stream);
+                if ((rc = team_allreduce(T, SC_TOT, use_mg ? 1 : 2)))
                   return rc;
               }
           }
         for (size_t k = 0; k < R; ++k)
           mi::launch_cg_final_check(cgs[k], int(it), T.members[k]->stream);
         if ((rc = poll()))
+          return rc;
+        if (use_mg && !done && it < max_it && (rc = precondition()))
           return rc;
       }
     if (max_it <= 0)
@@ -484,6 +502,7 @@ namespace mi_detail
     if (!c)
       return;
     linear_destroy(c);
+    mg_destroy(c);
     for (auto &s : c->stamps)
       {
         hipEventDestroy(s.a);
@@ -640,11 +659,11 @@ namespace mi_detail
     for (mi_ctx *m : T->members)
       destroy_member(m);
     if (T->nccl)
-      ncclCommDestroy(T->nccl);
+      ncclCommDestroy(static_cast<ncclComm_t>(T->nccl));
     for (void *p : {(void *)T->d_gbuf, (void *)T->d_ifbuf, (void *)T->d_sc_ptrs})
       if (p)
         hipFree(p);
-    if (T->stream)
+    if (T->stream && T->owns_stream)
       hipStreamDestroy(T->stream);
     delete T;
   }
@@ -732,7 +751,9 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     {
       ncclUniqueId id;
       std::memcpy(&id, comm->nccl_unique_id, sizeof(id));
-      const ncclResult_t r = ncclCommInitRank(&T->nccl, nranks, id, comm->rank);
+      ncclComm_t         nc = nullptr;
+      const ncclResult_t r  = ncclCommInitRank(&nc, nranks, id, comm->rank);
+      T->nccl               = nc;
       if (r != ncclSuccess)
         return bail(MI_ECOMM, std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
     }
@@ -746,6 +767,21 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
         return bail(rc, m->err);
     }
   mi_ctx *c0 = T->members[0];
+  {
+    int precond = 1;
+    if (const char *e = getenv("MI_PRECOND"))
+      precond = atoi(e);
+    for (mi_ctx *m : T->members)
+      {
+        m->precond = precond;
+        if (precond == 1)
+          {
+            const int rc = mg_setup(m);
+            if (rc != MI_OK)
+              return bail(rc, m->err);
+          }
+      }
+  }
   // global interface scratch + coordinates of the global interface nodes (summed over the owners)
   {
     const size_t nifg = std::max<size_t>(1, T->iface_global.size() * size_t(md->dim));
@@ -763,7 +799,7 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     if (T->nccl)
       {
         if (hipMemcpy(T->d_ifbuf, xyz.data(), nifg * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
-            ncclAllReduce(T->d_ifbuf, T->d_ifbuf, nifg, ncclDouble, ncclSum, T->nccl, T->stream) != ncclSuccess ||
+            ncclAllReduce(T->d_ifbuf, T->d_ifbuf, nifg, ncclDouble, ncclSum, static_cast<ncclComm_t>(T->nccl), T->stream) != ncclSuccess ||
             hipStreamSynchronize(T->stream) != hipSuccess ||
             hipMemcpy(xyz.data(), T->d_ifbuf, nifg * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
           return bail(MI_ECOMM, "exchange of the interface coordinates failed");
@@ -1279,6 +1315,16 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->sell_unroll = value;
       else if (k == "spmv_grid" && value >= 1 && value <= MAX_PART)
         m->grid_spmv = value;
+      else if (k == "precond" && (value == 0 || value == 1))
+        {
+          m->precond = value;
+          if (value == 1 && !m->mg)
+            {
+              const int rc = mg_setup(m);
+              if (rc)
+                return fail(c, rc, "%s", m->err.c_str());
+            }
+        }
       else
         return fail(c, MI_EINVAL, "unknown tuning key '%s' or value %d out of range", k.c_str(), value);
     }

@@ -22,10 +22,30 @@ namespace mi_detail
     W_P,     // CG search direction
     W_Q,     // CG A*p
     W_DINV,  // Jacobi
+    W_Z,     // preconditioned residual (multigrid)
     W_COUNT
   };
   struct LinearModel; // mi_linear.cpp
-  struct Team;        // mi_ctx.cpp: the slab contexts that advance together (1 unless decomposed)
+  struct Multigrid;   // mi_mg.cpp
+
+  // the slab contexts that advance together (1 unless decomposed), see mi_ctx.cpp
+  struct Team
+  {
+    std::vector<mi_ctx *> members; // local slab contexts (1 unless emulated)
+    int                   size     = 1;
+    bool                  emulated = false;
+    bool                  owns_stream = true;
+    void                 *nccl     = nullptr; // ncclComm_t
+    hipStream_t           stream   = nullptr;
+    int                   device   = 0;
+    int                   dim      = 0;
+    int64_t               n_global = 0, nnodes_global = 0;
+    std::vector<int64_t>  iface_global; // ascending global node ids
+    std::vector<double>   iface_xyz;    // their coordinates
+    double               *d_gbuf  = nullptr; // global-vector scratch (n_global doubles), on demand
+    double               *d_ifbuf = nullptr; // global interface scratch (n_if * dim doubles)
+    double              **d_sc_ptrs = nullptr; // emulated all-reduce: the members' scalar blocks
+  };
 } // namespace mi_detail
 
 struct mi_ctx
@@ -84,6 +104,11 @@ struct mi_ctx
   int32_t             *d_own_if_nodes = nullptr, *d_own_if_slots = nullptr; // owned interface nodes -> global slots
   int                  n_own_if = 0;
 
+  // multigrid preconditioner of this slab (mi_mg.cpp); precond: 0 Jacobi, 1 multigrid V-cycle
+  mi_detail::Multigrid *mg = nullptr;
+  int                   precond = 1;
+  bool                  mg_stale = true; // coarse operators must be rebuilt before the next preconditioned solve
+
   double *vec(int which) { return d_vecs + size_t(which) * size_t(n); }
   double *work(int which) { return d_work + size_t(which) * size_t(n); }
   double *part(int which) { return d_part + size_t(which) * mi_detail::MAX_PART; }
@@ -103,6 +128,16 @@ namespace mi_detail
   int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res);
   int  team_size(const mi_ctx *c);
   void linear_destroy(mi_ctx *c);
+  int  create_member(Team &T, const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int rank,
+                     mi_ctx **out);
+  void destroy_team(Team *T);
+  int  enqueue_assembly(mi_ctx *c);
+  // multigrid (mi_mg.cpp)
+  int  mg_setup(mi_ctx *c);                             // build the level hierarchy of a slab (once)
+  void mg_destroy(mi_ctx *c);
+  int  mg_update(mi_ctx *c);                            // re-assemble the coarse operators for the current state
+  int  mg_apply(mi_ctx *c, const double *r, double *z); // z = V-cycle(r) on the slab (whole local vectors)
+  bool mg_active(const mi_ctx *c);
 
 #define HIPCHK(ctx, call)                                                                                   \
   do                                                                                                        \

@@ -51,6 +51,7 @@ namespace mi
     double        *partials;
     const int32_t *done;
     int32_t        nslices;
+    int32_t        own_begin, own_end; // rows (nodes) that contribute to the fused dot product
     int32_t        xcd_remap; // 1: workgroups of one XCD take a contiguous eighth of the slices (measured slower)
   };
 
@@ -63,6 +64,8 @@ namespace mi
     int32_t      *flags; // [2] done, iterations
     int64_t       n;
     int32_t       npart, npart_pq;
+    const double *z;      // preconditioned residual (general preconditioner); null -> Jacobi fused in the kernels
+    double       *hist;   // optional [2*it] alpha, [2*it+1] beta of every iteration (Lanczos eigenvalue estimates)
     const double *totals; // distributed: all-reduced [rr, rz, pq, bb]; null -> consumers reduce the partials
   };
 
@@ -72,6 +75,19 @@ namespace mi
     const double *du;
     double  alpha1, alpha2, alpha3, alpha4, alpha5, alpha6;
     int64_t n;
+  };
+
+  // index-space transfer between two lattices (see lattice_interp / lattice_restrict)
+  struct LatticeParams
+  {
+    int64_t        n_tgt;    // nodes of the target (interp) or coarse (restrict) lattice
+    int32_t        nt[3];    // its extents
+    int32_t        ns[3];    // extents of the source (interp) / fine (restrict) lattice
+    const int32_t *i0[3];    // interp: source index per target index
+    const double  *w[3];     //         weight of i0+1
+    const int32_t *rstart[3]; // restrict: per coarse index, range into ri/rw
+    const int32_t *ri[3];
+    const double  *rw[3];
   };
 
   struct LinearParams
@@ -95,6 +111,16 @@ namespace mi
                           double *sell_vals, hipStream_t s);
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s);
+  void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, int grid, hipStream_t s);
+  void launch_cheb_step(double *x, double *d, const double *b, const double *q, const double *dinv, double c1, double c2,
+                        int64_t n, hipStream_t s);
+  void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st);
+  void launch_vec_residual(double *res, const double *b, const double *q, int64_t n, hipStream_t s);
+  void launch_copy_owned(double *y, const double *x, int64_t n, int64_t own0, int64_t own_n, hipStream_t s);
+  void launch_lattice_interp(int dim, bool add, const LatticeParams &p, double *tgt, const double *src,
+                             const uint8_t *cmask_tgt, hipStream_t s);
+  void launch_lattice_restrict(int dim, const LatticeParams &p, double *coarse, const double *fine,
+                               const uint8_t *cmask_coarse, hipStream_t s);
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s);
   void launch_cg_update_xr(const CgParams &c, int it, int grid, hipStream_t s);
   void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s);

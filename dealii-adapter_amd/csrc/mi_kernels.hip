@@ -914,7 +914,7 @@ namespace mi
             for (int i = 0; i < D; ++i)
               {
                 prm.y[int64_t(node) * D + i] = acc[i];
-                if (prm.dotv)
+                if (prm.dotv && node >= prm.own_begin && node < prm.own_end)
                   dsum += acc[i] * prm.dotv[int64_t(node) * D + i];
               }
           }
@@ -1035,8 +1035,14 @@ namespace mi
       }
     const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-      c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
+    if (c.hist && blockIdx.x == 0 && threadIdx.x == 0)
+      c.hist[2 * (it - 1) + 1] = beta;
+    if (c.z)
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+        c.p[i] = c.z[i] + beta * c.p[i];
+    else
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+        c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
   }
 
   // cg_update_xr: alpha = rz / (p.Ap); x += alpha p; r -= alpha Ap; partials of ||r||^2 and r.dinv.r
@@ -1047,6 +1053,8 @@ namespace mi
       return;
     const double pq    = c.totals ? c.totals[2] : reduce_partials<256>(c.part_pq, c.npart_pq, s_red);
     const double alpha = c.sc[it & 1] / pq;
+    if (c.hist && blockIdx.x == 0 && threadIdx.x == 0)
+      c.hist[2 * (it - 1)] = alpha;
     const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
     double        srr = 0.0, srz = 0.0;
@@ -1063,8 +1071,167 @@ namespace mi
     if (threadIdx.x == 0)
       {
         c.part_rr[blockIdx.x] = srr;
-        c.part_rz[blockIdx.x] = srz;
+        if (!c.z) // with a general preconditioner r.z is formed after z = M^-1 r (dot_partials)
+          c.part_rz[blockIdx.x] = srz;
       }
+  }
+
+  // partials of a . b over [0,n)
+  __global__ __launch_bounds__(256) void dot_partials(const double *__restrict__ a, const double *__restrict__ b,
+                                                      int64_t n, double *part)
+  {
+    __shared__ double s_red[4];
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = blockIdx.x * per, i1 = imin64(n, i0 + per);
+    double        s  = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      s += a[i] * b[i];
+    s = block_sum<256>(s, s_red);
+    if (threadIdx.x == 0)
+      part[blockIdx.x] = s;
+  }
+
+  // ------------------------------------------------------------------ multigrid pieces
+  // One Chebyshev-Jacobi step for A x = b:  res = b - q (q = A x, or 0 if q == null);
+  // d = c1 d + c2 D^-1 res;  x += d.   (Saad, Iterative Methods, Alg. 12.1 with D^-1 A)
+  __global__ __launch_bounds__(256) void cheb_step(double *x, double *d, const double *__restrict__ b,
+                                                   const double *__restrict__ q, const double *__restrict__ dinv,
+                                                   double c1, double c2, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n)
+      return;
+    const double res = b[i] - (q ? q[i] : 0.0);
+    const double dn  = c1 * d[i] + c2 * dinv[i] * res;
+    d[i]             = dn;
+    x[i]             = (q ? x[i] : 0.0) + dn; // first step starts from x = 0
+  }
+  // dst = s * a .* b   (b == null: dst = s * a)
+  __global__ __launch_bounds__(256) void vec_scale_mul(double *dst, const double *__restrict__ a,
+                                                       const double *__restrict__ b, double s, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+      dst[i] = s * a[i] * (b ? b[i] : 1.0);
+  }
+  // res = b - q
+  __global__ __launch_bounds__(256) void vec_residual(double *res, const double *__restrict__ b,
+                                                      const double *__restrict__ q, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+      res[i] = b[i] - q[i];
+  }
+  // y = mask(x): copy the dofs inside [own0, own0+own_n), zero elsewhere (block preconditioner input)
+  __global__ __launch_bounds__(256) void copy_owned(double *y, const double *__restrict__ x, int64_t n, int64_t own0,
+                                                    int64_t own_n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+      y[i] = (i >= own0 && i < own0 + own_n) ? x[i] : 0.0;
+  }
+
+  // Lattice transfers in index space.  Every level is a tensor-product lattice; along each direction the table
+  // gives, for a TARGET index t, the source index i0[t] and the weight w[t] of i0[t]+1 (linear interpolation).
+  //   interp  : target[t] (+)= sum over the 2^dim source corners  (prolongation: target fine, source coarse;
+  //             state transfer: target coarse, source fine)
+  //   restrict: coarse[I] = sum over fine nodes whose interpolation stencil touches I (transpose of interp),
+  //             written as a gather over per-direction lists  start[I] .. start[I+1]  of (fine index, weight)
+  template <int D, bool ADD>
+  __global__ __launch_bounds__(256) void lattice_interp(LatticeParams p, double *tgt, const double *__restrict__ src,
+                                                        const uint8_t *__restrict__ cmask_tgt)
+  {
+    const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= p.n_tgt)
+      return;
+    int ti[3] = {int(t % p.nt[0]), int((t / p.nt[0]) % p.nt[1]), int(t / (int64_t(p.nt[0]) * p.nt[1]))};
+    int    i0[3] = {0, 0, 0};
+    double w[3]  = {0, 0, 0};
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      {
+        i0[d] = p.i0[d][ti[d]];
+        w[d]  = p.w[d][ti[d]];
+      }
+    double acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      acc[c] = 0.0;
+#pragma unroll
+    for (int corner = 0; corner < (1 << D); ++corner)
+      {
+        double  wt = 1.0;
+        int64_t s  = 0, stride = 1;
+        bool    ok = true;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          {
+            const int hi = (corner >> d) & 1;
+            const double wd = hi ? w[d] : 1.0 - w[d];
+            wt *= wd;
+            const int idx = i0[d] + hi;
+            ok            = ok && (wd != 0.0);
+            s += int64_t(idx < p.ns[d] ? idx : p.ns[d] - 1) * stride;
+            stride *= p.ns[d];
+          }
+        if (ok)
+#pragma unroll
+          for (int c = 0; c < D; ++c)
+            acc[c] += wt * src[s * D + c];
+      }
+    const int m = cmask_tgt ? cmask_tgt[t] : 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      {
+        const double v = ((m >> c) & 1) ? 0.0 : acc[c];
+        if (ADD)
+          tgt[t * D + c] += v;
+        else
+          tgt[t * D + c] = v;
+      }
+  }
+
+  template <int D>
+  __global__ __launch_bounds__(256) void lattice_restrict(LatticeParams p, double *coarse, const double *__restrict__ fine,
+                                                          const uint8_t *__restrict__ cmask_coarse)
+  {
+    const int64_t I = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (I >= p.n_tgt)
+      return;
+    int ci[3] = {int(I % p.nt[0]), int((I / p.nt[0]) % p.nt[1]), int(I / (int64_t(p.nt[0]) * p.nt[1]))};
+    int b[3] = {0, 0, 0}, e[3] = {1, 1, 1};
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      {
+        b[d] = p.rstart[d][ci[d]];
+        e[d] = p.rstart[d][ci[d] + 1];
+      }
+    double acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      acc[c] = 0.0;
+    for (int kz = b[2]; kz < e[2]; ++kz)
+      {
+        const double  wz = (D == 3) ? p.rw[2][kz] : 1.0;
+        const int64_t fz = (D == 3) ? p.ri[2][kz] : 0;
+        for (int ky = b[1]; ky < e[1]; ++ky)
+          {
+            const double  wy = p.rw[1][ky] * wz;
+            const int64_t fy = p.ri[1][ky];
+            for (int kx = b[0]; kx < e[0]; ++kx)
+              {
+                const double  wt = p.rw[0][kx] * wy;
+                const int64_t f  = p.ri[0][kx] + int64_t(p.ns[0]) * (fy + int64_t(p.ns[1]) * fz);
+#pragma unroll
+                for (int c = 0; c < D; ++c)
+                  acc[c] += wt * fine[f * D + c];
+              }
+          }
+      }
+    const int m = cmask_coarse ? cmask_coarse[I] : 0;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+      coarse[I * D + c] = ((m >> c) & 1) ? 0.0 : acc[c];
   }
 
   // r = b - q (q = A x0), partials of ||r||^2, r.dinv.r and ||b||^2
@@ -1459,6 +1626,56 @@ namespace mi
                               hipStream_t s)
   {
     hipLaunchKernelGGL(sell_build_cols, dim3((p.nslices + 3) / 4), dim3(256), 0, s, p, rowptr, bsr_col, sell_col);
+  }
+
+  void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, int grid, hipStream_t s)
+  {
+    hipLaunchKernelGGL(dot_partials, dim3(grid), dim3(256), 0, s, a, b, n, part);
+  }
+  void launch_cheb_step(double *x, double *d, const double *b, const double *q, const double *dinv, double c1, double c2,
+                        int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cheb_step, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, d, b, q, dinv, c1, c2, n);
+  }
+  void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st)
+  {
+    hipLaunchKernelGGL(vec_scale_mul, dim3(int((n + 255) / 256)), dim3(256), 0, st, dst, a, b, s, n);
+  }
+  void launch_vec_residual(double *res, const double *b, const double *q, int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(vec_residual, dim3(int((n + 255) / 256)), dim3(256), 0, s, res, b, q, n);
+  }
+  void launch_copy_owned(double *y, const double *x, int64_t n, int64_t own0, int64_t own_n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(copy_owned, dim3(int((n + 255) / 256)), dim3(256), 0, s, y, x, n, own0, own_n);
+  }
+  void launch_lattice_interp(int dim, bool add, const LatticeParams &p, double *tgt, const double *src,
+                             const uint8_t *cmask_tgt, hipStream_t s)
+  {
+    const int grid = int((p.n_tgt + 255) / 256);
+    if (dim == 3)
+      {
+        if (add)
+          hipLaunchKernelGGL((lattice_interp<3, true>), dim3(grid), dim3(256), 0, s, p, tgt, src, cmask_tgt);
+        else
+          hipLaunchKernelGGL((lattice_interp<3, false>), dim3(grid), dim3(256), 0, s, p, tgt, src, cmask_tgt);
+      }
+    else
+      {
+        if (add)
+          hipLaunchKernelGGL((lattice_interp<2, true>), dim3(grid), dim3(256), 0, s, p, tgt, src, cmask_tgt);
+        else
+          hipLaunchKernelGGL((lattice_interp<2, false>), dim3(grid), dim3(256), 0, s, p, tgt, src, cmask_tgt);
+      }
+  }
+  void launch_lattice_restrict(int dim, const LatticeParams &p, double *coarse, const double *fine,
+                               const uint8_t *cmask_coarse, hipStream_t s)
+  {
+    const int grid = int((p.n_tgt + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((lattice_restrict<3>), dim3(grid), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
+    else
+      hipLaunchKernelGGL((lattice_restrict<2>), dim3(grid), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
   }
 
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s)

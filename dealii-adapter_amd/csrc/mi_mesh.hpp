@@ -556,9 +556,10 @@ namespace mi
       build_sell(own_begin, own_end < 0 ? nnodes : own_end);
     }
 
-    // SpMV rows = the owned node range only
-    void build_sell(int64_t own_begin, int64_t own_end)
+    // SpMV rows = ALL local rows (the CG only uses the owned ones; the slab-local multigrid needs them all)
+    void build_sell(int64_t /*own_begin*/, int64_t /*own_end*/)
     {
+      const int64_t own_begin = 0, own_end = nnodes;
       std::vector<int32_t> lens;
       for (int64_t n = 0; n < nnodes; ++n)
         lens.push_back(rowptr[size_t(n) + 1] - rowptr[size_t(n)]);
