@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=59, help="cells per side of the Q2 block (59 -> 5,055,477 DoFs)")
     ap.add_argument("--tol-lin", type=float, default=1e-6)
+    ap.add_argument("--precond", choices=["mg", "jacobi"], default="mg",
+                    help="CG preconditioner: geometric multigrid V-cycle (default) or Jacobi")
     ap.add_argument("--slabs", type=int, default=1, help="diagnostic: cut the mesh into this many slabs on ONE GPU")
     ap.add_argument("--cpu-cells", type=int, default=16, help="cells per side of the CPU-baseline sample (0: skip)")
     args = ap.parse_args()
@@ -106,6 +108,7 @@ def main():
     G = M.Context(dim=3, degree=2, reps=(n, n, n), lo=(0, 0, 0), hi=(1, 1, 1), mu=0.5e6, nu=0.4, rho=1000.0,
                   beta=0.25, gamma=0.5, delta_t=0.005, device=local_rank, rank=rank, world=world, unique_id=uid,
                   slabs=args.slabs if world == 1 else 1)
+    G.set_tuning("precond", 1 if args.precond == "mg" else 0)
     nnzb = G.nnz // 9
     traction = (0.0, -2e3, 0.0)
 
@@ -146,6 +149,12 @@ def main():
         spmv_avg_ms = spmv_ms / max(spmv_n, 1)
         bytes_bsr = spmv_bytes(G.nnodes, nnzb, 3) // world  # bytes of the rows this rank owns
         achieved = bytes_bsr / (spmv_avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
+        # HBM traffic of the same kernel on the same workload from the committed PMC passes (rocprofv3 --pmc cannot be
+        # collected from inside this process); only quoted when the workload is the one that was profiled
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_n59.json")
+        if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9  # GB per launch
         out = {
             "metric": "DoF-updates/sec per Newmark step (assembly+CG), 3D Q2 ~5M DoFs",
             "value": G.n * args.steps / elapsed,
@@ -161,8 +170,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %d^3 cells, %d DoFs, %d nnz, Newton+Newmark, "
-                            "Jacobi-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
-                            % (n, G.n, G.nnz, args.tol_lin),
+                            "%s-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
+                            % (n, G.n, G.nnz, "multigrid" if args.precond == "mg" else "Jacobi", args.tol_lin),
+                "preconditioner": "geometric multigrid V-cycle (Chebyshev-Jacobi smoothing, re-assembled coarse levels), "
+                                  "block-wise per slab" if args.precond == "mg" else "Jacobi",
                 "n_dofs": G.n,
                 "nnz": G.nnz,
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs emulated on one GPU" % args.slabs) if world == 1 else
@@ -181,7 +192,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "bytes_per_launch": bytes_bsr,
                 "launches_timed": spmv_n,
                 "avg_launch_ms": spmv_avg_ms,
