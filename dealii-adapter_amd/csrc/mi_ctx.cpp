@@ -141,6 +141,7 @@ namespace mi_detail
     p.alpha1 = c->alpha[1];
     for (int i = 0; i < 3; ++i)
       p.body[i] = c->mat.body_force[i];
+    p.variant = c->asm_variant;
     return p;
   }
 
@@ -364,8 +365,12 @@ namespace mi_detail
       for (size_t k = 0; k < R; ++k)
         {
           mi_ctx *m = T.members[k];
-          if (m->mg_stale && (rc = mg_update(m)))
-            return fail(c0, rc, "%s", m->err.c_str());
+          if (m->mg_stale && (m->mg_force || !m->mg_lag))
+            {
+              if ((rc = mg_update(m)))
+                return fail(c0, rc, "%s", m->err.c_str());
+              m->mg_force = false;
+            }
           cgs[k].z = m->work(W_Z) + m->own0;
         }
     // z = M^-1 r by the slab-local V-cycle, then the partials of r.z (and their team totals)
@@ -973,6 +978,7 @@ int mi_newton_begin_step(mi_ctx *c)
     {
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_SOLUTION_DELTA), 0, size_t(m->n) * sizeof(double), m->stream));
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
+      m->mg_force = true; // new time step: refresh the coarse operators at its first solve
     }
   return MI_OK;
 }
@@ -1315,6 +1321,10 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->sell_unroll = value;
       else if (k == "spmv_grid" && value >= 1 && value <= MAX_PART)
         m->grid_spmv = value;
+      else if (k == "asm_variant" && value >= 0 && value <= 8)
+        m->asm_variant = value;
+      else if (k == "mg_lag" && (value == 0 || value == 1))
+        m->mg_lag = value;
       else if (k == "precond" && (value == 0 || value == 1))
         {
           m->precond = value;

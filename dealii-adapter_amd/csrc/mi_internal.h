@@ -107,7 +107,10 @@ struct mi_ctx
   // multigrid preconditioner of this slab (mi_mg.cpp); precond: 0 Jacobi, 1 multigrid V-cycle
   mi_detail::Multigrid *mg = nullptr;
   int                   precond = 1;
-  bool                  mg_stale = true; // coarse operators must be rebuilt before the next preconditioned solve
+  bool                  mg_stale = true; // the coarse operators belong to an older state than the fine tangent
+  bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
+  int                   asm_variant = 0;
+  int                   mg_lag   = 1;    // 1: keep the coarse operators over the Newton iterations of one step
 
   double *vec(int which) { return d_vecs + size_t(which) * size_t(n); }
   double *work(int which) { return d_work + size_t(which) * size_t(n); }

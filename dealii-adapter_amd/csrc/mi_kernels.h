@@ -21,6 +21,7 @@ namespace mi
     double          body[3];
     int64_t         cell_begin;
     int32_t         cell_count;
+    int32_t         variant; // kernel variant for A/B timing
   };
 
   struct SpmvParams

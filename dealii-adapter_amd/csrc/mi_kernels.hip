@@ -239,8 +239,8 @@ namespace mi
   //   phase A: per-QP kinematics/material records -> LDS (4 lanes per QP)
   //   per chunk of QC points: phase B (qp,node) records g, m, v, n -> LDS; main loop; residual
   //   epilogue: read-modify-write of the cell's blocks into the global block-CSR (colouring => race free)
-  template <int DIM, int P, int QSPLIT, int NT, int QC>
-  __global__ __launch_bounds__(NT) void assemble_cells(AsmParams prm)
+  template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1>
+  __global__ __launch_bounds__(NT, MINW) void assemble_cells(AsmParams prm)
   {
     using E = Elem<DIM, P>;
     constexpr int NPC = E::NPC, NPCP = E::NPCP, NQ = E::NQ, NQ1 = E::NQ1, NP1 = E::NP1, DD = E::DD, NV = E::NV;
@@ -1497,10 +1497,10 @@ namespace mi
   }
 
   // ------------------------------------------------------------------ launchers
-  template <int DIM, int P, int QSPLIT, int NT, int QC>
+  template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1>
   static void launch_asm(const AsmParams &p, hipStream_t s)
   {
-    hipLaunchKernelGGL((assemble_cells<DIM, P, QSPLIT, NT, QC>), dim3(p.cell_count), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((assemble_cells<DIM, P, QSPLIT, NT, QC, MINW>), dim3(p.cell_count), dim3(NT), 0, s, p);
   }
 
   int launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s)
@@ -1509,7 +1509,20 @@ namespace mi
       return 0;
     // <DIM, P, QSPLIT, NT, QC>: NT >= NTILES*QSPLIT and >= NPC*DIM; QC divides NQ
     if (dim == 3 && degree == 2)
-      launch_asm<3, 2, 2, 256, 16>(p, s); // 105 tiles x 2, 64 QPs in chunks of 16
+      {
+        // 105 tiles x 2 lanes, 64 quadrature points in chunks of QC; variants for A/B timing (mi_set_tuning "asm_variant")
+        switch (p.variant)
+          {
+            case 1:
+              launch_asm<3, 2, 2, 256, 16>(p, s); // 54 kB LDS, 2 workgroups per CU: 23.6 ms per assembly at 5M DoFs
+              break;
+            case 2:
+              launch_asm<3, 2, 2, 256, 4>(p, s); // 27 kB LDS: no faster than QC = 8 (register limited)
+              break;
+            default:
+              launch_asm<3, 2, 2, 256, 8>(p, s); // 36 kB LDS, 3 workgroups per CU: 19.5 ms
+          }
+      }
     else if (dim == 3 && degree == 1)
       launch_asm<3, 1, 4, 64, 27>(p, s); // 10 tiles x 4
     else if (dim == 2 && degree == 1)
