@@ -265,6 +265,25 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // sum over all slabs of a replicated vector (every slab holds all n entries): coarse multigrid residuals
+  int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n)
+  {
+    if (T.size == 1)
+      return MI_OK;
+    if (T.nccl)
+      {
+        mi_ctx *c = T.members[0];
+        NCCLCHK(c, ncclAllReduce(vec(c), vec(c), n, ncclDouble, ncclSum, TNCCL(T), T.stream));
+        return MI_OK;
+      }
+    mi_ctx *c0 = T.members[0];
+    for (size_t r = 1; r < T.members.size(); ++r)
+      mi::launch_vec_add(vec(c0), vec(T.members[r]), int64_t(n), T.stream);
+    for (size_t r = 1; r < T.members.size(); ++r)
+      HIPCHK(c0, hipMemcpyAsync(vec(T.members[r]), vec(c0), n * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
+    return MI_OK;
+  }
+
   // sum over all ranks of a device buffer that every rank holds in full (global vector / interface scratch)
   int team_allreduce_buffer(Team &T, double *buf, size_t n)
   {
@@ -362,25 +381,25 @@ namespace mi_detail
     for (mi_ctx *m : T.members)
       use_mg = use_mg && mg_active(m);
     if (use_mg)
-      for (size_t k = 0; k < R; ++k)
-        {
-          mi_ctx *m = T.members[k];
-          if (m->mg_stale && (m->mg_force || !m->mg_lag))
-            {
-              if ((rc = mg_update(m)))
-                return fail(c0, rc, "%s", m->err.c_str());
+      {
+        if (c0->mg_stale && (c0->mg_force || !c0->mg_lag))
+          {
+            if ((rc = mg_update(T)))
+              return rc;
+            for (mi_ctx *m : T.members)
               m->mg_force = false;
-            }
-          cgs[k].z = m->work(W_Z) + m->own0;
-        }
-    // z = M^-1 r by the slab-local V-cycle, then the partials of r.z (and their team totals)
+          }
+        for (size_t k = 0; k < R; ++k)
+          cgs[k].z = T.members[k]->work(W_Z) + T.members[k]->own0;
+      }
+    // z = M^-1 r by the team-wide V-cycle, then the partials of r.z (and their team totals)
     auto precondition = [&]() -> int {
+      int e = mg_apply(T);
+      if (e)
+        return e;
       for (size_t k = 0; k < R; ++k)
         {
           mi_ctx *m = T.members[k];
-          int     e = mg_apply(m, m->work(W_R), m->work(W_Z));
-          if (e)
-            return e;
           mi::launch_dot_partials(cgs[k].r, cgs[k].z, m->own_n, cgs[k].part_rz, m->grid_vec, m->stream);
           if (dist)
             mi::launch_reduce_to_totals(cgs[k].part_rz, m->grid_vec, m->d_sc + SC_TOT + 1, nullptr, 0, nullptr, nullptr,
@@ -728,6 +747,8 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   T->emulated = emulated;
   T->device   = device_id;
   T->dim      = md->dim;
+  T->md       = *md;
+  T->md.vertex_perturbation = nullptr; // coarse levels use the unperturbed box
   auto bail   = [&](int code, const std::string &msg) {
     g_create_error = msg;
     destroy_team(T);

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ namespace mi_detail
     double               *d_gbuf  = nullptr; // global-vector scratch (n_global doubles), on demand
     double               *d_ifbuf = nullptr; // global interface scratch (n_if * dim doubles)
     double              **d_sc_ptrs = nullptr; // emulated all-reduce: the members' scalar blocks
+    mi_mesh_desc          md{};                // the undecomposed mesh (coarse multigrid levels are global)
   };
 } // namespace mi_detail
 
@@ -136,11 +138,15 @@ namespace mi_detail
   void destroy_team(Team *T);
   int  enqueue_assembly(mi_ctx *c);
   // multigrid (mi_mg.cpp)
-  int  mg_setup(mi_ctx *c);                             // build the level hierarchy of a slab (once)
+  int  mg_setup(mi_ctx *c); // build the level hierarchy of a slab (once)
   void mg_destroy(mi_ctx *c);
-  int  mg_update(mi_ctx *c);                            // re-assemble the coarse operators for the current state
-  int  mg_apply(mi_ctx *c, const double *r, double *z); // z = V-cycle(r) on the slab (whole local vectors)
+  int  mg_update(Team &T);  // re-assemble the coarse operators for the current state (team-wide)
+  int  mg_apply(Team &T);   // W_Z = V-cycle(W_R) on every slab of the team (team-wide, collective)
   bool mg_active(const mi_ctx *c);
+  // team collectives (mi_ctx.cpp)
+  int team_allreduce(Team &T, int off, int cnt);
+  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec);
+  int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);
 
 #define HIPCHK(ctx, call)                                                                                   \
   do                                                                                                        \

@@ -1153,6 +1153,10 @@ namespace mi
         i0[d] = p.i0[d][ti[d]];
         w[d]  = p.w[d][ti[d]];
       }
+    bool served = true; // a negative source index: this target node is served by another slab (contributes 0)
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      served = served && (i0[d] >= 0);
     double acc[D];
 #pragma unroll
     for (int c = 0; c < D; ++c)
@@ -1162,7 +1166,7 @@ namespace mi
       {
         double  wt = 1.0;
         int64_t s  = 0, stride = 1;
-        bool    ok = true;
+        bool    ok = served;
 #pragma unroll
         for (int d = 0; d < D; ++d)
           {

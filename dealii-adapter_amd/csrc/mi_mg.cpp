@@ -1,18 +1,21 @@
-// mi_mg.cpp -- geometric multigrid V-cycle used as the CG preconditioner of a slab (the
-// reference preconditions with SSOR, which is sequential; Jacobi needs ~450 iterations per solve at 5 M DoFs).
+// mi_mg.cpp -- geometric multigrid V-cycle used as the CG preconditioner (the reference
+// preconditions with SSOR, which is sequential; Jacobi needs ~450 iterations per solve at 5 M DoFs).
 //
 // Everything is built from pieces that already exist on the device:
-//   * levels are ordinary device contexts on coarser lattices of the same box: first p-coarsening to Q1 on the
-//     same cells, then index-space coarsening of the cells by 2 down to a single cell;
+//   * level 0 is the fine problem itself, distributed over the slabs of the team exactly like the CG (owned rows,
+//     ghost planes by halo exchange);
+//   * levels >= 1 are ordinary device contexts on coarser lattices of the UNDECOMPOSED box: first p-coarsening to
+//     Q1 on the same cells, then index-space coarsening of the cells by 2 down to a single cell.  They are 15x and
+//     more smaller than the fine level and are REPLICATED on every slab/GPU: the only collective a V-cycle adds is
+//     one all-reduce of the restricted (level-1) residual;
 //   * coarse operators are RE-ASSEMBLED by the same element kernel at the current state (displacement
 //     interpolated to the level), so no sparse triple products are needed and the Newmark mass term, the
 //     Dirichlet rows and the material are treated exactly as on the fine level;
 //   * smoothers are Chebyshev-Jacobi polynomials on the level's sliced-ELL SpMV, with the largest eigenvalue of
-//     D^-1 A from a device-side power iteration; the coarsest level (one cell) is "solved" by a longer polynomial;
+//     D^-1 A from a power iteration; the coarsest level (one cell) is "solved" by a longer polynomial;
 //   * transfers are tensor-product linear interpolation in lattice index space and its transpose.
 // The cycle is symmetric (same polynomial before and after the coarse correction), so it is a valid CG
-// preconditioner.  On a decomposed mesh every slab runs the cycle on its own local box (owned residual in, owned
-// correction out): a block preconditioner without any extra communication.
+// preconditioner, and it is the same operator for any number of slabs up to rounding.
 #include <cmath>
 #include <cstring>
 
@@ -29,7 +32,7 @@ namespace mi_detail
   struct MgLevel
   {
     mi_ctx *ctx  = nullptr; // level 0: the slab itself (not owned)
-    Team   *team = nullptr; // levels >= 1 own a private team (shared stream)
+    Team   *team = nullptr; // levels >= 1 own a private single-slab team (shared stream)
     double *ws   = nullptr; // workspace: b, x, d, q, ev  (5 local vectors; ev = running eigenvector estimate)
     bool    ev_ready = false;
     double  lmax = 0.0;     // estimate of the largest eigenvalue of D^-1 A
@@ -76,8 +79,8 @@ namespace mi_detail
     // i0 and the weight w of i0+1 on a lattice with ns points covering the same interval
     void interp_table(int nt, int ns, std::vector<int32_t> &i0, std::vector<double> &w)
     {
-      i0.resize(size_t(nt));
-      w.resize(size_t(nt));
+      i0.resize((size_t)nt);
+      w.resize((size_t)nt);
       for (int t = 0; t < nt; ++t)
         {
           const double s = (nt > 1) ? double(t) * double(ns - 1) / double(nt - 1) : 0.0;
@@ -99,37 +102,57 @@ namespace mi_detail
         }
     }
 
-    int build_transfer(mi_ctx *fine, mi_ctx *coarse, MgTransfer &t)
+    // Transfer tables between a fine context and a coarse GLOBAL context.  The fine context may be a slab: along the
+    // decomposed (last) direction its local lattice index k corresponds to the global index k + zoff, and it owns
+    // the local planes [own_lo, own_hi).  Ownership keeps sums over slabs free of double counting:
+    //   restriction lists only contain owned fine planes; the state transfer serves a coarse node only on the slab
+    //   that owns its left source plane; prolongation fills every local fine plane (ghosts included).
+    int build_transfer(mi_ctx *fine, mi_ctx *coarse, MgTransfer &t, bool fine_is_slab)
     {
-      const int dim = fine->dim;
+      const int dim = fine->dim, zd = dim - 1;
       int       rc;
-      t.prolong.n_tgt  = fine->mesh.nnodes;
+      t.prolong.n_tgt   = fine->mesh.nnodes;
       t.restrict_.n_tgt = coarse->mesh.nnodes;
-      t.state.n_tgt    = coarse->mesh.nnodes;
+      t.state.n_tgt     = coarse->mesh.nnodes;
       for (int d = 0; d < 3; ++d)
         {
-          const int nf = d < dim ? fine->mesh.nn[d] : 1, nc = d < dim ? coarse->mesh.nn[d] : 1;
-          t.prolong.nt[d] = nf;
-          t.prolong.ns[d] = nc;
+          const int nf_loc = d < dim ? fine->mesh.nn[d] : 1, nc = d < dim ? coarse->mesh.nn[d] : 1;
+          t.prolong.nt[d]   = nf_loc;
+          t.prolong.ns[d]   = nc;
           t.restrict_.nt[d] = nc;
-          t.restrict_.ns[d] = nf;
-          t.state.nt[d] = nc;
-          t.state.ns[d] = nf;
+          t.restrict_.ns[d] = nf_loc;
+          t.state.nt[d]     = nc;
+          t.state.ns[d]     = nf_loc;
           if (d >= dim)
             continue;
-          std::vector<int32_t> i0;
-          std::vector<double>  w;
-          interp_table(nf, nc, i0, w); // prolongation: fine target <- coarse source
+          const bool cut  = fine_is_slab && d == zd;
+          const int  zoff = cut ? int(fine->slab.node_offset / fine->slab.plane_nodes) : 0;
+          const int  nf   = cut ? int(fine->slab.nnodes_global / fine->slab.plane_nodes) : nf_loc; // global extent
+          const int  own_lo = cut ? int(fine->slab.own_begin / fine->slab.plane_nodes) : 0;
+          const int  own_hi = cut ? int(fine->slab.own_end / fine->slab.plane_nodes) : nf_loc; // local, exclusive
+          std::vector<int32_t> gi0;
+          std::vector<double>  gw;
+          interp_table(nf, nc, gi0, gw); // fine (global index) <- coarse
+          // prolongation: every local fine index
+          std::vector<int32_t> i0((size_t)nf_loc);
+          std::vector<double>  w((size_t)nf_loc);
+          for (int k = 0; k < nf_loc; ++k)
+            {
+              i0[size_t(k)] = gi0[size_t(k + zoff)];
+              w[size_t(k)]  = gw[size_t(k + zoff)];
+            }
           if ((rc = to_device(fine, t, i0, &t.prolong.i0[d])) || (rc = to_device(fine, t, w, &t.prolong.w[d])))
             return rc;
-          // restriction = transpose: for every coarse index the fine indices whose stencil touches it
+          // restriction = transpose over the OWNED fine planes
           std::vector<std::vector<std::pair<int32_t, double>>> lists((size_t)nc);
-          for (int f = 0; f < nf; ++f)
+          for (int k = own_lo; k < own_hi; ++k)
             {
-              if (1.0 - w[size_t(f)] != 0.0)
-                lists[size_t(i0[size_t(f)])].push_back({f, 1.0 - w[size_t(f)]});
-              if (w[size_t(f)] != 0.0)
-                lists[size_t(i0[size_t(f)] + 1)].push_back({f, w[size_t(f)]});
+              const int    c0 = gi0[size_t(k + zoff)];
+              const double w1 = gw[size_t(k + zoff)];
+              if (1.0 - w1 != 0.0)
+                lists[size_t(c0)].push_back({k, 1.0 - w1});
+              if (w1 != 0.0)
+                lists[size_t(c0 + 1)].push_back({k, w1});
             }
           std::vector<int32_t> rs(1, 0), ri;
           std::vector<double>  rw;
@@ -145,55 +168,95 @@ namespace mi_detail
           if ((rc = to_device(fine, t, rs, &t.restrict_.rstart[d])) || (rc = to_device(fine, t, ri, &t.restrict_.ri[d])) ||
               (rc = to_device(fine, t, rw, &t.restrict_.rw[d])))
             return rc;
-          interp_table(nc, nf, i0, w); // state transfer: coarse target <- fine source
-          if ((rc = to_device(fine, t, i0, &t.state.i0[d])) || (rc = to_device(fine, t, w, &t.state.w[d])))
+          // state transfer: coarse target <- fine source, served by the slab that owns the left source plane
+          interp_table(nc, nf, gi0, gw);
+          std::vector<int32_t> si0((size_t)nc);
+          std::vector<double>  sw((size_t)nc);
+          for (int tI = 0; tI < nc; ++tI)
+            {
+              const int kl = gi0[size_t(tI)] - zoff; // local index of the left source plane
+              if (kl >= own_lo && kl < own_hi)
+                {
+                  si0[size_t(tI)] = kl;
+                  sw[size_t(tI)]  = gw[size_t(tI)];
+                  if (kl + 1 >= nf_loc && gw[size_t(tI)] != 0.0)
+                    return fail(fine, MI_EINVAL, "multigrid: state transfer needs a plane outside the slab");
+                }
+              else
+                {
+                  si0[size_t(tI)] = -1;
+                  sw[size_t(tI)]  = 0.0;
+                }
+            }
+          if ((rc = to_device(fine, t, si0, &t.state.i0[d])) || (rc = to_device(fine, t, sw, &t.state.w[d])))
             return rc;
         }
       return MI_OK;
     }
 
-    // power iteration for lambda_max(D^-1 A) of a level
-    int estimate_lmax(Multigrid &mg, MgLevel &L)
+    // power iteration for lambda_max(D^-1 A); level 0 is distributed over the team, the others are replicated
+    int estimate_lmax(Team &T, size_t l)
     {
-      mi_ctx       *c = L.ctx;
-      const int64_t n = c->n;
-      double       *v = L.ev(), *q = L.q(), *w = L.d();
-      int           its = mg.power_its_update;
-      if (!L.ev_ready)
+      mi_ctx    *c0  = T.members[0];
+      Multigrid &mg0 = *c0->mg;
+      const bool fine = (l == 0);
+      int        its  = mg0.power_its_update;
+      for (mi_ctx *m : T.members)
         {
-          // deterministic start vector with all frequencies: v_i = 1 + 0.5 sin(i) on unconstrained dofs; later
-          // updates continue from the previous estimate of the dominant eigenvector
-          std::vector<double> h((size_t)n, 0.0);
-          double              nrm = 0;
-          for (int64_t i = 0; i < n; ++i)
+          MgLevel      &L = m->mg->levels[l];
+          mi_ctx       *c = L.ctx;
+          const int64_t n = c->n;
+          if (!L.ev_ready)
             {
-              h[size_t(i)] =
-                ((c->mesh.cmask[size_t(i / c->dim)] >> int(i % c->dim)) & 1) ? 0.0 : 1.0 + 0.5 * std::sin(double(i));
-              nrm += h[size_t(i)] * h[size_t(i)];
+              // deterministic start vector with all frequencies (a function of the GLOBAL dof index, so that slabs
+              // agree on their ghost copies): v_i = 1 + 0.5 sin(i) on unconstrained dofs
+              std::vector<double> h((size_t)n, 0.0);
+              const int64_t       g0 = fine ? c->slab.node_offset * c->dim : 0;
+              for (int64_t i = 0; i < n; ++i)
+                h[size_t(i)] =
+                  ((c->mesh.cmask[size_t(i / c->dim)] >> int(i % c->dim)) & 1) ? 0.0 : 1.0 + 0.5 * std::sin(double(i + g0));
+              HIPCHK(c, hipMemcpyAsync(L.ev(), h.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
+              HIPCHK(c, hipStreamSynchronize(c->stream)); // h goes out of scope
+              L.ev_ready = true;
+              its        = mg0.power_its + 1; // the first pass only normalises
             }
-          nrm = std::sqrt(nrm);
-          for (double &x : h)
-            x /= (nrm > 0 ? nrm : 1.0);
-          HIPCHK(c, hipMemcpyAsync(v, h.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream)); // h goes out of scope
-          L.ev_ready = true;
-          its        = mg.power_its;
         }
       double lam = 0.0;
+      int    rc;
+      auto   ev_of = [l](mi_ctx *m) { return m->mg->levels[l].ev(); };
       for (int it = 0; it < its; ++it)
         {
-          enqueue_spmv(c, v, q, nullptr, nullptr, nullptr);
-          mi::launch_vec_scale_mul(w, q, c->work(W_DINV), 1.0, n, c->stream); // w = D^-1 A v
-          mi::launch_masked_norm(c->dim, w, c->d_cmask, n, c->part(5), c->grid_vec, c->d_sc + 14, c->stream);
-          HIPCHK(c, hipMemcpyAsync(c->h_pinned, c->d_sc + 14, sizeof(double), hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
-          lam = std::sqrt(c->h_pinned[0]); // |D^-1 A v| with |v| = 1
-          if (!(lam > 0.0) || !std::isfinite(lam))
-            return fail(c, MI_EINVAL, "multigrid: power iteration broke down on a level with %lld dofs", (long long)n);
-          mi::launch_vec_scale_mul(v, w, nullptr, 1.0 / lam, n, c->stream);
+          if (fine && (rc = team_halo(T, ev_of)))
+            return rc;
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel &L = m->mg->levels[l];
+              mi_ctx  *c = L.ctx;
+              enqueue_spmv(c, L.ev(), L.q(), nullptr, nullptr, nullptr);
+              mi::launch_vec_scale_mul(L.d(), L.q(), c->work(W_DINV), 1.0, c->n, c->stream); // w = D^-1 A v
+              // |w|^2 over the owned dofs -> scalar slot 14 of the slab (level 0) / of the level context
+              const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : c->n;
+              mi::launch_masked_norm(c->dim, L.d() + o0, c->d_cmask + (fine ? m->slab.own_begin : 0), on, c->part(5),
+                                     c->grid_vec, c->d_sc + 14, c->stream);
+            }
+          if (fine && (rc = team_allreduce(T, 14, 1)))
+            return rc;
+          mi_ctx *cr = c0->mg->levels[l].ctx;
+          HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, cr->d_sc + 14, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+          HIPCHK(c0, hipStreamSynchronize(c0->stream));
+          const double nw = std::sqrt(c0->h_pinned[0]); // |D^-1 A v|, equal to lambda once |v| = 1
+          if (!(nw > 0.0) || !std::isfinite(nw))
+            return fail(c0, MI_EINVAL, "multigrid: power iteration broke down on level %d", int(l));
+          lam = nw;
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel &L = m->mg->levels[l];
+              mi::launch_vec_scale_mul(L.ev(), L.d(), nullptr, 1.0 / nw, L.ctx->n, L.ctx->stream);
+            }
         }
-      HIPCHK(c, hipGetLastError());
-      L.lmax = lam * mg.lmax_safety;
+      HIPCHK(c0, hipGetLastError());
+      for (mi_ctx *m : T.members)
+        m->mg->levels[l].lmax = lam * mg0.lmax_safety;
       return MI_OK;
     }
   } // namespace
@@ -228,8 +291,9 @@ namespace mi_detail
     MgLevel L0;
     L0.ctx = c;
     mg->levels.push_back(L0);
-    // level hierarchy over the slab's local box
-    int       p = c->degree, reps[3] = {c->mesh.reps[0], c->mesh.reps[1], c->mesh.reps[2]};
+    // level hierarchy over the UNDECOMPOSED box
+    const mi_mesh_desc &g = c->team->md;
+    int       p = c->degree, reps[3] = {g.reps[0], g.reps[1], g.reps[2]};
     const int dim = c->dim;
     for (int guard = 0; guard < 24; ++guard)
       {
@@ -247,26 +311,21 @@ namespace mi_detail
             if (!changed)
               break;
           }
-        mi_mesh_desc md{};
-        md.dim    = dim;
-        md.degree = p;
+        mi_mesh_desc md = g;
+        md.degree       = p;
         for (int d = 0; d < 3; ++d)
-          {
-            md.reps[d] = d < dim ? reps[d] : 1;
-            md.lo[d]   = c->slab.local_lo[d];
-            md.hi[d]   = c->slab.local_hi[d];
-          }
-        for (int f = 0; f < 6; ++f)
-          md.face_role[f] = c->slab.local_face_role[f];
-        Team *T        = new Team;
-        T->size        = 1;
-        T->device      = c->device;
-        T->dim         = dim;
-        T->stream      = c->stream;
-        T->owns_stream = false;
+          md.reps[d] = d < dim ? reps[d] : 1;
+        md.vertex_perturbation = nullptr;
+        Team *T         = new Team;
+        T->size         = 1;
+        T->device       = c->device;
+        T->dim          = dim;
+        T->stream       = c->stream;
+        T->owns_stream  = false;
+        T->md           = md;
         T->iface_global = mi::global_interface_nodes(dim, p, md.reps, md.face_role);
-        mi_ctx   *lc   = nullptr;
-        const int rc   = create_member(*T, &md, &c->mat, &c->nm, 0, &lc);
+        mi_ctx   *lc    = nullptr;
+        const int rc    = create_member(*T, &md, &c->mat, &c->nm, 0, &lc);
         T->members.push_back(lc);
         if (rc != MI_OK)
           {
@@ -287,7 +346,7 @@ namespace mi_detail
         HIPCHK(c, hipMemsetAsync(L.ws, 0, size_t(5) * size_t(L.ctx->n) * sizeof(double), c->stream));
         if (l + 1 < mg->levels.size())
           {
-            const int rc = build_transfer(L.ctx, mg->levels[l + 1].ctx, L.to_coarse);
+            const int rc = build_transfer(L.ctx, mg->levels[l + 1].ctx, L.to_coarse, l == 0 && c->team->size > 1);
             if (rc)
               return rc;
           }
@@ -296,57 +355,78 @@ namespace mi_detail
     return MI_OK;
   }
 
-  // coarse operators for the current state of the slab: u_total interpolated down the hierarchy, every level
-  // re-assembled, eigenvalue estimates refreshed
-  int mg_update(mi_ctx *c)
+  // coarse operators for the current state: u_total interpolated down the hierarchy (level 1 summed over the
+  // slabs), every level re-assembled (replicated), eigenvalue estimates refreshed
+  int mg_update(Team &T)
   {
-    if (!c->mg || c->mg->levels.size() < 2)
+    mi_ctx *c0 = T.members[0];
+    if (!c0->mg || c0->mg->levels.size() < 2)
       return MI_OK;
-    Multigrid &mg = *c->mg;
-    int        rc;
-    // level 0: u_total = u + du into the workspace, then down
-    MgLevel &L0 = mg.levels[0];
-    HIPCHK(c, hipMemcpyAsync(L0.x(), c->vec(MI_V_TOTAL_DISPLACEMENT), size_t(c->n) * sizeof(double),
-                             hipMemcpyDeviceToDevice, c->stream));
-    mi::launch_vec_add(L0.x(), c->vec(MI_V_SOLUTION_DELTA), c->n, c->stream);
-    const double *src = L0.x();
-    for (size_t l = 0; l + 1 < mg.levels.size(); ++l)
+    const size_t nl = c0->mg->levels.size();
+    int          rc;
+    for (mi_ctx *m : T.members)
       {
-        MgLevel &F = mg.levels[l], &C = mg.levels[l + 1];
-        mi::launch_lattice_interp(c->dim, false, F.to_coarse.state, C.ctx->vec(MI_V_TOTAL_DISPLACEMENT), src,
-                                  C.ctx->d_cmask, c->stream);
-        if ((rc = enqueue_assembly(C.ctx)))
-          {
-            c->err = C.ctx->err;
-            return rc;
-          }
-        src = C.ctx->vec(MI_V_TOTAL_DISPLACEMENT);
+        Multigrid &mg = *m->mg;
+        MgLevel   &L0 = mg.levels[0], &L1 = mg.levels[1];
+        // u_total = u + du of the slab, then the (ownership-masked) state transfer to level 1
+        HIPCHK(m, hipMemcpyAsync(L0.x(), m->vec(MI_V_TOTAL_DISPLACEMENT), size_t(m->n) * sizeof(double),
+                                 hipMemcpyDeviceToDevice, m->stream));
+        mi::launch_vec_add(L0.x(), m->vec(MI_V_SOLUTION_DELTA), m->n, m->stream);
+        mi::launch_lattice_interp(m->dim, false, L0.to_coarse.state, L1.ctx->vec(MI_V_TOTAL_DISPLACEMENT), L0.x(),
+                                  L1.ctx->d_cmask, m->stream);
       }
-    HIPCHK(c, hipGetLastError());
-    for (MgLevel &L : mg.levels)
-      if ((rc = estimate_lmax(mg, L)))
-        {
-          c->err = L.ctx->err;
-          return rc;
-        }
-    c->mg_stale = false;
+    if ((rc = team_allreduce_vectors(
+           T, [](mi_ctx *m) { return m->mg->levels[1].ctx->vec(MI_V_TOTAL_DISPLACEMENT); },
+           size_t(c0->mg->levels[1].ctx->n))))
+      return rc;
+    for (mi_ctx *m : T.members)
+      {
+        Multigrid &mg = *m->mg;
+        for (size_t l = 1; l < nl; ++l)
+          {
+            MgLevel &C = mg.levels[l];
+            if (l > 1)
+              mi::launch_lattice_interp(m->dim, false, mg.levels[l - 1].to_coarse.state,
+                                        C.ctx->vec(MI_V_TOTAL_DISPLACEMENT),
+                                        mg.levels[l - 1].ctx->vec(MI_V_TOTAL_DISPLACEMENT), C.ctx->d_cmask, m->stream);
+            if ((rc = enqueue_assembly(C.ctx)))
+              return fail(c0, rc, "multigrid level %d: %s", int(l), C.ctx->err.c_str());
+          }
+      }
+    HIPCHK(c0, hipGetLastError());
+    for (size_t l = 0; l < nl; ++l)
+      if ((rc = estimate_lmax(T, l)))
+        return rc;
+    for (mi_ctx *m : T.members)
+      m->mg_stale = false;
     return MI_OK;
   }
 
   namespace
   {
-    // k Chebyshev-Jacobi steps on level L for A x = b over [lmax/ratio, lmax]; zero_start: x = 0 on entry
-    void chebyshev(MgLevel &L, int k, double ratio, bool zero_start)
+    // k Chebyshev-Jacobi steps on level l for A x = b over [lmax/ratio, lmax]; zero_start: x = 0 on entry.
+    // Level 0 runs on all slabs in lockstep (halo exchange of x before every SpMV, update on the owned dofs).
+    int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start)
     {
-      mi_ctx      *c = L.ctx;
-      const double b = L.lmax, a = L.lmax / ratio;
+      const bool   fine = (l == 0);
+      const double b = T.members[0]->mg->levels[l].lmax, a = b / ratio;
       const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
       double       rho_old = 1.0 / sigma;
+      auto         x_of    = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
+      int          rc;
       for (int j = 0; j < k; ++j)
         {
-          const bool first = (j == 0);
-          if (!(first && zero_start))
-            enqueue_spmv(c, L.x(), L.q(), nullptr, nullptr, nullptr);
+          const bool first = (j == 0), skip_spmv = first && zero_start;
+          if (!skip_spmv)
+            {
+              if (fine && (rc = team_halo(T, x_of)))
+                return rc;
+              for (mi_ctx *m : T.members)
+                {
+                  MgLevel &L = m->mg->levels[l];
+                  enqueue_spmv(L.ctx, L.x(), L.q(), nullptr, nullptr, nullptr);
+                }
+            }
           double c1, c2;
           if (first)
             {
@@ -360,39 +440,69 @@ namespace mi_detail
               c2               = 2.0 * rho / delta;
               rho_old          = rho;
             }
-          mi::launch_cheb_step(L.x(), L.d(), L.b(), (first && zero_start) ? nullptr : L.q(), c->work(W_DINV), c1, c2, c->n,
-                               c->stream);
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel      &L  = m->mg->levels[l];
+              const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : L.ctx->n;
+              mi::launch_cheb_step(L.x() + o0, L.d() + o0, L.b() + o0, skip_spmv ? nullptr : L.q() + o0,
+                                   L.ctx->work(W_DINV) + o0, c1, c2, on, L.ctx->stream);
+            }
         }
+      return MI_OK;
     }
 
-    void vcycle(Multigrid &mg, size_t l)
+    int vcycle(Team &T, size_t l)
     {
-      MgLevel &L = mg.levels[l];
-      mi_ctx  *c = L.ctx;
-      if (l + 1 == mg.levels.size())
+      mi_ctx      *c0  = T.members[0];
+      Multigrid   &mg0 = *c0->mg;
+      const size_t nl  = mg0.levels.size();
+      const bool   fine = (l == 0);
+      int          rc;
+      if (l + 1 == nl)
+        return chebyshev(T, l, mg0.coarse_degree, mg0.coarse_ratio, true);
+      if ((rc = chebyshev(T, l, mg0.nu, mg0.smooth_ratio, true)))
+        return rc;
+      auto x_of = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
+      if (fine && (rc = team_halo(T, x_of)))
+        return rc;
+      for (mi_ctx *m : T.members)
         {
-          chebyshev(L, mg.coarse_degree, mg.coarse_ratio, true);
-          return;
+          MgLevel      &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
+          const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : L.ctx->n;
+          enqueue_spmv(L.ctx, L.x(), L.q(), nullptr, nullptr, nullptr);
+          mi::launch_vec_residual(L.q() + o0, L.b() + o0, L.q() + o0, on, L.ctx->stream); // q = b - A x (owned)
+          // restriction over the owned fine planes only: partial sums on a decomposed fine level
+          mi::launch_lattice_restrict(L.ctx->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, L.ctx->stream);
         }
-      MgLevel &C = mg.levels[l + 1];
-      chebyshev(L, mg.nu, mg.smooth_ratio, true);
-      enqueue_spmv(c, L.x(), L.q(), nullptr, nullptr, nullptr);
-      mi::launch_vec_residual(L.q(), L.b(), L.q(), c->n, c->stream); // q = b - A x
-      mi::launch_lattice_restrict(c->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, c->stream);
-      vcycle(mg, l + 1);
-      mi::launch_lattice_interp(c->dim, true, L.to_coarse.prolong, L.x(), C.x(), c->d_cmask, c->stream);
-      chebyshev(L, mg.nu, mg.smooth_ratio, false);
+      if (fine && (rc = team_allreduce_vectors(
+                     T, [l](mi_ctx *m) { return m->mg->levels[l + 1].b(); }, size_t(mg0.levels[l + 1].ctx->n))))
+        return rc;
+      if ((rc = vcycle(T, l + 1)))
+        return rc;
+      for (mi_ctx *m : T.members)
+        {
+          MgLevel &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
+          mi::launch_lattice_interp(L.ctx->dim, true, L.to_coarse.prolong, L.x(), C.x(), L.ctx->d_cmask, L.ctx->stream);
+        }
+      return chebyshev(T, l, mg0.nu, mg0.smooth_ratio, false);
     }
   } // namespace
 
-  int mg_apply(mi_ctx *c, const double *r, double *z)
+  // W_Z = V-cycle(W_R) on every slab (owned residual in, correction out)
+  int mg_apply(Team &T)
   {
-    Multigrid &mg = *c->mg;
-    MgLevel   &L0 = mg.levels[0];
-    mi::launch_copy_owned(L0.b(), r, c->n, c->own0, c->own_n, c->stream);
-    vcycle(mg, 0);
-    HIPCHK(c, hipMemcpyAsync(z, L0.x(), size_t(c->n) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    HIPCHK(c, hipGetLastError());
+    for (mi_ctx *m : T.members)
+      {
+        MgLevel &L0 = m->mg->levels[0];
+        mi::launch_copy_owned(L0.b(), m->work(W_R), m->n, m->own0, m->own_n, m->stream);
+      }
+    int rc = vcycle(T, 0);
+    if (rc)
+      return rc;
+    for (mi_ctx *m : T.members)
+      HIPCHK(m, hipMemcpyAsync(m->work(W_Z), m->mg->levels[0].x(), size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
+                               m->stream));
+    HIPCHK(T.members[0], hipGetLastError());
     return MI_OK;
   }
 } // namespace mi_detail
