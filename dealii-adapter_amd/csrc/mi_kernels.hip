@@ -75,7 +75,7 @@ namespace mi
   };
 
   constexpr int RQ = 32; // doubles per quadrature-point record in LDS
-  constexpr int RN = 10; // doubles per (qp,node) record: g[3], m[3], v[3], n
+  constexpr int RN = 10; // doubles per (qp,node) record: g[3], m[3], t[3] = tau g, n
   // quadrature-point record layout
   constexpr int Q_M    = 0;  // 9: Jinv * Finv  (unit gradient -> spatial gradient)
   constexpr int Q_TAU  = 9;  // 6: tau      xx yy zz xy xz yz
@@ -419,13 +419,12 @@ namespace mi
             double *o = &s_nd[(qq * NPCP + a) * RN];
             sym_mul(&r[Q_TISO], g, t);
             sym_mul(&r[Q_TAU], g, v);
-            const double cs2 = r[Q_CS2];
 #pragma unroll
             for (int j = 0; j < 3; ++j)
               {
                 o[j]     = g[j];
                 o[3 + j] = (-2.0 / DIM) * t[j];
-                o[6 + j] = cs2 * g[j] + v[j];
+                o[6 + j] = v[j]; // tau g_a itself: the residual then is exactly zero for a stress-free state
               }
             o[9] = r[Q_SQN] * N;
           }
@@ -437,7 +436,7 @@ namespace mi
             for (int qq = qslot; qq < QC; qq += QSPLIT)
               {
                 const double *r    = &s_qp[(chunk * QC + qq) * RQ];
-                const double  w    = r[Q_W], wcII = r[Q_WCII], wcs2 = w * r[Q_CS2];
+                const double  w    = r[Q_W], wcII = r[Q_WCII], cs2 = r[Q_CS2], wcs2 = w * cs2;
                 const double *nd   = &s_nd[qq * NPCP * RN];
                 double        ha[2][3], gw[2][3], gc[2][3], na[2];
 #pragma unroll
@@ -464,7 +463,7 @@ namespace mi
                       {
                         gb[j] = pb[j];
                         mb[j] = pb[3 + j];
-                        vb[j] = pb[6 + j];
+                        vb[j] = cs2 * pb[j] + pb[6 + j]; // v_b = (c_S/2) g_b + tau g_b
                       }
                     const double nb = pb[9];
 #pragma unroll
@@ -494,8 +493,7 @@ namespace mi
               {
                 const double *r  = &s_qp[(chunk * QC + qq) * RQ];
                 const double *pa = &s_nd[(qq * NPCP + a) * RN];
-                const double  tg = pa[6 + i] - r[Q_CS2] * pa[i]; // (tau g_a)_i
-                rres -= r[Q_W] * tg + (pa[9] * r[Q_NINV]) * r[Q_FACC + i];
+                rres -= r[Q_W] * pa[6 + i] + (pa[9] * r[Q_NINV]) * r[Q_FACC + i]; // w (tau g_a)_i + N_a rho w (acc - b)_i
               }
           }
         __syncthreads();

@@ -1,0 +1,123 @@
+"""GPU tests of edge cases and of size-independent properties at a BASELINE configuration size (config 3: 34^3 Q2
+cells, 985,527 DoFs), where the CPU oracle would take too long to be the checker:
+symmetry and linearity of the assembled operator through the SpMV kernel, the solved system's true residual,
+invariance of assembly and SpMV under the slab decomposition, bitwise repeatability.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg
+
+M = load_pkg()
+pytestmark = pytest.mark.gpu
+
+
+def test_zero_load_step_follows_reference_escape_hatches():
+    """no traction, zero state: residual 0 -> the Newton loop ends through the absolute escape hatches
+    (nonlinear_elasticity.cc:459-463) after one (trivial) linear solve, for both preconditioners"""
+    for precond in (0, 1):
+        G = M.Context(dim=3, degree=2, reps=(3, 2, 2), hi=(0.3, 0.2, 0.2))
+        G.set_tuning("precond", precond)
+        rc, info = G.newmark_step()
+        assert rc == 0 and info.converged == 1
+        assert info.newton_iterations == 1 and info.assemblies == 2 and info.lin_its_total == 0
+        assert info.res_abs == 0.0 and np.all(G.get(M.V_U) == 0.0)
+
+
+def test_mesh_without_interface_and_single_cell():
+    roles = [O.FACE_CLAMPED, 0, 0, 0, 0, 0]
+    G = M.Context(dim=3, degree=1, reps=(2, 2, 2), face_role=roles, body_force=(0.0, -9.81, 0.0))
+    P = O.Problem(O.make_desc(dim=3, degree=1, reps=(2, 2, 2), face_role=roles, body_force=(0.0, -9.81, 0.0)))
+    ids, xyz = G.interface()
+    assert len(ids) == 0 and xyz.shape == (0, 3)
+    G.set_interface_traction(np.zeros((0, 3)))
+    assert G.get_interface_displacement().shape == (0, 3)
+    rc, info = G.newmark_step(tol_lin=1e-12)  # driven by the body force only
+    rc_o, _ = P.newmark_step(O.SOLVER_DIRECT)
+    assert rc == 0 and rc_o == 0
+    assert np.abs(G.get(M.V_U) - P.vec(O.V_U)).max() / np.abs(P.vec(O.V_U)).max() < 1e-8
+    # one cell, highest supported degrees
+    for dim, p in ((2, 4), (3, 2)):
+        G1 = M.Context(dim=dim, degree=p, reps=(1,) * dim, hi=(0.1,) * dim)
+        P1 = O.Problem(O.make_desc(dim=dim, degree=p, reps=(1,) * dim, hi=(0.1,) * dim))
+        t = (0.0, -500.0, 0.0)[:dim]
+        G1.set_interface_traction(t)
+        P1.set_interface_traction(t)
+        assert G1.newmark_step(tol_lin=1e-12, max_it_mult=3.0)[0] == 0 and P1.newmark_step(O.SOLVER_DIRECT)[0] == 0
+        assert np.abs(G1.get(M.V_U) - P1.vec(O.V_U)).max() / np.abs(P1.vec(O.V_U)).max() < 1e-8
+
+
+@pytest.fixture(scope="module")
+def config3():
+    n = 34
+    G = M.Context(dim=3, degree=2, reps=(n, n, n))
+    assert G.n == 985527 and G.nnz == 183117753  # SURVEY.md section 8 size table
+    rng = np.random.default_rng(1234)
+    free = ~G.constrained
+    G.set(M.V_U, 0.02 / (2 * n) * rng.standard_normal(G.n) * free)
+    G.set(M.V_V_OLD, 0.1 * rng.standard_normal(G.n))
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    G.update_acceleration()
+    G.assemble()
+    return G
+
+
+def test_fullsize_operator_symmetry_and_linearity(config3):
+    G = config3
+    rng = np.random.default_rng(4321)
+    x, y = rng.standard_normal(G.n), rng.standard_normal(G.n)
+    Kx, Ky = G.spmv(x), G.spmv(y)
+    assert abs(y @ Kx - x @ Ky) / abs(y @ Kx) < 1e-11  # symmetric tangent (mirrored lower triangle, :1033-1035)
+    Kz = G.spmv(2.5 * x - 0.75 * y)
+    assert np.abs(Kz - (2.5 * Kx - 0.75 * Ky)).max() / np.abs(Kz).max() < 1e-12
+    cons = G.constrained
+    e = np.zeros(G.n)
+    e[cons] = rng.standard_normal(cons.sum())
+    Ke = G.spmv(e)
+    assert np.all(Ke[~cons] == 0.0) and np.all(Ke[cons] * e[cons] > 0)  # constrained rows: positive diagonal only
+    # block-CSR cross-check kernel on the same matrix
+    G.set_tuning("spmv_variant", 1)
+    assert np.abs(G.spmv(x) - Kx).max() / np.abs(Kx).max() < 1e-13
+    G.set_tuning("spmv_variant", 3)
+
+
+def test_fullsize_solve_true_residual_and_preconditioners_agree(config3):
+    G = config3
+    b = G.get(M.V_RHS)
+    sols = {}
+    for precond in (1, 0):
+        G.set_tuning("precond", precond)
+        G.set(M.V_NEWTON, np.zeros(G.n))
+        rc, its, res = G.cg_solve(rel_tol=1e-9)
+        assert rc == 0
+        x = G.get(M.V_NEWTON)
+        true_res = np.linalg.norm(b - G.spmv(x))
+        assert true_res <= 1.5e-9 * np.linalg.norm(b)  # recursion residual == true residual
+        assert abs(true_res - res) / res < 1e-3
+        sols[precond] = (x, its)
+    assert np.abs(sols[1][0] - sols[0][0]).max() / np.abs(sols[0][0]).max() < 1e-6
+    assert sols[1][1] * 8 < sols[0][1]  # multigrid: mesh-independent iteration count
+    G.set_tuning("precond", 1)
+
+
+def test_fullsize_decomposition_invariance(config3):
+    """4 slabs reproduce the single-slab residual vector and operator action at 1M DoFs"""
+    G = config3
+    n = 34
+    G4 = M.Context(dim=3, degree=2, reps=(n, n, n), slabs=4)
+    for k in (M.V_U, M.V_V_OLD):
+        G4.set(k, G.get(k))
+    G4.set_interface_traction((0.0, -2e3, 0.0))
+    G4.update_acceleration()
+    rn4 = G4.assemble()
+    r1, r4 = G.get(M.V_RHS), G4.get(M.V_RHS)
+    assert np.abs(r4 - r1).max() / np.abs(r1).max() < 1e-12
+    assert abs(rn4 - np.linalg.norm(r1[~G.constrained])) / rn4 < 1e-12
+    x = np.random.default_rng(5).standard_normal(G.n)
+    assert np.abs(G4.spmv(x) - G.spmv(x)).max() / np.abs(G.spmv(x)).max() < 1e-13
+    rc, its4, _ = G4.cg_solve(rel_tol=1e-8)
+    G.set(M.V_NEWTON, np.zeros(G.n))
+    rc1, its1, _ = G.cg_solve(rel_tol=1e-8)
+    assert rc == 0 and rc1 == 0 and abs(its4 - its1) <= 1
+    assert np.abs(G4.get(M.V_NEWTON) - G.get(M.V_NEWTON)).max() / np.abs(G.get(M.V_NEWTON)).max() < 1e-6
