@@ -71,7 +71,7 @@ def cpu_baseline(n_cells_side, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=59, help="cells per side of the Q2 block (59 -> 5,055,477 DoFs)")
     ap.add_argument("--tol-lin", type=float, default=1e-6)

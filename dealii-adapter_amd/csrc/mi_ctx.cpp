@@ -303,7 +303,7 @@ namespace mi_detail
   int enqueue_assembly(mi_ctx *c)
   {
     const int64_t dd = int64_t(c->dim) * c->dim;
-    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, size_t(c->mesh.nnzb) * dd * sizeof(double), c->stream)); // :1054
+    (void)dd; // tangent_matrix = 0 (:1054) is implied: the first cell that touches a block stores instead of adding
     HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SYSTEM_RHS), 0, size_t(c->n) * sizeof(double), c->stream)); // :1055
     mi::AsmParams p  = asm_params(c);
     mi_ctx       *c0 = c->team->members[0];

@@ -239,7 +239,8 @@ namespace mi
   //   phase A: per-QP kinematics/material records -> LDS (4 lanes per QP)
   //   per chunk of QC points: phase B (qp,node) records g, m, v, n -> LDS; main loop; residual
   //   epilogue: read-modify-write of the cell's blocks into the global block-CSR (colouring => race free)
-  template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1>
+  // ABL (timing only, results wrong): 1 = no tangent scatter, 2 = no main loop and no scatter, 3 = scatter only
+  template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1, int ABL = 0>
   __global__ __launch_bounds__(NT, MINW) void assemble_cells(AsmParams prm)
   {
     using E = Elem<DIM, P>;
@@ -431,7 +432,7 @@ namespace mi
         __syncthreads();
 
         // ---- main loop: accumulate the 2x2 tile over this lane's share of the chunk
-        if (active)
+        if (active && ABL != 2 && ABL != 3)
           {
             for (int qq = qslot; qq < QC; qq += QSPLIT)
               {
@@ -520,7 +521,15 @@ namespace mi
     // ---- tangent scatter: lane `qslot` of a tile writes the blocks bl with bl % QSPLIT == qslot.
     // [DEAL.II distribute_local_to_global] constrained rows/cols are dropped, the diagonal of a constrained
     // dof receives |K_e(i,i)|.
-    if (active)
+    if (ABL == 2 || ABL == 3)
+      {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int k = 0; k < DD; ++k)
+            asm volatile("" ::"v"(K[b][k]));
+      }
+    if (active && ABL != 1 && ABL != 2)
       {
         const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
 #pragma unroll
@@ -533,8 +542,12 @@ namespace mi
               continue;
             const int32_t A = s_conn[a], B = s_conn[b];
             const int     ma = prm.cmask[A], mb = prm.cmask[B];
-            double *__restrict__ pab = prm.vals + (int64_t(prm.rowptr[A]) + offc[a * NPC + b]) * DD;
-            double *__restrict__ pba = prm.vals + (int64_t(prm.rowptr[B]) + offc[b * NPC + a]) * DD;
+            const uint16_t oab = offc[a * NPC + b], oba = offc[b * NPC + a];
+            double *__restrict__ pab = prm.vals + (int64_t(prm.rowptr[A]) + (oab & 0x7fff)) * DD;
+            double *__restrict__ pba = prm.vals + (int64_t(prm.rowptr[B]) + (oba & 0x7fff)) * DD;
+            // bit 15: first touch of the block in processing order -> plain store instead of read-modify-write
+            const bool first_ab = oab >> 15, first_ba = oba >> 15;
+            double     vab[DD], vba[DD];
 #pragma unroll
             for (int i = 0; i < DIM; ++i)
 #pragma unroll
@@ -543,10 +556,26 @@ namespace mi
                   double v = K[bl][i * DIM + j];
                   if (((ma >> i) | (mb >> j)) & 1)
                     v = (a == b && i == j) ? fabs(v) : 0.0;
-                  pab[i * DIM + j] += v;
-                  if (a != b)
-                    pba[j * DIM + i] += v;
+                  vab[i * DIM + j] = v;
+                  vba[j * DIM + i] = v;
                 }
+            if (!first_ab)
+#pragma unroll
+              for (int k = 0; k < DD; ++k)
+                vab[k] += pab[k];
+#pragma unroll
+            for (int k = 0; k < DD; ++k)
+              pab[k] = vab[k];
+            if (a != b)
+              {
+                if (!first_ba)
+#pragma unroll
+                  for (int k = 0; k < DD; ++k)
+                    vba[k] += pba[k];
+#pragma unroll
+                for (int k = 0; k < DD; ++k)
+                  pba[k] = vba[k];
+              }
           }
       }
   }
@@ -1499,10 +1528,10 @@ namespace mi
   }
 
   // ------------------------------------------------------------------ launchers
-  template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1>
+  template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1, int ABL = 0>
   static void launch_asm(const AsmParams &p, hipStream_t s)
   {
-    hipLaunchKernelGGL((assemble_cells<DIM, P, QSPLIT, NT, QC, MINW>), dim3(p.cell_count), dim3(NT), 0, s, p);
+    hipLaunchKernelGGL((assemble_cells<DIM, P, QSPLIT, NT, QC, MINW, ABL>), dim3(p.cell_count), dim3(NT), 0, s, p);
   }
 
   int launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s)
@@ -1520,6 +1549,15 @@ namespace mi
               break;
             case 2:
               launch_asm<3, 2, 2, 256, 4>(p, s); // 27 kB LDS: no faster than QC = 8 (register limited)
+              break;
+            case 6:
+              launch_asm<3, 2, 2, 256, 8, 1, 1>(p, s); // timing only: no tangent scatter
+              break;
+            case 7:
+              launch_asm<3, 2, 2, 256, 8, 1, 2>(p, s); // timing only: phases A/B + residual
+              break;
+            case 8:
+              launch_asm<3, 2, 2, 256, 8, 1, 3>(p, s); // timing only: phases A/B + residual + scatter
               break;
             default:
               launch_asm<3, 2, 2, 256, 8>(p, s); // 36 kB LDS, 3 workgroups per CU: 19.5 ms

@@ -222,7 +222,7 @@ int mi_linear_setup(mi_ctx *c, double theta)
           const int32_t A = m.conn[size_t(cell) * npc + a];
           for (int b = 0; b < npc; ++b)
             {
-              const size_t blk = size_t(m.rowptr[size_t(A)]) + off[a * npc + b];
+              const size_t blk = size_t(m.rowptr[size_t(A)]) + (off[a * npc + b] & 0x7fff); // bit 15 is the first-touch flag
               for (int ci = 0; ci < dim; ++ci)
                 {
                   for (int cj = 0; cj < dim; ++cj)

@@ -290,7 +290,8 @@ namespace mi
     std::vector<int32_t>  rowptr;       // [nnodes+1] block rows
     std::vector<int32_t>  colidx;       // [nnzb]
     std::vector<int32_t>  diagpos;      // [nnodes] block index of (node,node)
-    std::vector<uint16_t> off;          // [ncells][npc][npc]: column slot of node b in block row of node a
+    std::vector<uint16_t> off;          // [ncells][npc][npc]: column slot of node b in block row of node a (bits 0-14);
+                                        // bit 15: this cell is the FIRST (in processing order) to touch that block
     std::vector<uint8_t>  cmask;        // [nnodes] bit c set: dof (node,c) is Dirichlet-constrained
     std::vector<int32_t>  iface_nodes;  // ascending
     std::vector<InterfaceFace> iface_faces;         // sorted by colour
@@ -411,8 +412,8 @@ namespace mi
               couple_range(d, ni[d], a, b);
               cnt *= (b - a + 1);
             }
-          if (cnt > 65535)
-            throw std::invalid_argument("row too long for uint16 scatter offsets");
+          if (cnt > 32767)
+            throw std::invalid_argument("row too long for 15-bit scatter offsets");
           rowptr[size_t(n) + 1] = int32_t(cnt);
         }
       {
@@ -542,6 +543,27 @@ namespace mi
           if (iface_mask)
             faces_by_colour[colour_of_pos[size_t(pos)]].push_back({int32_t(pos), int32_t(iface_mask)});
         }
+      // first-touch flags: cells are processed colour by colour in this (colour-sorted) order and two cells of one
+      // colour never share a block, so the first cell in this order that contains a block may WRITE it; all later
+      // ones add to it.  Every pattern block is touched at least once, so the value array needs no zero fill.
+      {
+        std::vector<uint8_t> touched((size_t)nnzb, 0);
+        for (int64_t pos = 0; pos < ncells; ++pos)
+          {
+            const int32_t *cn = &conn[size_t(pos) * npc];
+            uint16_t      *co = &off[size_t(pos) * npc * npc];
+            for (int a = 0; a < npc; ++a)
+              for (int b = 0; b < npc; ++b)
+                {
+                  const size_t blk = size_t(rowptr[size_t(cn[a])]) + co[a * npc + b];
+                  if (!touched[blk])
+                    {
+                      touched[blk] = 1;
+                      co[a * npc + b] |= uint16_t(0x8000);
+                    }
+                }
+          }
+      }
       iface_nodes.clear();
       for (int64_t n = 0; n < nnodes; ++n)
         if (on_iface[size_t(n)])
