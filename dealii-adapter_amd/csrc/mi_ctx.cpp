@@ -1047,7 +1047,24 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
       m->active_dinv      = nullptr;
     }
   // warm start: SolverCG starts from the passed vector (:1184-1187)
-  return cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res);
+  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res);
+  if (rc == MI_ENOCONV_LIN && mg_active(c))
+    {
+      // safety net: should the V-cycle ever stall (e.g. an eigenvalue bound gone stale under a violent state
+      // change), continue from the current iterate with the Jacobi preconditioner instead of giving up
+      const int done_its = its ? *its : 0;
+      for (mi_ctx *m : c->team->members)
+        m->precond = 0;
+      rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res);
+      for (mi_ctx *m : c->team->members)
+        {
+          m->precond  = 1;
+          m->mg_force = true; // rebuild the hierarchy before it is used again
+        }
+      if (its)
+        *its += done_its;
+    }
+  return rc;
 }
 
 int mi_apply_newton_update(mi_ctx *c, double *upd_norm)

@@ -26,7 +26,23 @@ namespace Nonlinear_Elasticity
   }
 
   template <int dim>
-  Solid<dim>::~Solid() = default;
+  Solid<dim>::~Solid()
+  {
+    // device-side companion of the TimerOutput table (HIP events on the solver's stream), MI_PROFILE=1
+    if (device && std::getenv("MI_PROFILE"))
+      {
+        mi_timings t{};
+        if (mi_get_timings(device->ctx(), &t) == MI_OK)
+          {
+            static const char *names[MI_T_COUNT] = {"assemble cells", "assemble total", "SpMV (CG)", "CG vector kernels",
+                                                    "CG total",       "Newmark",        "step (host wall)"};
+            std::cout << "\nDevice timings (ms, launches):" << std::endl;
+            for (int i = 0; i < MI_T_COUNT; ++i)
+              std::cout << "  " << std::left << std::setw(20) << names[i] << std::right << std::setw(12) << std::fixed
+                        << std::setprecision(3) << t.ms[i] << std::setw(10) << t.count[i] << std::endl;
+          }
+      }
+  }
 
   // time loop of nonlinear_elasticity.cc:99-167
   template <int dim>
@@ -56,6 +72,7 @@ namespace Nonlinear_Elasticity
         solve_nonlinear_timestep();
         // total_displacement += solution_delta; update_acceleration/velocity/old_variables (:139-144)
         device->check(mi_newmark_finish_step(device->ctx()), "mi_newmark_finish_step");
+        log_step_json();
 
         timer.enter_subsection("Advance adapter");
         adapter.advance(total_displacement, time.get_delta_t());
@@ -170,6 +187,8 @@ namespace Nonlinear_Elasticity
     if (const char *e = std::getenv("MI_DEVICE"))
       dev_id = std::atoi(e);
     device = std::make_unique<mi::Device>(mesh_desc, mat, nm, dev_id);
+    if (std::getenv("MI_PROFILE"))
+      mi_set_profiling(device->ctx(), 1);
 
     std::cout << "Triangulation:"
               << "\n\t Number of active cells: " << mi_n_cells(device->ctx())
@@ -214,6 +233,7 @@ namespace Nonlinear_Elasticity
     const double tol_lin = direct ? 1e-12 : parameters.tol_lin;
     const double it_mult = direct ? std::max(10.0, parameters.max_iterations_lin) : parameters.max_iterations_lin;
 
+    last_newton_iterations = last_lin_iterations = 0;
     unsigned int newton_iteration = 0;
     for (; newton_iteration < parameters.max_iterations_NR; ++newton_iteration)
       {
@@ -248,6 +268,8 @@ namespace Nonlinear_Elasticity
         const int rc = mi_cg_solve(ctx, tol_lin, static_cast<int64_t>(double(mi_n_dofs(ctx)) * it_mult), &lin_it, &lin_res);
         timer.leave_subsection();
         device->check(rc, "mi_cg_solve"); // SolverControl::NoConvergence
+        ++last_newton_iterations;
+        last_lin_iterations += static_cast<unsigned int>(lin_it);
 
         device->check(mi_apply_newton_update(ctx, &error_update.u), "mi_apply_newton_update"); // :476-487
         if (newton_iteration == 0)
@@ -292,6 +314,18 @@ namespace Nonlinear_Elasticity
               << "Displacement:\t" << error_update.u << std::endl
               << "Residual: \t" << error_residual.u << std::endl
               << "v / V_0:\t" << vol_current << " / " << vol_reference << std::endl;
+  }
+
+  template <int dim>
+  void Solid<dim>::log_step_json() const
+  {
+    std::ofstream out(parameters.output_folder + "/steps.jsonl", std::ios::app);
+    if (!out)
+      return;
+    out << std::setprecision(17) << "{\"timestep\": " << time.get_timestep() << ", \"time\": " << time.current()
+        << ", \"newton_iterations\": " << last_newton_iterations << ", \"linear_iterations\": " << last_lin_iterations
+        << ", \"residual_abs\": " << error_residual.u << ", \"update_abs\": " << error_update.u
+        << ", \"n_dofs\": " << mi_n_dofs(device->ctx()) << "}\n";
   }
 
   // :1215-1254: solution-XXX.vtk with index timestep / output_interval

@@ -72,5 +72,9 @@ namespace Nonlinear_Elasticity
       }
     };
     Errors error_residual, error_residual_0, error_residual_norm, error_update, error_update_0, error_update_norm;
+
+    // machine-readable companion of the Newton table: one JSON line per solved step in <Output folder>/steps.jsonl
+    unsigned int last_newton_iterations = 0, last_lin_iterations = 0;
+    void         log_step_json() const;
   };
 } // namespace Nonlinear_Elasticity

@@ -83,6 +83,11 @@ def test_executable_nonlinear_explicit_2d(tmp_path):
     for section in ("Setup system", "Assemble linear system", "Linear solver", "Advance adapter", "Output results"):
         assert section in stdout
     assert os.path.exists(tmp_path / "out" / "solution-000.vtk")
+    # machine-readable step log next to the Newton table
+    import json
+    steps = [json.loads(l) for l in open(tmp_path / "out" / "steps.jsonl")]
+    assert [s["timestep"] for s in steps] == [1, 2, 3, 4] and all(s["newton_iterations"] >= 1 for s in steps)
+    assert steps[0]["n_dofs"] == P.n and all(s["linear_iterations"] >= s["newton_iterations"] for s in steps)
 
 
 def test_executable_nonlinear_implicit_checkpointing(tmp_path):
