@@ -128,6 +128,40 @@ def test_executable_nonlinear_3d(tmp_path, name, windows, traction):
         assert rc == 0
         exp.append(((k + 1) * dt, P.vec(O.V_U).reshape(-1, 3)[ids].copy()))
     _check_rows(rows, exp, 3)
+    if name == "block_neo_3d_q2":
+        _check_vtk(tmp_path / "out" / "solution-000.vtk", P, zero=True)
+        _check_vtk(tmp_path / "out" / "solution-001.vtk", P, zero=False)  # timestep 2 / Output interval 2
+
+
+def _check_vtk(path, P, zero):
+    """patch-wise VTK with displacement + strain_ij scalars (postprocessor.h:46-111)"""
+    txt = open(path).read().split("\n")
+    npc, ncells = 27, P.ncells
+    i = next(k for k, l in enumerate(txt) if l.startswith("POINTS"))
+    npts = int(txt[i].split()[1])
+    assert npts == ncells * npc
+    pts = np.array([l.split() for l in txt[i + 1:i + 1 + npts]], dtype=float)
+    j = next(k for k, l in enumerate(txt) if l.startswith("VECTORS displacement"))
+    disp = np.array([l.split() for l in txt[j + 1:j + 1 + npts]], dtype=float)
+    fields = {}
+    for k, l in enumerate(txt):
+        if l.startswith("SCALARS strain_"):
+            fields[l.split()[1]] = np.array(txt[k + 2:k + 2 + npts], dtype=float)
+    assert sorted(fields) == sorted("strain_" + a + b for a in "xyz" for b in "xyz")
+    if zero:
+        assert np.all(disp == 0) and all(np.all(f == 0) for f in fields.values())
+        return
+    # points are the displaced support points; displacement matches the oracle node by reference coordinate
+    ref = pts - disp
+    X, U = P.coords, P.vec(O.V_U).reshape(-1, 3)
+    key = {tuple(np.round(x, 7) + 0.0): k for k, x in enumerate(X)}
+    idx = np.array([key[tuple(np.round(x, 7) + 0.0)] for x in ref])
+    assert np.abs(disp - U[idx]).max() / np.abs(U).max() < 1e-7  # 12 significant digits in the ASCII file
+    for a in "xyz":
+        for b in "xyz":
+            assert np.array_equal(fields["strain_" + a + b], fields["strain_" + b + a])
+    # small strains: trace of the strain ~ relative volume change, bounded by |grad u|
+    assert 0 < np.abs(fields["strain_yy"]).max() < 0.1
 
 
 def _linear_pair(desc):
