@@ -118,6 +118,9 @@ def lib():
         L.mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.mi_partition_describe.restype = C.c_int
         L.mi_partition_describe.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(PartitionInfo)]
+        L.mi_partition_spmv_rows.restype = C.c_int
+        L.mi_partition_spmv_rows.argtypes = [C.POINTER(MeshDesc), C.c_int, C.c_int, C.POINTER(C.c_int64),
+                                             C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64]
         L.mi_comm_unique_id.restype = C.c_int
         L.mi_comm_unique_id.argtypes = [C.c_void_p]
         L.mi_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
@@ -164,6 +167,20 @@ def partition_describe(md, rank, size):
     if rc != MI_OK:
         raise MiError(rc, lib().mi_last_error(None).decode())
     return info
+
+
+def partition_spmv_rows(md, rank, size):
+    """host-only: (rows, n_interior_slots) -- SpMV row order of a slab, interior rows first (-1 = padding)"""
+    ns, ni = C.c_int64(), C.c_int64()
+    rc = lib().mi_partition_spmv_rows(C.byref(md), rank, size, C.byref(ns), C.byref(ni), None, 0)
+    if rc != MI_OK:
+        raise MiError(rc, lib().mi_last_error(None).decode())
+    rows = np.zeros(ns.value * 64, dtype=np.int32)
+    rc = lib().mi_partition_spmv_rows(C.byref(md), rank, size, C.byref(ns), C.byref(ni),
+                                      rows.ctypes.data_as(C.POINTER(C.c_int32)), rows.size)
+    if rc != MI_OK:
+        raise MiError(rc, lib().mi_last_error(None).decode())
+    return rows, ni.value * 64
 
 
 def comm_unique_id():

@@ -204,15 +204,61 @@ namespace mi_detail
     return p;
   }
 
-  // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors
-  void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done)
+  // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
+  // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
+  void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
+                    int part)
   {
     if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
-      mi::launch_sell_spmv(c->dim, sell_params(c, x, y, dotv, partials, done), c->grid_spmv, c->stream,
-                           c->sell_unroll);
-    else
+      {
+        mi::SellParams p   = sell_params(c, x, y, dotv, partials, done);
+        const int32_t  nin = int32_t(c->mesh.sell_nslices_interior), nbd = int32_t(c->mesh.sell_nslices) - nin;
+        if (part != 2 && nin > 0)
+          {
+            p.slice0  = 0;
+            p.nslices = nin;
+            p.part0   = 0;
+            mi::launch_sell_spmv(c->dim, p, c->grid_spmv_int, c->stream, c->sell_unroll);
+          }
+        if (part != 1 && nbd > 0)
+          {
+            p.slice0  = nin;
+            p.nslices = nbd;
+            p.part0   = nin > 0 ? c->grid_spmv_int : 0;
+            mi::launch_sell_spmv(c->dim, p, c->grid_spmv_bnd, c->stream, c->sell_unroll);
+          }
+      }
+    else if (part != 1) // block-CSR cross-check kernel: not split, runs after the halo
       mi::launch_spmv(c->dim, spmv_params(c, x, y, dotv, partials, done), c->grid_spmv, c->stream, c->spmv_variant,
                       c->maxrow);
+  }
+
+  // y = K x on every slab of the team with the ghost planes of x exchanged on the way: the halo travels (RCCL: on
+  // the team's communication stream) while the interior rows are computed; the boundary rows follow it.
+  int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
+                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion)
+  {
+    auto launch = [&](int part) {
+      for (size_t k = 0; k < T.members.size(); ++k)
+        {
+          mi_ctx *m = T.members[k];
+          enqueue_spmv(ctx_of(m), x_of(m), y_of(m), fusion ? fusion[k].dotv : nullptr,
+                       fusion ? fusion[k].partials : nullptr, fusion ? fusion[k].done : nullptr, part);
+        }
+    };
+    if (T.size == 1)
+      {
+        launch(0);
+        return MI_OK;
+      }
+    int rc = team_halo_begin(T, x_of);
+    if (rc)
+      return rc;
+    launch(1);
+    if ((rc = team_halo_end(T)))
+      return rc;
+    launch(2);
+    return MI_OK;
   }
 
   // ---- team collectives (no-ops for a single slab) -------------------------------------------------------
@@ -229,40 +275,65 @@ namespace mi_detail
     return MI_OK;
   }
 
-  // ghost planes of a local vector from the neighbouring slabs
-  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec)
+  // ghost planes of a local vector from the neighbouring slabs, split-phase: _begin starts the exchange of the
+  // planes as the team's stream has them at this point, _end makes the stream wait for the ghost values.
+  // The transfer (RCCL send/recv; device copies between emulated slabs) runs on the team's communication stream, so
+  // work enqueued between _begin and _end that does not touch the ghost planes overlaps with it.
+  int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec)
   {
     if (T.size == 1)
       return MI_OK;
     const int D = T.dim;
+    mi_ctx           *c  = T.members[0];
+    const bool        ov = T.overlap && T.comm_stream;
+    const hipStream_t cs = ov ? T.comm_stream : T.stream;
+    if (ov)
+      {
+        HIPCHK(c, hipEventRecord(T.ev_ready, T.stream));
+        HIPCHK(c, hipStreamWaitEvent(T.comm_stream, T.ev_ready, 0));
+      }
     if (T.nccl)
       {
-        mi_ctx                  *c = T.members[0];
         const mi::SlabPartition &s = c->slab;
         double                  *v = vec(c);
         NCCLCHK(c, ncclGroupStart());
         if (s.up_send_n)
           {
-            NCCLCHK(c, ncclSend(v + s.up_send * D, size_t(s.up_send_n) * D, ncclDouble, s.rank + 1, TNCCL(T), T.stream));
-            NCCLCHK(c, ncclRecv(v + s.up_recv * D, size_t(s.up_recv_n) * D, ncclDouble, s.rank + 1, TNCCL(T), T.stream));
+            NCCLCHK(c, ncclSend(v + s.up_send * D, size_t(s.up_send_n) * D, ncclDouble, s.rank + 1, TNCCL(T), cs));
+            NCCLCHK(c, ncclRecv(v + s.up_recv * D, size_t(s.up_recv_n) * D, ncclDouble, s.rank + 1, TNCCL(T), cs));
           }
         if (s.down_send_n)
           {
-            NCCLCHK(c, ncclSend(v + s.down_send * D, size_t(s.down_send_n) * D, ncclDouble, s.rank - 1, TNCCL(T), T.stream));
-            NCCLCHK(c, ncclRecv(v + s.down_recv * D, size_t(s.down_recv_n) * D, ncclDouble, s.rank - 1, TNCCL(T), T.stream));
+            NCCLCHK(c, ncclSend(v + s.down_send * D, size_t(s.down_send_n) * D, ncclDouble, s.rank - 1, TNCCL(T), cs));
+            NCCLCHK(c, ncclRecv(v + s.down_recv * D, size_t(s.down_recv_n) * D, ncclDouble, s.rank - 1, TNCCL(T), cs));
           }
         NCCLCHK(c, ncclGroupEnd());
-        return MI_OK;
       }
-    for (size_t r = 0; r + 1 < T.members.size(); ++r)
-      {
-        mi_ctx *a = T.members[r], *b = T.members[r + 1];
-        HIPCHK(a, hipMemcpyAsync(vec(b) + b->slab.down_recv * D, vec(a) + a->slab.up_send * D,
-                                 size_t(a->slab.up_send_n) * D * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
-        HIPCHK(a, hipMemcpyAsync(vec(a) + a->slab.up_recv * D, vec(b) + b->slab.down_send * D,
-                                 size_t(a->slab.up_recv_n) * D * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
-      }
+    else
+      for (size_t r = 0; r + 1 < T.members.size(); ++r)
+        {
+          mi_ctx *a = T.members[r], *b = T.members[r + 1];
+          HIPCHK(a, hipMemcpyAsync(vec(b) + b->slab.down_recv * D, vec(a) + a->slab.up_send * D,
+                                   size_t(a->slab.up_send_n) * D * sizeof(double), hipMemcpyDeviceToDevice, cs));
+          HIPCHK(a, hipMemcpyAsync(vec(a) + a->slab.up_recv * D, vec(b) + b->slab.down_send * D,
+                                   size_t(a->slab.up_recv_n) * D * sizeof(double), hipMemcpyDeviceToDevice, cs));
+        }
+    if (ov)
+      HIPCHK(c, hipEventRecord(T.ev_halo, cs));
     return MI_OK;
+  }
+
+  int team_halo_end(Team &T)
+  {
+    if (T.size > 1 && T.overlap && T.comm_stream)
+      HIPCHK(T.members[0], hipStreamWaitEvent(T.stream, T.ev_halo, 0));
+    return MI_OK;
+  }
+
+  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec)
+  {
+    const int rc = team_halo_begin(T, vec);
+    return rc ? rc : team_halo_end(T);
   }
 
   // sum over all slabs of a replicated vector (every slab holds all n entries): coarse multigrid residuals
@@ -376,6 +447,9 @@ namespace mi_detail
         cgs.push_back(cg);
       }
     const size_t R = T.members.size();
+    std::vector<SpmvFusion> fusion; // q = K p with the partials of p.q
+    for (size_t k = 0; k < R; ++k)
+      fusion.push_back(SpmvFusion{T.members[k]->work(W_P), cgs[k].part_pq, cgs[k].flags});
     int          rc;
     bool         use_mg = true;
     for (mi_ctx *m : T.members)
@@ -412,12 +486,12 @@ namespace mi_detail
     auto         p_of = [](mi_ctx *m) { return m->work(W_P); };
 
     // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
-    if ((rc = team_halo(T, x_of)))
-      return rc;
+    auto self = [](mi_ctx *m) { return m; };
+    auto q_of = [](mi_ctx *m) { return m->work(W_Q); };
     {
       const int t = tic(c0, MI_T_SPMV);
-      for (mi_ctx *m : T.members)
-        enqueue_spmv(m, m->vec(x_id), m->work(W_Q), nullptr, nullptr, nullptr);
+      if ((rc = team_spmv(T, self, x_of, q_of, nullptr)))
+        return rc;
       toc(c0, t);
     }
     for (size_t k = 0; k < R; ++k)
@@ -460,12 +534,9 @@ namespace mi_detail
             for (size_t k = 0; k < R; ++k)
               mi::launch_cg_update_p(cgs[k], int(it), T.members[k]->grid_vec, T.members[k]->stream);
             toc(c0, t);
-            if ((rc = team_halo(T, p_of)))
-              return rc;
             t = tic(c0, MI_T_SPMV);
-            for (size_t k = 0; k < R; ++k)
-              enqueue_spmv(T.members[k], T.members[k]->work(W_P), T.members[k]->work(W_Q), T.members[k]->work(W_P),
-                           cgs[k].part_pq, cgs[k].flags);
+            if ((rc = team_spmv(T, self, p_of, q_of, fusion.data())))
+              return rc;
             toc(c0, t);
             if (dist)
               {
@@ -665,7 +736,14 @@ namespace mi_detail
     // launch geometry: vector kernels use a fixed grid so that reduction partials are deterministic;
     // SpMV: one wavefront per 64-row slice (measured best), grid-stride above MAX_PART workgroups
     c->grid_vec  = int(std::max<int64_t>(1, std::min<int64_t>(1024, (c->own_n + 255) / 256)));
-    c->grid_spmv = int(std::max<int64_t>(1, std::min<int64_t>(MAX_PART, (m.sell_nslices + 3) / 4)));
+    {
+      const int64_t nin = m.sell_nslices_interior, nbd = m.sell_nslices - nin;
+      c->grid_spmv_bnd  = int(std::min<int64_t>(MAX_PART / 4, (nbd + 3) / 4));
+      c->grid_spmv_int  = int(std::min<int64_t>(MAX_PART - c->grid_spmv_bnd, (nin + 3) / 4));
+      c->grid_spmv      = std::max(1, c->grid_spmv_int + c->grid_spmv_bnd);
+      if (nin == 0 && nbd == 0)
+        c->grid_spmv_int = 1;
+    }
     for (int64_t nd = 0; nd < m.nnodes; ++nd)
       c->maxrow = std::max(c->maxrow, int(m.rowptr[size_t(nd) + 1] - m.rowptr[size_t(nd)]));
     if (const char *v = getenv("MI_SPMV_VARIANT"))
@@ -687,6 +765,14 @@ namespace mi_detail
     for (void *p : {(void *)T->d_gbuf, (void *)T->d_ifbuf, (void *)T->d_sc_ptrs})
       if (p)
         hipFree(p);
+    if (T->comm_stream)
+      {
+        hipStreamSynchronize(T->comm_stream);
+        hipStreamDestroy(T->comm_stream);
+      }
+    for (hipEvent_t e : {T->ev_ready, T->ev_halo})
+      if (e)
+        hipEventDestroy(e);
     if (T->stream && T->owns_stream)
       hipStreamDestroy(T->stream);
     delete T;
@@ -782,6 +868,16 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
       T->nccl               = nc;
       if (r != ncclSuccess)
         return bail(MI_ECOMM, std::string("ncclCommInitRank failed: ") + ncclGetErrorString(r));
+    }
+  if (nranks > 1)
+    {
+      // second stream + events for the halo exchange that overlaps with the interior rows of the SpMV
+      if (hipStreamCreateWithFlags(&T->comm_stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&T->ev_ready, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&T->ev_halo, hipEventDisableTiming) != hipSuccess)
+        return bail(MI_EHIP, "cannot create the communication stream");
+      if (const char *e = getenv("MI_HALO_OVERLAP"))
+        T->overlap = atoi(e) != 0;
     }
   const int first = emulated ? 0 : (comm ? comm->rank : 0), count = emulated ? nranks : 1;
   for (int r = first; r < first + count; ++r)
@@ -1357,8 +1453,16 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->xcd_remap = value;
       else if (k == "sell_unroll" && value >= -2 && value <= 4 && value != 0)
         m->sell_unroll = value;
-      else if (k == "spmv_grid" && value >= 1 && value <= MAX_PART)
-        m->grid_spmv = value;
+      else if (k == "spmv_grid" && value >= 1 && value + m->grid_spmv_bnd <= MAX_PART)
+        {
+          if (m->mesh.sell_nslices_interior > 0)
+            m->grid_spmv_int = value;
+          else
+            m->grid_spmv_bnd = value;
+          m->grid_spmv = m->grid_spmv_int + m->grid_spmv_bnd;
+        }
+      else if (k == "halo_overlap" && (value == 0 || value == 1))
+        c->team->overlap = value;
       else if (k == "asm_variant" && value >= 0 && value <= 8)
         m->asm_variant = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
@@ -1483,6 +1587,38 @@ int mi_partition_describe(const mi_mesh_desc *md, int rank, int size, mi_partiti
         }
       for (int f = 0; f < 6; ++f)
         out->local_face_role[f] = s.local_face_role[f];
+    }
+  catch (const std::exception &e)
+    {
+      return fail(nullptr, MI_EINVAL, "%s", e.what());
+    }
+  return MI_OK;
+}
+
+int mi_partition_spmv_rows(const mi_mesh_desc *md, int rank, int size, int64_t *n_slices, int64_t *n_interior_slices,
+                           int32_t *rows, int64_t capacity)
+{
+  if (!md || !n_slices || !n_interior_slices)
+    return fail(nullptr, MI_EINVAL, "null argument");
+  try
+    {
+      const mi::SlabPartition s =
+        mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, size);
+      mi::HostMesh m;
+      if (size == 1)
+        m.build(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, nullptr);
+      else
+        m.build(md->dim, md->degree, s.local_reps, md->lo, md->hi, s.local_face_role, nullptr, s.z0,
+                md->reps[md->dim - 1], s.own_begin, s.own_end);
+      *n_slices          = m.sell_nslices;
+      *n_interior_slices = m.sell_nslices_interior;
+      if (rows)
+        {
+          if (capacity < int64_t(m.sell_perm.size()))
+            return fail(nullptr, MI_EINVAL, "rows[] holds %lld entries, %lld needed", (long long)capacity,
+                        (long long)m.sell_perm.size());
+          std::copy(m.sell_perm.begin(), m.sell_perm.end(), rows);
+        }
     }
   catch (const std::exception &e)
     {

@@ -26,6 +26,13 @@ namespace mi_detail
     W_Z,     // preconditioned residual (multigrid)
     W_COUNT
   };
+  // what an SpMV launch fuses on top of y = K x: partials of dotv . y, skipped altogether when *done != 0
+  struct SpmvFusion
+  {
+    const double  *dotv;
+    double        *partials;
+    const int32_t *done;
+  };
   struct LinearModel; // mi_linear.cpp
   struct Multigrid;   // mi_mg.cpp
 
@@ -38,6 +45,9 @@ namespace mi_detail
     bool                  owns_stream = true;
     void                 *nccl     = nullptr; // ncclComm_t
     hipStream_t           stream   = nullptr;
+    hipStream_t           comm_stream = nullptr; // RCCL halo exchange next to the interior rows of the SpMV
+    hipEvent_t            ev_ready = nullptr, ev_halo = nullptr;
+    int                   overlap  = 1;          // 0: halo exchange in line on `stream`
     int                   device   = 0;
     int                   dim      = 0;
     int64_t               n_global = 0, nnodes_global = 0;
@@ -78,7 +88,7 @@ struct mi_ctx
   size_t    h_pinned_doubles = 0;
   bool      have_saved = false;
 
-  int grid_vec = 0, grid_spmv = 0;
+  int grid_vec = 0, grid_spmv = 0, grid_spmv_int = 0, grid_spmv_bnd = 0; // grid_spmv = _int + _bnd (partials)
   int spmv_variant = 3, maxrow = 0, sell_unroll = 2, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
 
   // profiling
@@ -127,7 +137,8 @@ namespace mi_detail
   int  sync(mi_ctx *c);
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
                              const int32_t *done);
-  void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done);
+  void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
+                    int part = 0);
   // Jacobi-PCG on the active matrix (all slabs of the team): x = vector x_id (warm start), b = vector b_id;
   // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
   int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res);
@@ -146,6 +157,10 @@ namespace mi_detail
   // team collectives (mi_ctx.cpp)
   int team_allreduce(Team &T, int off, int cnt);
   int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec);
+  int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec);
+  int team_halo_end(Team &T);
+  int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
+                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion);
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);
 
 #define HIPCHK(ctx, call)                                                                                   \

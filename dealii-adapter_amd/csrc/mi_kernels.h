@@ -51,7 +51,9 @@ namespace mi
     const double  *dotv;
     double        *partials;
     const int32_t *done;
-    int32_t        nslices;
+    int32_t        nslices;            // slices this launch works on ...
+    int32_t        slice0;             // ... starting here (interior / boundary launches of a slab)
+    int32_t        part0;              // first slot of `partials` this launch writes (one per workgroup)
     int32_t        own_begin, own_end; // rows (nodes) that contribute to the fused dot product
     int32_t        xcd_remap; // 1: workgroups of one XCD take a contiguous eighth of the slices (measured slower)
   };

@@ -876,7 +876,7 @@ namespace mi
     const int nwg = gridDim.x, b = blockIdx.x;
     const int lb  = (prm.xcd_remap && nwg % 8 == 0) ? (b % 8) * (nwg / 8) + b / 8 : b;
     const int per = (prm.nslices + nwg - 1) / nwg;
-    const int s0 = lb * per, s1 = min(prm.nslices, s0 + per);
+    const int s0 = prm.slice0 + lb * per, s1 = min(prm.slice0 + prm.nslices, s0 + per);
     double    dsum = 0.0;
     for (int sl0 = s0 + wave; sl0 < s1; sl0 += 4)
       {
@@ -957,7 +957,7 @@ namespace mi
       {
         const double tot = block_sum<256>(dsum, s_red);
         if (threadIdx.x == 0)
-          prm.partials[b] = tot;
+          prm.partials[prm.part0 + b] = tot;
       }
   }
 

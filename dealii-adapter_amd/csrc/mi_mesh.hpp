@@ -300,6 +300,7 @@ namespace mi
     // sliced-ELL view of the block pattern for the SpMV: rows grouped by length (a box mesh has at most
     // 2^dim... in fact dim+1 distinct lengths), 64 rows per slice, lane = row, no padding inside a slice
     int64_t              sell_nslices = 0, sell_nblk64 = 0; // sum over slices of their length (units of 64 blocks)
+    int64_t              sell_nslices_interior = 0;         // slices [0, this) hold rows without ghost columns
     std::vector<int32_t> sell_perm;                         // [nslices*64] node of a slot, -1 = padding row
     std::vector<int32_t> sell_len;                          // [nslices] blocks per row in the slice
     std::vector<int64_t> sell_off;                          // [nslices+1] prefix sum of sell_len
@@ -578,10 +579,10 @@ namespace mi
       build_sell(own_begin, own_end < 0 ? nnodes : own_end);
     }
 
-    // SpMV rows = ALL local rows (the CG only uses the owned ones; the slab-local multigrid needs them all)
-    void build_sell(int64_t /*own_begin*/, int64_t /*own_end*/)
+    // SpMV rows = the OWNED rows only: ghost rows are incomplete here and complete on the neighbouring slab, their
+    // values arrive by the halo exchange
+    void build_sell(int64_t own_begin, int64_t own_end)
     {
-      const int64_t own_begin = 0, own_end = nnodes;
       std::vector<int32_t> lens;
       for (int64_t n = 0; n < nnodes; ++n)
         lens.push_back(rowptr[size_t(n) + 1] - rowptr[size_t(n)]);
@@ -590,22 +591,32 @@ namespace mi
       classes.erase(std::unique(classes.begin(), classes.end()), classes.end());
       sell_perm.clear();
       sell_len.clear();
-      for (int32_t L : classes)
+      // interior rows (all columns owned) first, then the boundary rows, which read ghost columns and have to wait
+      // for the halo exchange; the columns of a row ascend, so its first and last one decide
+      auto boundary = [&](int64_t n) {
+        return colidx[size_t(rowptr[size_t(n)])] < own_begin || colidx[size_t(rowptr[size_t(n) + 1]) - 1] >= own_end;
+      };
+      for (int bnd = 0; bnd < 2; ++bnd)
         {
-          int64_t cnt = 0;
-          for (int64_t n = own_begin; n < own_end; ++n)
-            if (lens[size_t(n)] == L)
-              {
-                sell_perm.push_back(int32_t(n));
-                ++cnt;
-              }
-          while (cnt % 64)
+          for (int32_t L : classes)
             {
-              sell_perm.push_back(-1);
-              ++cnt;
+              int64_t cnt = 0;
+              for (int64_t n = own_begin; n < own_end; ++n)
+                if (lens[size_t(n)] == L && int(boundary(n)) == bnd)
+                  {
+                    sell_perm.push_back(int32_t(n));
+                    ++cnt;
+                  }
+              while (cnt % 64)
+                {
+                  sell_perm.push_back(-1);
+                  ++cnt;
+                }
+              for (int64_t sl = 0; sl < cnt / 64; ++sl)
+                sell_len.push_back(L);
             }
-          for (int64_t sl = 0; sl < cnt / 64; ++sl)
-            sell_len.push_back(L);
+          if (bnd == 0)
+            sell_nslices_interior = int64_t(sell_len.size());
         }
       sell_nslices = int64_t(sell_len.size());
       sell_off.assign(size_t(sell_nslices) + 1, 0);

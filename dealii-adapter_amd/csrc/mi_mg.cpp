@@ -194,6 +194,22 @@ namespace mi_detail
       return MI_OK;
     }
 
+    // q = A_l x on level l of every slab: level 0 is distributed (halo exchange overlapped with the interior rows),
+    // the coarser levels are replicated
+    int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of)
+    {
+      if (l == 0)
+        return team_spmv(
+          T, [](mi_ctx *m) { return m->mg->levels[0].ctx; }, x_of, [](mi_ctx *m) { return m->mg->levels[0].q(); },
+          nullptr);
+      for (mi_ctx *m : T.members)
+        {
+          MgLevel &L = m->mg->levels[l];
+          enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr);
+        }
+      return MI_OK;
+    }
+
     // power iteration for lambda_max(D^-1 A); level 0 is distributed over the team, the others are replicated
     int estimate_lmax(Team &T, size_t l)
     {
@@ -226,13 +242,12 @@ namespace mi_detail
       auto   ev_of = [l](mi_ctx *m) { return m->mg->levels[l].ev(); };
       for (int it = 0; it < its; ++it)
         {
-          if (fine && (rc = team_halo(T, ev_of)))
+          if ((rc = level_spmv(T, l, ev_of)))
             return rc;
           for (mi_ctx *m : T.members)
             {
               MgLevel &L = m->mg->levels[l];
               mi_ctx  *c = L.ctx;
-              enqueue_spmv(c, L.ev(), L.q(), nullptr, nullptr, nullptr);
               mi::launch_vec_scale_mul(L.d(), L.q(), c->work(W_DINV), 1.0, c->n, c->stream); // w = D^-1 A v
               // |w|^2 over the owned dofs -> scalar slot 14 of the slab (level 0) / of the level context
               const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : c->n;
@@ -419,13 +434,8 @@ namespace mi_detail
           const bool first = (j == 0), skip_spmv = first && zero_start;
           if (!skip_spmv)
             {
-              if (fine && (rc = team_halo(T, x_of)))
+              if ((rc = level_spmv(T, l, x_of)))
                 return rc;
-              for (mi_ctx *m : T.members)
-                {
-                  MgLevel &L = m->mg->levels[l];
-                  enqueue_spmv(L.ctx, L.x(), L.q(), nullptr, nullptr, nullptr);
-                }
             }
           double c1, c2;
           if (first)
@@ -463,13 +473,12 @@ namespace mi_detail
       if ((rc = chebyshev(T, l, mg0.nu, mg0.smooth_ratio, true)))
         return rc;
       auto x_of = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
-      if (fine && (rc = team_halo(T, x_of)))
+      if ((rc = level_spmv(T, l, x_of)))
         return rc;
       for (mi_ctx *m : T.members)
         {
           MgLevel      &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
           const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : L.ctx->n;
-          enqueue_spmv(L.ctx, L.x(), L.q(), nullptr, nullptr, nullptr);
           mi::launch_vec_residual(L.q() + o0, L.b() + o0, L.q() + o0, on, L.ctx->stream); // q = b - A x (owned)
           // restriction over the owned fine planes only: partial sums on a decomposed fine level
           mi::launch_lattice_restrict(L.ctx->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, L.ctx->stream);

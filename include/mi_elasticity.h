@@ -86,6 +86,11 @@ typedef struct
   int32_t local_face_role[6];
 } mi_partition_info;
 int mi_partition_describe(const mi_mesh_desc *mesh, int rank, int size, mi_partition_info *out);
+/* host-only: the row order of the slab's SpMV (sliced-ELL, 64 rows per slice).  rows[] receives the LOCAL node of
+ * every slot (-1 = padding) if it is not NULL and capacity suffices; slots [0, 64*n_interior_slices) hold the rows
+ * without ghost columns (computed while the halo exchange is in flight), the rest the rows that wait for it. */
+int mi_partition_spmv_rows(const mi_mesh_desc *mesh, int rank, int size, int64_t *n_slices, int64_t *n_interior_slices,
+                           int32_t *rows, int64_t capacity);
 int mi_comm_unique_id(void *out128); /* ncclGetUniqueId */
 
 /* parameters.cc:61-99 ("Solver" subsection) */
@@ -218,8 +223,11 @@ typedef struct
   int64_t count[MI_T_COUNT]; /* launches / calls           */
 } mi_timings;
 int mi_set_profiling(mi_ctx *ctx, int enable);
-/* kernel selection for A/B timing: "spmv_variant" 3 sliced-ELL (default), 1 block-CSR; "spmv_grid" workgroups;
- * "sell_unroll" 1..4; "xcd_remap" 0/1 */
+/* run-time switches (A/B timing, tests): "spmv_variant" 3 sliced-ELL (default), 1 block-CSR; "spmv_grid" workgroups;
+ * "sell_unroll" 1..4; "xcd_remap" 0/1; "precond" 1 multigrid V-cycle (default), 0 Jacobi; "mg_lag" 1 coarse
+ * operators kept over the Newton iterations of a step (default), 0 rebuilt after every assembly; "asm_variant"
+ * element-kernel ablations; "halo_overlap" 1 ghost-plane exchange on the communication stream next to the interior
+ * rows of the SpMV (default), 0 in line on the compute stream.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 int mi_reset_timings(mi_ctx *ctx);
 int mi_get_timings(mi_ctx *ctx, mi_timings *out);

@@ -117,6 +117,41 @@ def test_team_newmark_steps_interface_displacement(slabs):
     assert np.array_equal(G.get(M.V_U), u)
 
 
+@pytest.mark.parametrize("precond", [0, 1])
+def test_halo_overlap_is_bitwise_neutral(precond):
+    """the halo exchange runs on the communication stream next to the interior rows of the SpMV; with the overlap
+    switched off (exchange in line on the compute stream) every iterate must be bit-identical.  24 cell layers
+    over 3 slabs: the interior launch is long enough for a missing dependency to show."""
+    dim, p, reps = 3, 2, (10, 10, 24)
+    runs = []
+    for overlap in (1, 0):
+        _, G = _setup(dim, p, reps, 3, perturb_amp=0.0)
+        G.set_tuning("halo_overlap", overlap)
+        G.set_tuning("precond", precond)
+        rng = np.random.default_rng(7)
+        G.set(M.V_U, 1e-4 * rng.standard_normal(G.n) * ~G.constrained)
+        G.set_interface_traction((0.0, -2e3, 0.0))
+        G.update_acceleration()
+        G.assemble()
+        x = rng.standard_normal(G.n)
+        y = G.spmv(x)
+        rc, its, res = G.cg_solve(rel_tol=1e-9)
+        assert rc == 0
+        runs.append((y, its, res, G.get(M.V_NEWTON)))
+    assert np.array_equal(runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2]
+    assert np.array_equal(runs[0][3], runs[1][3])
+    _, G1 = _setup(dim, p, reps, 1, perturb_amp=0.0)  # and the undecomposed solve agrees to the CG tolerance
+    G1.set_tuning("precond", precond)
+    rng = np.random.default_rng(7)
+    G1.set(M.V_U, 1e-4 * rng.standard_normal(G1.n) * ~G1.constrained)
+    G1.set_interface_traction((0.0, -2e3, 0.0))
+    G1.update_acceleration()
+    G1.assemble()
+    assert G1.cg_solve(rel_tol=1e-9)[0] == 0
+    assert _relmax(runs[0][3], G1.get(M.V_NEWTON)) < 1e-6
+
+
 def test_too_many_slabs_is_an_error():
     with pytest.raises(M.MiError) as e:
         M.Context(dim=3, degree=1, reps=(2, 2, 2), slabs=3)

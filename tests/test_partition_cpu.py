@@ -176,3 +176,33 @@ def test_two_rank_gloo_decomposition(dim, p, reps):
         assert pr.exitcode == 0
     assert errs["rhs"] < 1e-12 and errs["spmv"] < 1e-12
     assert errs["cg"] < 1e-7 and errs["its"] <= 1
+
+
+@pytest.mark.parametrize("dim,p,reps,size", [(3, 2, (3, 2, 7), 3), (3, 1, (3, 3, 9), 4), (2, 3, (5, 9), 4), (3, 2, (2, 2, 2), 2)])
+def test_spmv_rows_interior_first(dim, p, reps, size):
+    """the SpMV covers exactly the owned rows; the rows without ghost columns come first (they are computed while
+    the halo exchange is in flight), the rows that read ghost planes last"""
+    md = _md(dim, p, reps, tuple(0.1 * r for r in reps))
+    for r in range(size):
+        s = M.partition_describe(md, r, size)
+        rows, n_int = M.partition_spmv_rows(md, r, size)
+        real = rows[rows >= 0]
+        assert np.array_equal(np.sort(real), np.arange(s.own_begin, s.own_end))  # every owned row once, no ghost row
+        # a row couples to all nodes of its cells: it reads a ghost plane iff it lies in the cell layer above the
+        # lower ghost plane (rank > 0) or on the top owned plane below the ghost layer (rank < size-1)
+        plane = rows // s.plane_nodes
+        lo_ghost = s.down_recv_n > 0
+        hi_ghost = s.up_recv_n > 0
+        own_planes = (s.own_begin // s.plane_nodes, s.own_end // s.plane_nodes)
+        expect_bnd = np.zeros(rows.size, dtype=bool)
+        if lo_ghost:
+            expect_bnd |= (plane >= own_planes[0]) & (plane < own_planes[0] + p)
+        if hi_ghost:
+            expect_bnd |= plane == own_planes[1] - 1
+        is_bnd = np.arange(rows.size) >= n_int
+        ok = rows >= 0
+        assert np.array_equal(is_bnd[ok], expect_bnd[ok])
+        if size > 1 and s.z1 - s.z0 >= 3:
+            assert 0 < n_int < rows.size
+    rows, n_int = M.partition_spmv_rows(md, 0, 1)
+    assert n_int == rows.size  # undecomposed: a single launch over all rows
