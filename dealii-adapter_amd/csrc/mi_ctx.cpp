@@ -251,7 +251,7 @@ namespace mi_detail
         launch(0);
         return MI_OK;
       }
-    int rc = team_halo_begin(T, x_of);
+    int rc = team_halo_begin(T, x_of, ctx_of);
     if (rc)
       return rc;
     launch(1);
@@ -279,11 +279,14 @@ namespace mi_detail
   // planes as the team's stream has them at this point, _end makes the stream wait for the ghost values.
   // The transfer (RCCL send/recv; device copies between emulated slabs) runs on the team's communication stream, so
   // work enqueued between _begin and _end that does not touch the ghost planes overlaps with it.
-  int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec)
+  int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec,
+                      const std::function<mi_ctx *(mi_ctx *)> &ctx_of)
   {
     if (T.size == 1)
       return MI_OK;
     const int D = T.dim;
+    // the slab geometry is that of ctx_of(member): the member itself or its distributed multigrid level
+    auto slab_of = [&](mi_ctx *m) -> const mi::SlabPartition & { return (ctx_of ? ctx_of(m) : m)->slab; };
     mi_ctx           *c  = T.members[0];
     const bool        ov = T.overlap && T.comm_stream;
     const hipStream_t cs = ov ? T.comm_stream : T.stream;
@@ -294,7 +297,7 @@ namespace mi_detail
       }
     if (T.nccl)
       {
-        const mi::SlabPartition &s = c->slab;
+        const mi::SlabPartition &s = slab_of(c);
         double                  *v = vec(c);
         NCCLCHK(c, ncclGroupStart());
         if (s.up_send_n)
@@ -313,10 +316,11 @@ namespace mi_detail
       for (size_t r = 0; r + 1 < T.members.size(); ++r)
         {
           mi_ctx *a = T.members[r], *b = T.members[r + 1];
-          HIPCHK(a, hipMemcpyAsync(vec(b) + b->slab.down_recv * D, vec(a) + a->slab.up_send * D,
-                                   size_t(a->slab.up_send_n) * D * sizeof(double), hipMemcpyDeviceToDevice, cs));
-          HIPCHK(a, hipMemcpyAsync(vec(a) + a->slab.up_recv * D, vec(b) + b->slab.down_send * D,
-                                   size_t(a->slab.up_recv_n) * D * sizeof(double), hipMemcpyDeviceToDevice, cs));
+          const mi::SlabPartition &sa = slab_of(a), &sb = slab_of(b);
+          HIPCHK(a, hipMemcpyAsync(vec(b) + sb.down_recv * D, vec(a) + sa.up_send * D,
+                                   size_t(sa.up_send_n) * D * sizeof(double), hipMemcpyDeviceToDevice, cs));
+          HIPCHK(a, hipMemcpyAsync(vec(a) + sa.up_recv * D, vec(b) + sb.down_send * D,
+                                   size_t(sa.up_recv_n) * D * sizeof(double), hipMemcpyDeviceToDevice, cs));
         }
     if (ov)
       HIPCHK(c, hipEventRecord(T.ev_halo, cs));
@@ -330,9 +334,9 @@ namespace mi_detail
     return MI_OK;
   }
 
-  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec)
+  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec, const std::function<mi_ctx *(mi_ctx *)> &ctx_of)
   {
-    const int rc = team_halo_begin(T, vec);
+    const int rc = team_halo_begin(T, vec, ctx_of);
     return rc ? rc : team_halo_end(T);
   }
 
@@ -748,6 +752,8 @@ namespace mi_detail
       c->maxrow = std::max(c->maxrow, int(m.rowptr[size_t(nd) + 1] - m.rowptr[size_t(nd)]));
     if (const char *v = getenv("MI_SPMV_VARIANT"))
       c->spmv_variant = atoi(v);
+    if (const char *v = getenv("MI_SELL_UNROLL"))
+      c->sell_unroll = atoi(v);
     return MI_OK;
   }
 
@@ -1451,7 +1457,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->spmv_variant = value;
       else if (k == "xcd_remap" && (value == 0 || value == 1))
         m->xcd_remap = value;
-      else if (k == "sell_unroll" && value >= -2 && value <= 4 && value != 0)
+      else if (k == "sell_unroll" && value >= -2 && value <= 8 && value != 0)
         m->sell_unroll = value;
       else if (k == "spmv_grid" && value >= 1 && value + m->grid_spmv_bnd <= MAX_PART)
         {

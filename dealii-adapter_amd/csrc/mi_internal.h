@@ -89,7 +89,7 @@ struct mi_ctx
   bool      have_saved = false;
 
   int grid_vec = 0, grid_spmv = 0, grid_spmv_int = 0, grid_spmv_bnd = 0; // grid_spmv = _int + _bnd (partials)
-  int spmv_variant = 3, maxrow = 0, sell_unroll = 2, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
+  int spmv_variant = 3, maxrow = 0, sell_unroll = 5, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
 
   // profiling
   bool profiling = false;
@@ -156,8 +156,11 @@ namespace mi_detail
   bool mg_active(const mi_ctx *c);
   // team collectives (mi_ctx.cpp)
   int team_allreduce(Team &T, int off, int cnt);
-  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec);
-  int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec);
+  // ctx_of: whose slab geometry the vector has (null: the member's own; else e.g. its distributed multigrid level)
+  int team_halo(Team &T, const std::function<double *(mi_ctx *)> &vec,
+                const std::function<mi_ctx *(mi_ctx *)> &ctx_of = nullptr);
+  int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec,
+                      const std::function<mi_ctx *(mi_ctx *)> &ctx_of = nullptr);
   int team_halo_end(Team &T);
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
                 const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion);

@@ -115,6 +115,10 @@ namespace mi
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s);
   void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, int grid, hipStream_t s);
+  void launch_cheb4_start(double *x, double *d, double *r, const double *b, const double *q, const double *dinv,
+                          double s0, int64_t n, hipStream_t s);
+  void launch_cheb4_step(double *x, double *d, double *r, const double *q, const double *dinv, double beta, double ca,
+                         double cb, int64_t n, hipStream_t s);
   void launch_cheb_step(double *x, double *d, const double *b, const double *q, const double *dinv, double c1, double c2,
                         int64_t n, hipStream_t s);
   void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st);

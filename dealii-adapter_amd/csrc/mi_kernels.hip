@@ -865,7 +865,9 @@ namespace mi
   // segment, lane = row, so there is no cross-lane reduction and neighbouring rows gather neighbouring x.
   // One wavefront per slice (grid-stride), U blocks in flight per lane.
   // ABL (timing only): 1 = x read at a coalesced slot-based index, 2 = no column / x loads
-  template <int D, int U, int ABL = 0>
+  // NTL: 1 = matrix values and column indices loaded with the non-temporal hint (streamed once, no reuse: keeps the
+  //      L2 for the gathered x), 2 = values only
+  template <int D, int U, int ABL = 0, int NTL = 0>
   __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
@@ -897,12 +899,12 @@ namespace mi
             double  v[U][DD], xx[U][D];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-              c[u] = (ABL == 2) ? 0 : cp[int64_t(k + u) * 64];
+              c[u] = (ABL == 2) ? 0 : (NTL == 1 ? __builtin_nontemporal_load(&cp[int64_t(k + u) * 64]) : cp[int64_t(k + u) * 64]);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
               for (int e = 0; e < DD; ++e)
-                v[u][e] = vp[(int64_t(k + u) * DD + e) * 64];
+                v[u][e] = NTL ? __builtin_nontemporal_load(&vp[(int64_t(k + u) * DD + e) * 64]) : vp[(int64_t(k + u) * DD + e) * 64];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1139,6 +1141,39 @@ namespace mi
     const double dn  = c1 * d[i] + c2 * dinv[i] * res;
     d[i]             = dn;
     x[i]             = (q ? x[i] : 0.0) + dn; // first step starts from x = 0
+  }
+  // Chebyshev smoother of the 4th kind with optimised weights (Lottes, "Optimal polynomial smoothers for multigrid
+  // V-cycles", 2022, Alg. 3) on D^-1 A; only an upper bound rho of the spectrum is needed.
+  //   start: r = b - q (q = A x0, null for x0 = 0 which is then written);  d = s0 D^-1 r
+  //   step : x += beta d;  then (q = A d given)  r -= q;  d = ca d + cb D^-1 r     (q == null: last step, x only)
+  __global__ __launch_bounds__(256) void cheb4_start(double *x, double *d, double *r, const double *__restrict__ b,
+                                                     const double *__restrict__ q, const double *__restrict__ dinv,
+                                                     double s0, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n)
+      return;
+    const double res = b[i] - (q ? q[i] : 0.0);
+    r[i]             = res;
+    d[i]             = s0 * dinv[i] * res;
+    if (!q)
+      x[i] = 0.0;
+  }
+  __global__ __launch_bounds__(256) void cheb4_step(double *x, double *d, double *r, const double *__restrict__ q,
+                                                    const double *__restrict__ dinv, double beta, double ca, double cb,
+                                                    int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n)
+      return;
+    const double di = d[i];
+    x[i] += beta * di;
+    if (q)
+      {
+        const double res = r[i] - q[i];
+        r[i]             = res;
+        d[i]             = ca * di + cb * dinv[i] * res;
+      }
   }
   // dst = s * a .* b   (b == null: dst = s * a)
   __global__ __launch_bounds__(256) void vec_scale_mul(double *dst, const double *__restrict__ a,
@@ -1656,7 +1691,7 @@ namespace mi
   {
     if (dim == 3)
       {
-        if (unroll >= 4)
+        if (unroll == 4)
           hipLaunchKernelGGL((sell_spmv<3, 4>), dim3(grid), dim3(256), 0, s, p);
         else if (unroll == 3)
           hipLaunchKernelGGL((sell_spmv<3, 3>), dim3(grid), dim3(256), 0, s, p);
@@ -1666,6 +1701,14 @@ namespace mi
           hipLaunchKernelGGL((sell_spmv<3, 2, 1>), dim3(grid), dim3(256), 0, s, p);
         else if (unroll == -2)
           hipLaunchKernelGGL((sell_spmv<3, 2, 2>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == 5)
+          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == 6)
+          hipLaunchKernelGGL((sell_spmv<3, 3, 0, 1>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == 7)
+          hipLaunchKernelGGL((sell_spmv<3, 4, 0, 1>), dim3(grid), dim3(256), 0, s, p);
+        else if (unroll == 8)
+          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 2>), dim3(grid), dim3(256), 0, s, p);
 
         else
           hipLaunchKernelGGL((sell_spmv<3, 1>), dim3(grid), dim3(256), 0, s, p);
@@ -1696,6 +1739,16 @@ namespace mi
                         int64_t n, hipStream_t s)
   {
     hipLaunchKernelGGL(cheb_step, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, d, b, q, dinv, c1, c2, n);
+  }
+  void launch_cheb4_start(double *x, double *d, double *r, const double *b, const double *q, const double *dinv,
+                          double s0, int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cheb4_start, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, d, r, b, q, dinv, s0, n);
+  }
+  void launch_cheb4_step(double *x, double *d, double *r, const double *q, const double *dinv, double beta, double ca,
+                         double cb, int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cheb4_step, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, d, r, q, dinv, beta, ca, cb, n);
   }
   void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st)
   {

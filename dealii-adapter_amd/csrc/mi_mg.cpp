@@ -4,10 +4,12 @@
 // Everything is built from pieces that already exist on the device:
 //   * level 0 is the fine problem itself, distributed over the slabs of the team exactly like the CG (owned rows,
 //     ghost planes by halo exchange);
-//   * levels >= 1 are ordinary device contexts on coarser lattices of the UNDECOMPOSED box: first p-coarsening to
-//     Q1 on the same cells, then index-space coarsening of the cells by 2 down to a single cell.  They are 15x and
-//     more smaller than the fine level and are REPLICATED on every slab/GPU: the only collective a V-cycle adds is
-//     one all-reduce of the restricted (level-1) residual;
+//   * levels >= 1 are ordinary device contexts on coarser lattices: first p-coarsening to Q1 on the same cells,
+//     then index-space coarsening of the cells by 2 down to a single cell.  The Q1 level on the same cells (8x
+//     fewer dofs, 12x fewer non-zeros) shares the slab decomposition of the fine level -- same cell layers, same
+//     ownership rule, halo exchange instead of sums -- while the levels on coarsened cells (another 8x smaller each)
+//     live on the UNDECOMPOSED box and are REPLICATED on every slab/GPU: the only collective besides halos that a
+//     V-cycle adds is one all-reduce of the first replicated level's restricted residual;
 //   * coarse operators are RE-ASSEMBLED by the same element kernel at the current state (displacement
 //     interpolated to the level), so no sparse triple products are needed and the Newmark mass term, the
 //     Dirichlet rows and the material are treated exactly as on the fine level;
@@ -33,7 +35,7 @@ namespace mi_detail
   {
     mi_ctx *ctx  = nullptr; // level 0: the slab itself (not owned)
     Team   *team = nullptr; // levels >= 1 own a private single-slab team (shared stream)
-    double *ws   = nullptr; // workspace: b, x, d, q, ev  (5 local vectors; ev = running eigenvector estimate)
+    double *ws   = nullptr; // workspace: b, x, d, q, ev, r  (6 local vectors; ev = running eigenvector estimate)
     bool    ev_ready = false;
     double  lmax = 0.0;     // estimate of the largest eigenvalue of D^-1 A
     MgTransfer to_coarse;   // to level l+1
@@ -42,19 +44,29 @@ namespace mi_detail
     double *d() const { return ws + 2 * ctx->n; }
     double *q() const { return ws + 3 * ctx->n; }
     double *ev() const { return ws + 4 * ctx->n; }
+    double *r() const { return ws + 5 * ctx->n; }
   };
 
   struct Multigrid
   {
     std::vector<MgLevel> levels;
-    int    nu            = 2;    // Chebyshev degree of the pre- and post-smoother
+    size_t n_dist        = 1;    // levels [0, n_dist) are distributed over the slabs of the team, the others replicated
+    int    nu            = 2;    // Chebyshev degree of the pre- and post-smoother on the finest level
+    int    nu_coarse     = 2;    // ... on the coarser levels
+    int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
+    int    coarsest_reps = 1;    // stop coarsening once no direction has more cells than this
     double coarse_ratio  = 60.0;
     int    power_its     = 15;   // first estimate
     int    power_its_update = 4; // refresh, continuing from the previous eigenvector
     double lmax_safety   = 1.15;
   };
+
+  static inline bool is_dist(const Team &T, size_t l)
+  {
+    return T.size > 1 && l < T.members[0]->mg->n_dist;
+  }
 
   bool mg_active(const mi_ctx *c)
   {
@@ -194,13 +206,13 @@ namespace mi_detail
       return MI_OK;
     }
 
-    // q = A_l x on level l of every slab: level 0 is distributed (halo exchange overlapped with the interior rows),
-    // the coarser levels are replicated
+    // q = A_l x on level l of every slab: distributed levels exchange the ghost planes of x (overlapped with the
+    // interior rows), the coarser levels are replicated
     int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of)
     {
-      if (l == 0)
+      if (is_dist(T, l))
         return team_spmv(
-          T, [](mi_ctx *m) { return m->mg->levels[0].ctx; }, x_of, [](mi_ctx *m) { return m->mg->levels[0].q(); },
+          T, [l](mi_ctx *m) { return m->mg->levels[l].ctx; }, x_of, [l](mi_ctx *m) { return m->mg->levels[l].q(); },
           nullptr);
       for (mi_ctx *m : T.members)
         {
@@ -215,7 +227,7 @@ namespace mi_detail
     {
       mi_ctx    *c0  = T.members[0];
       Multigrid &mg0 = *c0->mg;
-      const bool fine = (l == 0);
+      const bool dist = is_dist(T, l);
       int        its  = mg0.power_its_update;
       for (mi_ctx *m : T.members)
         {
@@ -227,7 +239,7 @@ namespace mi_detail
               // deterministic start vector with all frequencies (a function of the GLOBAL dof index, so that slabs
               // agree on their ghost copies): v_i = 1 + 0.5 sin(i) on unconstrained dofs
               std::vector<double> h((size_t)n, 0.0);
-              const int64_t       g0 = fine ? c->slab.node_offset * c->dim : 0;
+              const int64_t       g0 = c->slab.node_offset * c->dim;
               for (int64_t i = 0; i < n; ++i)
                 h[size_t(i)] =
                   ((c->mesh.cmask[size_t(i / c->dim)] >> int(i % c->dim)) & 1) ? 0.0 : 1.0 + 0.5 * std::sin(double(i + g0));
@@ -249,15 +261,13 @@ namespace mi_detail
               MgLevel &L = m->mg->levels[l];
               mi_ctx  *c = L.ctx;
               mi::launch_vec_scale_mul(L.d(), L.q(), c->work(W_DINV), 1.0, c->n, c->stream); // w = D^-1 A v
-              // |w|^2 over the owned dofs -> scalar slot 14 of the slab (level 0) / of the level context
-              const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : c->n;
-              mi::launch_masked_norm(c->dim, L.d() + o0, c->d_cmask + (fine ? m->slab.own_begin : 0), on, c->part(5),
-                                     c->grid_vec, c->d_sc + 14, c->stream);
+              // |w|^2 over the owned dofs of the level -> scalar slot 14 of the slab
+              mi::launch_masked_norm(c->dim, L.d() + c->own0, c->d_cmask + c->slab.own_begin, c->own_n, m->part(5),
+                                     m->grid_vec, m->d_sc + 14, c->stream);
             }
-          if (fine && (rc = team_allreduce(T, 14, 1)))
+          if (dist && (rc = team_allreduce(T, 14, 1)))
             return rc;
-          mi_ctx *cr = c0->mg->levels[l].ctx;
-          HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, cr->d_sc + 14, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+          HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc + 14, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
           HIPCHK(c0, hipStreamSynchronize(c0->stream));
           const double nw = std::sqrt(c0->h_pinned[0]); // |D^-1 A v|, equal to lambda once |v| = 1
           if (!(nw > 0.0) || !std::isfinite(nw))
@@ -301,8 +311,18 @@ namespace mi_detail
     c->mg         = mg;
     if (const char *e = getenv("MI_MG_NU"))
       mg->nu = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_NU_COARSE"))
+      mg->nu_coarse = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_KIND"))
+      mg->kind = atoi(e) == 4 ? 4 : 1;
     if (const char *e = getenv("MI_MG_RATIO"))
       mg->smooth_ratio = std::max(2.0, atof(e));
+    if (const char *e = getenv("MI_MG_COARSEST"))
+      mg->coarsest_reps = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_COARSE_DEGREE"))
+      mg->coarse_degree = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_COARSE_RATIO"))
+      mg->coarse_ratio = std::max(2.0, atof(e));
     MgLevel L0;
     L0.ctx = c;
     mg->levels.push_back(L0);
@@ -318,7 +338,7 @@ namespace mi_detail
           {
             bool changed = false;
             for (int d = 0; d < dim; ++d)
-              if (reps[d] > 1)
+              if (reps[d] > mg->coarsest_reps)
                 {
                   reps[d] = (reps[d] + 1) / 2;
                   changed = true;
@@ -331,8 +351,10 @@ namespace mi_detail
         for (int d = 0; d < 3; ++d)
           md.reps[d] = d < dim ? reps[d] : 1;
         md.vertex_perturbation = nullptr;
+        // the Q1 level on the same cells takes over the slab decomposition of the fine level
+        const bool slab_level = c->team->size > 1 && mg->levels.size() == 1 && c->degree > 1;
         Team *T         = new Team;
-        T->size         = 1;
+        T->size         = slab_level ? c->team->size : 1;
         T->device       = c->device;
         T->dim          = dim;
         T->stream       = c->stream;
@@ -340,7 +362,9 @@ namespace mi_detail
         T->md           = md;
         T->iface_global = mi::global_interface_nodes(dim, p, md.reps, md.face_role);
         mi_ctx   *lc    = nullptr;
-        const int rc    = create_member(*T, &md, &c->mat, &c->nm, 0, &lc);
+        const int rc    = create_member(*T, &md, &c->mat, &c->nm, slab_level ? c->slab.rank : 0, &lc);
+        if (slab_level)
+          mg->n_dist = 2;
         T->members.push_back(lc);
         if (rc != MI_OK)
           {
@@ -357,11 +381,13 @@ namespace mi_detail
     for (size_t l = 0; l < mg->levels.size(); ++l)
       {
         MgLevel &L = mg->levels[l];
-        HIPCHK(c, hipMalloc((void **)&L.ws, size_t(5) * size_t(L.ctx->n) * sizeof(double)));
-        HIPCHK(c, hipMemsetAsync(L.ws, 0, size_t(5) * size_t(L.ctx->n) * sizeof(double), c->stream));
+        HIPCHK(c, hipMalloc((void **)&L.ws, size_t(6) * size_t(L.ctx->n) * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(L.ws, 0, size_t(6) * size_t(L.ctx->n) * sizeof(double), c->stream));
         if (l + 1 < mg->levels.size())
           {
-            const int rc = build_transfer(L.ctx, mg->levels[l + 1].ctx, L.to_coarse, l == 0 && c->team->size > 1);
+            // slab -> replicated level: ownership-aware tables; slab -> slab and box -> box: plain local tables
+            const bool cut = c->team->size > 1 && l + 1 == mg->n_dist;
+            const int  rc  = build_transfer(L.ctx, mg->levels[l + 1].ctx, L.to_coarse, cut);
             if (rc)
               return rc;
           }
@@ -381,29 +407,32 @@ namespace mi_detail
     int          rc;
     for (mi_ctx *m : T.members)
       {
-        Multigrid &mg = *m->mg;
-        MgLevel   &L0 = mg.levels[0], &L1 = mg.levels[1];
-        // u_total = u + du of the slab, then the (ownership-masked) state transfer to level 1
+        // u_total = u + du of the slab (all local nodes: the ghost copies are kept consistent)
+        MgLevel &L0 = m->mg->levels[0];
         HIPCHK(m, hipMemcpyAsync(L0.x(), m->vec(MI_V_TOTAL_DISPLACEMENT), size_t(m->n) * sizeof(double),
                                  hipMemcpyDeviceToDevice, m->stream));
         mi::launch_vec_add(L0.x(), m->vec(MI_V_SOLUTION_DELTA), m->n, m->stream);
-        mi::launch_lattice_interp(m->dim, false, L0.to_coarse.state, L1.ctx->vec(MI_V_TOTAL_DISPLACEMENT), L0.x(),
-                                  L1.ctx->d_cmask, m->stream);
       }
-    if ((rc = team_allreduce_vectors(
-           T, [](mi_ctx *m) { return m->mg->levels[1].ctx->vec(MI_V_TOTAL_DISPLACEMENT); },
-           size_t(c0->mg->levels[1].ctx->n))))
-      return rc;
-    for (mi_ctx *m : T.members)
+    for (size_t l = 1; l < nl; ++l)
       {
-        Multigrid &mg = *m->mg;
-        for (size_t l = 1; l < nl; ++l)
+        // state of level l from level l-1.  slab -> slab: plain interpolation inside the local box (ghosts
+        // included); slab -> replicated: ownership-masked interpolation, summed over the slabs
+        for (mi_ctx *m : T.members)
           {
-            MgLevel &C = mg.levels[l];
-            if (l > 1)
-              mi::launch_lattice_interp(m->dim, false, mg.levels[l - 1].to_coarse.state,
-                                        C.ctx->vec(MI_V_TOTAL_DISPLACEMENT),
-                                        mg.levels[l - 1].ctx->vec(MI_V_TOTAL_DISPLACEMENT), C.ctx->d_cmask, m->stream);
+            Multigrid    &mg  = *m->mg;
+            MgLevel      &F   = mg.levels[l - 1], &C = mg.levels[l];
+            const double *src = (l == 1) ? F.x() : F.ctx->vec(MI_V_TOTAL_DISPLACEMENT);
+            mi::launch_lattice_interp(m->dim, false, F.to_coarse.state, C.ctx->vec(MI_V_TOTAL_DISPLACEMENT), src,
+                                      C.ctx->d_cmask, m->stream);
+          }
+        if (is_dist(T, l - 1) && !is_dist(T, l) &&
+            (rc = team_allreduce_vectors(
+               T, [l](mi_ctx *m) { return m->mg->levels[l].ctx->vec(MI_V_TOTAL_DISPLACEMENT); },
+               size_t(c0->mg->levels[l].ctx->n))))
+          return rc;
+        for (mi_ctx *m : T.members)
+          {
+            MgLevel &C = m->mg->levels[l];
             if ((rc = enqueue_assembly(C.ctx)))
               return fail(c0, rc, "multigrid level %d: %s", int(l), C.ctx->err.c_str());
           }
@@ -423,7 +452,6 @@ namespace mi_detail
     // Level 0 runs on all slabs in lockstep (halo exchange of x before every SpMV, update on the owned dofs).
     int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start)
     {
-      const bool   fine = (l == 0);
       const double b = T.members[0]->mg->levels[l].lmax, a = b / ratio;
       const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
       double       rho_old = 1.0 / sigma;
@@ -453,7 +481,7 @@ namespace mi_detail
           for (mi_ctx *m : T.members)
             {
               MgLevel      &L  = m->mg->levels[l];
-              const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : L.ctx->n;
+              const int64_t o0 = L.ctx->own0, on = L.ctx->own_n;
               mi::launch_cheb_step(L.x() + o0, L.d() + o0, L.b() + o0, skip_spmv ? nullptr : L.q() + o0,
                                    L.ctx->work(W_DINV) + o0, c1, c2, on, L.ctx->stream);
             }
@@ -461,39 +489,112 @@ namespace mi_detail
       return MI_OK;
     }
 
+    // optimised 4th-kind weights beta_1..beta_k (Lottes 2022, table 1), k <= 6
+    const double *cheb4_betas(int k)
+    {
+      static const double b1[] = {1.12500000000000};
+      static const double b2[] = {1.02387287570313, 1.26408905371085};
+      static const double b3[] = {1.00842544782028, 1.08867839208730, 1.33753125909618};
+      static const double b4[] = {1.00391310427285, 1.04035811188593, 1.14863498546254, 1.38268869241000};
+      static const double b5[] = {1.00212930146164, 1.02173711549260, 1.07872433192603, 1.19810065292663,
+                                  1.41322542791682};
+      static const double b6[] = {1.00128517255940, 1.01304293035233, 1.04678215124113, 1.11616489419675,
+                                  1.23829020218444, 1.43524297106744};
+      static const double *const tab[] = {b1, b2, b3, b4, b5, b6};
+      return tab[k - 1];
+    }
+
+    // k steps of the 4th-kind Chebyshev smoother on level l (see cheb4_start / cheb4_step): k-1 SpMVs from x = 0,
+    // k otherwise -- the same count as the 1st-kind recurrence above
+    int chebyshev4(Team &T, size_t l, int k, bool zero_start)
+    {
+      k = std::min(k, 6);
+      const double  rho  = T.members[0]->mg->levels[l].lmax;
+      const double *beta = cheb4_betas(k);
+      auto          x_of = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
+      auto          d_of = [l](mi_ctx *m) { return m->mg->levels[l].d(); };
+      int           rc;
+      if (!zero_start && (rc = level_spmv(T, l, x_of)))
+        return rc;
+      for (mi_ctx *m : T.members)
+        {
+          MgLevel      &L  = m->mg->levels[l];
+          const int64_t o0 = L.ctx->own0, on = L.ctx->own_n;
+          mi::launch_cheb4_start(L.x() + o0, L.d() + o0, L.r() + o0, L.b() + o0, zero_start ? nullptr : L.q() + o0,
+                                 L.ctx->work(W_DINV) + o0, 4.0 / (3.0 * rho), on, L.ctx->stream);
+        }
+      for (int i = 1; i <= k; ++i)
+        {
+          const bool last = (i == k);
+          if (!last && (rc = level_spmv(T, l, d_of)))
+            return rc;
+          const double ca = (2.0 * i - 1.0) / (2.0 * i + 3.0), cb = (8.0 * i + 4.0) / ((2.0 * i + 3.0) * rho);
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel      &L  = m->mg->levels[l];
+              const int64_t o0 = L.ctx->own0, on = L.ctx->own_n;
+              mi::launch_cheb4_step(L.x() + o0, L.d() + o0, L.r() + o0, last ? nullptr : L.q() + o0,
+                                    L.ctx->work(W_DINV) + o0, beta[i - 1], ca, cb, on, L.ctx->stream);
+            }
+        }
+      return MI_OK;
+    }
+
+    int smooth(Team &T, size_t l, int k, bool zero_start)
+    {
+      Multigrid &mg0 = *T.members[0]->mg;
+      return mg0.kind == 4 ? chebyshev4(T, l, k, zero_start) : chebyshev(T, l, k, mg0.smooth_ratio, zero_start);
+    }
+
     int vcycle(Team &T, size_t l)
     {
       mi_ctx      *c0  = T.members[0];
       Multigrid   &mg0 = *c0->mg;
       const size_t nl  = mg0.levels.size();
-      const bool   fine = (l == 0);
       int          rc;
       if (l + 1 == nl)
         return chebyshev(T, l, mg0.coarse_degree, mg0.coarse_ratio, true);
-      if ((rc = chebyshev(T, l, mg0.nu, mg0.smooth_ratio, true)))
+      const bool dist_l = is_dist(T, l), dist_c = is_dist(T, l + 1);
+      const int  nu     = (l == 0) ? mg0.nu : mg0.nu_coarse;
+      if ((rc = smooth(T, l, nu, true)))
         return rc;
-      auto x_of = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
+      auto x_of   = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
+      auto q_of   = [l](mi_ctx *m) { return m->mg->levels[l].q(); };
+      auto ctx_l  = [l](mi_ctx *m) { return m->mg->levels[l].ctx; };
+      auto ctx_c  = [l](mi_ctx *m) { return m->mg->levels[l + 1].ctx; };
+      auto xc_of  = [l](mi_ctx *m) { return m->mg->levels[l + 1].x(); };
       if ((rc = level_spmv(T, l, x_of)))
         return rc;
       for (mi_ctx *m : T.members)
         {
-          MgLevel      &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
-          const int64_t o0 = fine ? m->own0 : 0, on = fine ? m->own_n : L.ctx->n;
-          mi::launch_vec_residual(L.q() + o0, L.b() + o0, L.q() + o0, on, L.ctx->stream); // q = b - A x (owned)
-          // restriction over the owned fine planes only: partial sums on a decomposed fine level
+          MgLevel &L = m->mg->levels[l];
+          mi::launch_vec_residual(L.q() + L.ctx->own0, L.b() + L.ctx->own0, L.q() + L.ctx->own0, L.ctx->own_n,
+                                  L.ctx->stream); // q = b - A x (owned)
+        }
+      // restriction.  distributed -> distributed (same slabs): the ghost planes of the residual come from the
+      // neighbours, every owned coarse node then sums its complete fine neighbourhood.  distributed -> replicated:
+      // every slab sums over its owned fine planes only and the partial sums are all-reduced.
+      if (dist_l && dist_c && (rc = team_halo(T, q_of, ctx_l)))
+        return rc;
+      for (mi_ctx *m : T.members)
+        {
+          MgLevel &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
           mi::launch_lattice_restrict(L.ctx->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, L.ctx->stream);
         }
-      if (fine && (rc = team_allreduce_vectors(
-                     T, [l](mi_ctx *m) { return m->mg->levels[l + 1].b(); }, size_t(mg0.levels[l + 1].ctx->n))))
+      if (dist_l && !dist_c &&
+          (rc = team_allreduce_vectors(
+             T, [l](mi_ctx *m) { return m->mg->levels[l + 1].b(); }, size_t(mg0.levels[l + 1].ctx->n))))
         return rc;
       if ((rc = vcycle(T, l + 1)))
+        return rc;
+      if (dist_c && (rc = team_halo(T, xc_of, ctx_c))) // prolongation reads the coarse ghost planes
         return rc;
       for (mi_ctx *m : T.members)
         {
           MgLevel &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
           mi::launch_lattice_interp(L.ctx->dim, true, L.to_coarse.prolong, L.x(), C.x(), L.ctx->d_cmask, L.ctx->stream);
         }
-      return chebyshev(T, l, mg0.nu, mg0.smooth_ratio, false);
+      return smooth(T, l, nu, false);
     }
   } // namespace
 
