@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--precond", choices=["mg", "jacobi"], default="mg",
                     help="CG preconditioner: geometric multigrid V-cycle (default) or Jacobi")
     ap.add_argument("--slabs", type=int, default=1, help="diagnostic: cut the mesh into this many slabs on ONE GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N GPUs: weak = every GPU gets its own cells^3 block of the beam (cells x cells x N*cells, default); "
+                         "strong = the one cells^3 block is cut into N slabs")
     ap.add_argument("--cpu-cells", type=int, default=16, help="cells per side of the CPU-baseline sample (0: skip)")
     args = ap.parse_args()
 
@@ -104,8 +107,11 @@ def main():
         box = [M.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
-    # strong scaling: the SAME 59^3 mesh is cut into `world` z-slabs, one per GPU
-    G = M.Context(dim=3, degree=2, reps=(n, n, n), lo=(0, 0, 0), hi=(1, 1, 1), mu=0.5e6, nu=0.4, rho=1000.0,
+    # z-slabs, one per GPU.  weak scaling: the block grows along z with the number of GPUs (cubic cells of the same
+    # size, cells^3 of them per GPU: at N=1 exactly the 59^3 case the metric names); strong: the 59^3 block is cut
+    parts = world if world > 1 else args.slabs
+    nz = n * parts if args.scaling == "weak" else n
+    G = M.Context(dim=3, degree=2, reps=(n, n, nz), lo=(0, 0, 0), hi=(1, 1, nz / n), mu=0.5e6, nu=0.4, rho=1000.0,
                   beta=0.25, gamma=0.5, delta_t=0.005, device=local_rank, rank=rank, world=world, unique_id=uid,
                   slabs=args.slabs if world == 1 else 1)
     G.set_tuning("precond", 1 if args.precond == "mg" else 0)
@@ -152,7 +158,7 @@ def main():
         # HBM traffic of the same kernel on the same workload from the committed PMC passes (rocprofv3 --pmc cannot be
         # collected from inside this process); only quoted when the workload is the one that was profiled
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_n59.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_nt_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9  # GB per launch
         out = {
@@ -164,16 +170,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %d^3 cells, %d DoFs, %d nnz, Newton+Newmark, "
-                            "%s-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
-                            % (n, G.n, G.nnz, "multigrid" if args.precond == "mg" else "Jacobi", args.tol_lin),
-                "preconditioner": "geometric multigrid V-cycle (Chebyshev-Jacobi smoothing, re-assembled coarse levels), "
-                                  "block-wise per slab" if args.precond == "mg" else "Jacobi",
+                "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %dx%dx%d cells (%d^3 per GPU), %d DoFs, %d nnz, "
+                            "Newton+Newmark, %s-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
+                            % (n, n, nz, n, G.n, G.nnz, "multigrid" if args.precond == "mg" else "Jacobi", args.tol_lin),
+                "preconditioner": "geometric multigrid V-cycle (Chebyshev-Jacobi smoothing, re-assembled coarse levels; Q2 and "
+                                  "Q1 levels of the fine cells distributed over the slabs, coarser levels replicated)"
+                if args.precond == "mg" else "Jacobi",
                 "n_dofs": G.n,
                 "nnz": G.nnz,
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs emulated on one GPU" % args.slabs) if world == 1 else
@@ -186,7 +193,8 @@ def main():
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
             },
             "roofline": {
-                "kernel": "sell_spmv<3,2> (CG matrix-vector product, sliced-ELL copy of the block-CSR tangent)",
+                "kernel": "sell_spmv<3,2,0,1> (CG matrix-vector product, sliced-ELL copy of the block-CSR tangent, "
+                          "non-temporal matrix loads)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

@@ -56,7 +56,8 @@ def main():
             for g in grids:
                 for u in (UNROLLS if v == 3 else [0]):
                     G.set_tuning("spmv_variant", v)
-                    G.set_tuning("spmv_grid", g)
+                    if g:  # 0: the library's own launch geometry
+                        G.set_tuning("spmv_grid", g)
                     if u:
                         G.set_tuning("sell_unroll", u)
                     res.setdefault((v * 100 + u if v == 3 else v, g), []).append(G.bench_spmv(args.reps))
