@@ -95,7 +95,13 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
                   file=sys.stderr)
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; a launcher that narrows the visible devices to one per process is honoured
+    ndev = torch.cuda.device_count()
+    if ndev == 0:
+        print("bench.py: no GPU visible (the hot path has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+    device = local_rank if local_rank < ndev else 0
+    torch.cuda.set_device(device)
     M = _pkg()
     n = args.cells
     uid = None
@@ -112,7 +118,7 @@ def main():
     parts = world if world > 1 else args.slabs
     nz = n * parts if args.scaling == "weak" else n
     G = M.Context(dim=3, degree=2, reps=(n, n, nz), lo=(0, 0, 0), hi=(1, 1, nz / n), mu=0.5e6, nu=0.4, rho=1000.0,
-                  beta=0.25, gamma=0.5, delta_t=0.005, device=local_rank, rank=rank, world=world, unique_id=uid,
+                  beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=rank, world=world, unique_id=uid,
                   slabs=args.slabs if world == 1 else 1)
     G.set_tuning("precond", 1 if args.precond == "mg" else 0)
     nnzb = G.nnz // 9
@@ -190,6 +196,7 @@ def main():
                 "assemblies_per_step": assemblies / args.steps,
                 "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
                 "ms_cg_per_step": tm["cg_total"][0] / args.steps,
+                "ms_sell_copy_per_step": tm["sell_copy"][0] / args.steps,
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
             },
             "roofline": {

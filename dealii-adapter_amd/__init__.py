@@ -18,8 +18,8 @@ HEADER = os.path.join(ROOT, "include", "mi_elasticity.h")
 MI_OK, MI_EINVAL, MI_EHIP, MI_ENOCONV_LIN, MI_ENOCONV_NR, MI_ECOMM = 0, -1, -2, -3, -4, -5
 FACE_FREE, FACE_CLAMPED, FACE_INTERFACE, FACE_ZCLAMP = 0, 1, 7, 8
 (V_U, V_U_OLD, V_V, V_V_OLD, V_A, V_A_OLD, V_STRESS, V_DELTA, V_NEWTON, V_RHS) = range(10)
-(T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_COUNT) = range(8)
-TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step"]
+(T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_SELL_COPY, T_COUNT) = range(9)
+TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step", "sell_copy"]
 
 
 class MeshDesc(C.Structure):
@@ -354,7 +354,7 @@ class Context:
     def timings(self):
         t = Timings()
         self._chk(lib().mi_get_timings(self.h, C.byref(t)))
-        return {TIMING_NAMES[i]: (t.ms[i], t.count[i]) for i in range(T_COUNT - 1)}
+        return {TIMING_NAMES[i]: (t.ms[i], t.count[i]) for i in range(T_COUNT)}
 
     def bench_spmv(self, reps=20):
         ms = C.c_double(0)

@@ -204,6 +204,19 @@ namespace mi_detail
     return p;
   }
 
+  // SpMV-side copy of the tangent (owned rows) in sliced-ELL order.  Lazy: the last assembly of a Newton loop only
+  // serves the convergence check (nonlinear_elasticity.cc:446-469) and is never multiplied.
+  void refresh_sell(mi_ctx *c)
+  {
+    if (!c->sell_stale || c->active_sell_vals)
+      return;
+    const int t = tic(c->team->members[0], MI_T_SELL_COPY);
+    mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
+                           c->d_sell_vals, c->stream);
+    toc(c->team->members[0], t);
+    c->sell_stale = false;
+  }
+
   // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
   // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
@@ -211,6 +224,7 @@ namespace mi_detail
   {
     if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
       {
+        refresh_sell(c);
         mi::SellParams p   = sell_params(c, x, y, dotv, partials, done);
         const int32_t  nin = int32_t(c->mesh.sell_nslices_interior), nbd = int32_t(c->mesh.sell_nslices) - nin;
         if (part != 2 && nin > 0)
@@ -396,9 +410,7 @@ namespace mi_detail
       }
     toc(c0, t0);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
-    // SpMV-side copy of the tangent (owned rows) in sliced-ELL order
-    mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
-                           c->d_sell_vals, c->stream);
+    c->sell_stale = true; // the SpMV-side copy is refreshed by the first product that needs it (enqueue_spmv)
     HIPCHK(c, hipGetLastError());
     c->mg_stale = true; // the coarse operators belong to an older state
     return MI_OK;
@@ -429,6 +441,8 @@ namespace mi_detail
     Team      &T    = *c->team;
     mi_ctx    *c0   = T.members[0];
     const bool dist = T.size > 1;
+    for (mi_ctx *m : T.members) // outside the timed SpMV launches
+      refresh_sell(m);
     const int  tt   = tic(c0, MI_T_CG_TOTAL);
     std::vector<mi::CgParams> cgs;
     for (mi_ctx *m : T.members)

@@ -119,6 +119,7 @@ struct mi_ctx
   // multigrid preconditioner of this slab (mi_mg.cpp); precond: 0 Jacobi, 1 multigrid V-cycle
   mi_detail::Multigrid *mg = nullptr;
   int                   precond = 1;
+  bool                  sell_stale = false; // the sliced-ELL copy is older than the block-CSR tangent
   bool                  mg_stale = true; // the coarse operators belong to an older state than the fine tangent
   bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
   int                   asm_variant = 0;

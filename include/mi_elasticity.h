@@ -215,6 +215,7 @@ enum
   MI_T_CG_TOTAL,
   MI_T_NEWMARK,
   MI_T_STEP,               /* whole mi_newmark_step                           */
+  MI_T_SELL_COPY,          /* block-CSR -> sliced-ELL copy before the first product with a new tangent */
   MI_T_COUNT
 };
 typedef struct
