@@ -506,12 +506,8 @@ namespace mi_detail
     // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
     auto self = [](mi_ctx *m) { return m; };
     auto q_of = [](mi_ctx *m) { return m->work(W_Q); };
-    {
-      const int t = tic(c0, MI_T_SPMV);
-      if ((rc = team_spmv(T, self, x_of, q_of, nullptr)))
-        return rc;
-      toc(c0, t);
-    }
+    if ((rc = team_spmv(T, self, x_of, q_of, nullptr))) // not under MI_T_SPMV: that class is the fused q = K p only
+      return rc;
     for (size_t k = 0; k < R; ++k)
       {
         mi_ctx *m = T.members[k];

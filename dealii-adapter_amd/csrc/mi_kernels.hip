@@ -867,7 +867,9 @@ namespace mi
   // ABL (timing only): 1 = x read at a coalesced slot-based index, 2 = no column / x loads
   // NTL: 1 = matrix values and column indices loaded with the non-temporal hint (streamed once, no reuse: keeps the
   //      L2 for the gathered x), 2 = values only
-  template <int D, int U, int ABL = 0, int NTL = 0>
+  // DOT: the CG's q = K p with the fused partials of p.q -- a separate instantiation so that profilers list the
+  //      product the roofline figure is quoted on apart from the preconditioner's products
+  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false>
   __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
@@ -950,12 +952,12 @@ namespace mi
             for (int i = 0; i < D; ++i)
               {
                 prm.y[int64_t(node) * D + i] = acc[i];
-                if (prm.dotv && node >= prm.own_begin && node < prm.own_end)
+                if (DOT && node >= prm.own_begin && node < prm.own_end)
                   dsum += acc[i] * prm.dotv[int64_t(node) * D + i];
               }
           }
       }
-    if (prm.partials)
+    if (DOT)
       {
         const double tot = block_sum<256>(dsum, s_red);
         if (threadIdx.x == 0)
@@ -1687,34 +1689,37 @@ namespace mi
       launch_spmv_d<2>(p, grid, s, variant, maxrow);
   }
 
+  // unroll: 1..4 blocks in flight per lane; 5..7 = 2..4 with non-temporal matrix loads (5 is the default),
+  // 8 = 2 with non-temporal values only; -1, -2 timing-only ablations
+  template <int D, bool DOT>
+  static void sell_dispatch(const SellParams &p, int grid, hipStream_t s, int unroll)
+  {
+#define MI_SELL(U, ABL, NTL) hipLaunchKernelGGL((sell_spmv<D, U, ABL, NTL, DOT>), dim3(grid), dim3(256), 0, s, p)
+    if constexpr (D == 2)
+      MI_SELL(4, 0, 0);
+    else
+      switch (unroll)
+        {
+        case 1: MI_SELL(1, 0, 0); break;
+        case 2: MI_SELL(2, 0, 0); break;
+        case 3: MI_SELL(3, 0, 0); break;
+        case 4: MI_SELL(4, 0, 0); break;
+        case 6: MI_SELL(3, 0, 1); break;
+        case 7: MI_SELL(4, 0, 1); break;
+        case 8: MI_SELL(2, 0, 2); break;
+        case -1: MI_SELL(2, 1, 0); break;
+        case -2: MI_SELL(2, 2, 0); break;
+        default: MI_SELL(2, 0, 1); break;
+        }
+#undef MI_SELL
+  }
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
   {
+    const bool dot = p.dotv && p.partials;
     if (dim == 3)
-      {
-        if (unroll == 4)
-          hipLaunchKernelGGL((sell_spmv<3, 4>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == 3)
-          hipLaunchKernelGGL((sell_spmv<3, 3>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == 2)
-          hipLaunchKernelGGL((sell_spmv<3, 2>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == -1)
-          hipLaunchKernelGGL((sell_spmv<3, 2, 1>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == -2)
-          hipLaunchKernelGGL((sell_spmv<3, 2, 2>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == 5)
-          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == 6)
-          hipLaunchKernelGGL((sell_spmv<3, 3, 0, 1>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == 7)
-          hipLaunchKernelGGL((sell_spmv<3, 4, 0, 1>), dim3(grid), dim3(256), 0, s, p);
-        else if (unroll == 8)
-          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 2>), dim3(grid), dim3(256), 0, s, p);
-
-        else
-          hipLaunchKernelGGL((sell_spmv<3, 1>), dim3(grid), dim3(256), 0, s, p);
-      }
+      dot ? sell_dispatch<3, true>(p, grid, s, unroll) : sell_dispatch<3, false>(p, grid, s, unroll);
     else
-      hipLaunchKernelGGL((sell_spmv<2, 4>), dim3(grid), dim3(256), 0, s, p);
+      dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
   }
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, hipStream_t s)
