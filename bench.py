@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--tol-lin", type=float, default=1e-6)
     ap.add_argument("--precond", choices=["mg", "jacobi"], default="mg",
                     help="CG preconditioner: geometric multigrid V-cycle (default) or Jacobi")
+    ap.add_argument("--precond-storage", choices=["f64", "f32"], default="f64",
+                    help="f32: the multigrid smoother multiplies with an fp32-rounded copy of the level matrices (the CG's "
+                         "own product, residuals, vectors and all arithmetic stay fp64); opt-in, not the headline setting")
     ap.add_argument("--slabs", type=int, default=1, help="diagnostic: cut the mesh into this many slabs on ONE GPU")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N GPUs: weak = every GPU gets its own cells^3 block of the beam (cells x cells x N*cells, default); "
@@ -121,6 +124,8 @@ def main():
                   beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=rank, world=world, unique_id=uid,
                   slabs=args.slabs if world == 1 else 1)
     G.set_tuning("precond", 1 if args.precond == "mg" else 0)
+    if args.precond_storage == "f32":
+        G.set_tuning("precond_storage", 32)
     nnzb = G.nnz // 9
     traction = (0.0, -2e3, 0.0)
 
@@ -187,6 +192,7 @@ def main():
                 "preconditioner": "geometric multigrid V-cycle (Chebyshev-Jacobi smoothing, re-assembled coarse levels; Q2 and "
                                   "Q1 levels of the fine cells distributed over the slabs, coarser levels replicated)"
                 if args.precond == "mg" else "Jacobi",
+                "preconditioner_storage": args.precond_storage,
                 "n_dofs": G.n,
                 "nnz": G.nnz,
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs emulated on one GPU" % args.slabs) if world == 1 else

@@ -212,7 +212,7 @@ namespace mi_detail
       return;
     const int t = tic(c->team->members[0], MI_T_SELL_COPY);
     mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
-                           c->d_sell_vals, c->stream);
+                           c->d_sell_vals, c->precond_storage == 32 ? c->d_sell_vals32 : nullptr, c->stream);
     toc(c->team->members[0], t);
     c->sell_stale = false;
   }
@@ -220,12 +220,14 @@ namespace mi_detail
   // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
   // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
-                    int part)
+                    int part, bool smoother)
   {
     if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
       {
         refresh_sell(c);
         mi::SellParams p   = sell_params(c, x, y, dotv, partials, done);
+        if (smoother && c->precond_storage == 32 && c->d_sell_vals32 && !c->active_sell_vals)
+          p.vals32 = c->d_sell_vals32;
         const int32_t  nin = int32_t(c->mesh.sell_nslices_interior), nbd = int32_t(c->mesh.sell_nslices) - nin;
         if (part != 2 && nin > 0)
           {
@@ -250,14 +252,14 @@ namespace mi_detail
   // y = K x on every slab of the team with the ghost planes of x exchanged on the way: the halo travels (RCCL: on
   // the team's communication stream) while the interior rows are computed; the boundary rows follow it.
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
-                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion)
+                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother)
   {
     auto launch = [&](int part) {
       for (size_t k = 0; k < T.members.size(); ++k)
         {
           mi_ctx *m = T.members[k];
           enqueue_spmv(ctx_of(m), x_of(m), y_of(m), fusion ? fusion[k].dotv : nullptr,
-                       fusion ? fusion[k].partials : nullptr, fusion ? fusion[k].done : nullptr, part);
+                       fusion ? fusion[k].partials : nullptr, fusion ? fusion[k].done : nullptr, part, smoother);
         }
     };
     if (T.size == 1)
@@ -606,6 +608,21 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // fp32-rounded copy of the sliced-ELL values for the multigrid smoother (the CG's own product, residuals and all
+  // arithmetic stay fp64); 64 drops it again
+  int set_precond_storage(mi_ctx *c, int bits)
+  {
+    if (bits == 32 && !c->d_sell_vals32)
+      {
+        const size_t cnt = std::max<size_t>(1, size_t(c->mesh.sell_nblk64) * 64 * size_t(c->dim) * c->dim);
+        HIPCHK(c, hipMalloc((void **)&c->d_sell_vals32, cnt * sizeof(float)));
+        HIPCHK(c, hipMemsetAsync(c->d_sell_vals32, 0, cnt * sizeof(float), c->stream));
+      }
+    c->precond_storage = bits;
+    c->sell_stale      = true; // refreshed (both copies) before the next product
+    return mg_set_storage(c, bits);
+  }
+
   void destroy_member(mi_ctx *c)
   {
     if (!c)
@@ -621,7 +638,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1483,6 +1500,12 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->asm_variant = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
         m->mg_lag = value;
+      else if (k == "precond_storage" && (value == 64 || value == 32))
+        {
+          const int rc = set_precond_storage(m, value);
+          if (rc)
+            return rc;
+        }
       else if (k == "precond" && (value == 0 || value == 1))
         {
           m->precond = value;

@@ -82,6 +82,8 @@ struct mi_ctx
   int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr;
   int64_t  *d_sell_off = nullptr;
   double   *d_sell_vals = nullptr;
+  float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
+  int       precond_storage = 64;
   uint16_t *d_off   = nullptr;
   uint8_t  *d_cmask = nullptr;
   double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
@@ -138,8 +140,10 @@ namespace mi_detail
   int  sync(mi_ctx *c);
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
                              const int32_t *done);
+  // smoother: the product belongs to the multigrid preconditioner and may use the fp32-rounded copy of the values
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
-                    int part = 0);
+                    int part = 0, bool smoother = false);
+  int  set_precond_storage(mi_ctx *c, int bits); // 64 | 32, for the context and its multigrid levels
   // Jacobi-PCG on the active matrix (all slabs of the team): x = vector x_id (warm start), b = vector b_id;
   // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
   int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res);
@@ -164,7 +168,8 @@ namespace mi_detail
                       const std::function<mi_ctx *(mi_ctx *)> &ctx_of = nullptr);
   int team_halo_end(Team &T);
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
-                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion);
+                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother = false);
+  int mg_set_storage(mi_ctx *c, int bits); // mi_mg.cpp: forwards to the level contexts
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);
 
 #define HIPCHK(ctx, call)                                                                                   \

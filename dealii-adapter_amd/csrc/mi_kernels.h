@@ -46,6 +46,7 @@ namespace mi
     const int64_t *off;  // [nslices+1]
     const int32_t *col;  // [nblk64*64]
     const double  *vals; // [nblk64*DD*64]
+    const float   *vals32; // same layout, rounded to fp32: the smoother's copy (null: use vals)
     const double  *x;
     double        *y;
     const double  *dotv;
@@ -111,7 +112,7 @@ namespace mi
   void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
-                          double *sell_vals, hipStream_t s);
+                          double *sell_vals, float *sell_vals32, hipStream_t s);
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s);
   void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, int grid, hipStream_t s);

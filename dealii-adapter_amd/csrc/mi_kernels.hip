@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mi_kernels.h"
 
 namespace mi
@@ -869,7 +871,8 @@ namespace mi
   //      L2 for the gathered x), 2 = values only
   // DOT: the CG's q = K p with the fused partials of p.q -- a separate instantiation so that profilers list the
   //      product the roofline figure is quoted on apart from the preconditioner's products
-  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false>
+  // F32: the matrix values come from the fp32-rounded copy (smoother only); all arithmetic stays fp64
+  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false, bool F32 = false>
   __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
@@ -889,7 +892,9 @@ namespace mi
         const int64_t off = prm.off[sl];
         const int     node = prm.perm[int64_t(sl) * 64 + lane];
         const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
-        const double *__restrict__ vp  = prm.vals + off * (DD * 64) + lane;
+        using VT = typename std::conditional<F32, float, double>::type;
+        const VT *__restrict__ vp = (F32 ? reinterpret_cast<const VT *>(prm.vals32) : reinterpret_cast<const VT *>(prm.vals)) +
+                                    off * (DD * 64) + lane;
         double acc[D];
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -968,7 +973,8 @@ namespace mi
   // block-CSR -> sliced-ELL copy of the values (after every assembly); one wavefront per slice
   template <int D>
   __global__ __launch_bounds__(256) void bsr_to_sell(SellParams prm, const int32_t *__restrict__ rowptr,
-                                                     const double *__restrict__ bsr_vals, double *sell_vals)
+                                                     const double *__restrict__ bsr_vals, double *sell_vals,
+                                                     float *sell_vals32)
   {
     constexpr int DD = D * D;
     const int     sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -981,6 +987,7 @@ namespace mi
     const int64_t off = prm.off[sl];
     const double *__restrict__ src = bsr_vals + int64_t(rowptr[node]) * DD;
     double *__restrict__ dst       = sell_vals + off * (DD * 64) + lane;
+    float *__restrict__ dst32      = sell_vals32 ? sell_vals32 + off * (DD * 64) + lane : nullptr;
     for (int k = 0; k < len; ++k)
       {
         double v[DD];
@@ -990,6 +997,10 @@ namespace mi
 #pragma unroll
         for (int e = 0; e < DD; ++e)
           dst[(int64_t(k) * DD + e) * 64] = v[e];
+        if (dst32)
+#pragma unroll
+          for (int e = 0; e < DD; ++e)
+            dst32[(int64_t(k) * DD + e) * 64] = float(v[e]);
       }
   }
 
@@ -1691,10 +1702,10 @@ namespace mi
 
   // unroll: 1..4 blocks in flight per lane; 5..7 = 2..4 with non-temporal matrix loads (5 is the default),
   // 8 = 2 with non-temporal values only; -1, -2 timing-only ablations
-  template <int D, bool DOT>
+  template <int D, bool DOT, bool F32 = false>
   static void sell_dispatch(const SellParams &p, int grid, hipStream_t s, int unroll)
   {
-#define MI_SELL(U, ABL, NTL) hipLaunchKernelGGL((sell_spmv<D, U, ABL, NTL, DOT>), dim3(grid), dim3(256), 0, s, p)
+#define MI_SELL(U, ABL, NTL) hipLaunchKernelGGL((sell_spmv<D, U, ABL, NTL, DOT, F32>), dim3(grid), dim3(256), 0, s, p)
     if constexpr (D == 2)
       MI_SELL(4, 0, 0);
     else
@@ -1716,19 +1727,21 @@ namespace mi
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
   {
     const bool dot = p.dotv && p.partials;
-    if (dim == 3)
+    if (p.vals32 && !dot) // smoother products on the fp32-rounded copy
+      dim == 3 ? sell_dispatch<3, false, true>(p, grid, s, unroll) : sell_dispatch<2, false, true>(p, grid, s, unroll);
+    else if (dim == 3)
       dot ? sell_dispatch<3, true>(p, grid, s, unroll) : sell_dispatch<3, false>(p, grid, s, unroll);
     else
       dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
   }
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
-                          double *sell_vals, hipStream_t s)
+                          double *sell_vals, float *sell_vals32, hipStream_t s)
   {
     const int grid = (p.nslices + 3) / 4;
     if (dim == 3)
-      hipLaunchKernelGGL((bsr_to_sell<3>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals);
+      hipLaunchKernelGGL((bsr_to_sell<3>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals, sell_vals32);
     else
-      hipLaunchKernelGGL((bsr_to_sell<2>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals);
+      hipLaunchKernelGGL((bsr_to_sell<2>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals, sell_vals32);
   }
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s)

@@ -138,7 +138,7 @@ namespace mi_detail
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipMemcpy(c->d_vals, bsr.data(), bsr.size() * sizeof(double), hipMemcpyHostToDevice));
       mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
-                             *d_sell, c->stream);
+                             *d_sell, nullptr, c->stream);
       HIPCHK(c, hipGetLastError());
       HIPCHK(c, hipStreamSynchronize(c->stream));
       return MI_OK;

@@ -213,11 +213,11 @@ namespace mi_detail
       if (is_dist(T, l))
         return team_spmv(
           T, [l](mi_ctx *m) { return m->mg->levels[l].ctx; }, x_of, [l](mi_ctx *m) { return m->mg->levels[l].q(); },
-          nullptr);
+          nullptr, true);
       for (mi_ctx *m : T.members)
         {
           MgLevel &L = m->mg->levels[l];
-          enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr);
+          enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr, 0, true);
         }
       return MI_OK;
     }
@@ -285,6 +285,19 @@ namespace mi_detail
       return MI_OK;
     }
   } // namespace
+
+  int mg_set_storage(mi_ctx *c, int bits)
+  {
+    if (!c->mg)
+      return MI_OK;
+    for (size_t l = 1; l < c->mg->levels.size(); ++l)
+      {
+        const int rc = set_precond_storage(c->mg->levels[l].ctx, bits);
+        if (rc)
+          return rc;
+      }
+    return MI_OK;
+  }
 
   void mg_destroy(mi_ctx *c)
   {

@@ -228,7 +228,9 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * "sell_unroll" 1..4; "xcd_remap" 0/1; "precond" 1 multigrid V-cycle (default), 0 Jacobi; "mg_lag" 1 coarse
  * operators kept over the Newton iterations of a step (default), 0 rebuilt after every assembly; "asm_variant"
  * element-kernel ablations; "halo_overlap" 1 ghost-plane exchange on the communication stream next to the interior
- * rows of the SpMV (default), 0 in line on the compute stream.  Unknown key / value: MI_EINVAL. */
+ * rows of the SpMV (default), 0 in line on the compute stream; "precond_storage" 64 (default) | 32: the multigrid
+ * smoother multiplies with an fp32-rounded copy of the level matrices (arithmetic, the CG's own product and its
+ * residuals stay fp64).  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 int mi_reset_timings(mi_ctx *ctx);
 int mi_get_timings(mi_ctx *ctx, mi_timings *out);

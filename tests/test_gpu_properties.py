@@ -121,3 +121,23 @@ def test_fullsize_decomposition_invariance(config3):
     rc1, its1, _ = G.cg_solve(rel_tol=1e-8)
     assert rc == 0 and rc1 == 0 and abs(its4 - its1) <= 1
     assert np.abs(G4.get(M.V_NEWTON) - G.get(M.V_NEWTON)).max() / np.abs(G.get(M.V_NEWTON)).max() < 1e-6
+
+
+def test_fp32_stored_smoother_matrix_is_only_a_preconditioner_change(config3):
+    """opt-in: the V-cycle's smoother multiplies with an fp32-rounded copy of the level matrices.  The CG operator,
+    its residual and the stopping rule stay fp64, so the solution satisfies the same true-residual bound and the
+    iteration count moves by at most a few"""
+    G = config3
+    b = G.get(M.V_RHS)
+    out = {}
+    for bits in (64, 32):
+        G.set_tuning("precond_storage", bits)
+        G.set(M.V_NEWTON, np.zeros(G.n))
+        rc, its, res = G.cg_solve(rel_tol=1e-10)
+        assert rc == 0
+        x = G.get(M.V_NEWTON)
+        assert np.linalg.norm(b - G.spmv(x)) <= 1.5e-10 * np.linalg.norm(b)  # fp64 product in mi_spmv
+        out[bits] = (x, its)
+    G.set_tuning("precond_storage", 64)
+    assert abs(out[32][1] - out[64][1]) <= 2
+    assert np.abs(out[32][0] - out[64][0]).max() / np.abs(out[64][0]).max() < 1e-7
