@@ -48,7 +48,7 @@ def main():
             G.set_tuning("asm_variant", v)
             res.setdefault(v, []).append(G.bench_assemble(args.reps))
     for v, ts in sorted(res.items()):
-        print("variant %d: median %.2f ms  min %.2f ms per assembly (memset + 8 colours + faces + diag + SELL copy)"
+        print("variant %d: median %.2f ms  min %.2f ms per assembly (memset + 8 colours + faces + diag)"
               % (v, float(np.median(ts)), float(np.min(ts))), flush=True)
 
 
