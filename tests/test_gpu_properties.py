@@ -141,3 +141,41 @@ def test_fp32_stored_smoother_matrix_is_only_a_preconditioner_change(config3):
     G.set_tuning("precond_storage", 64)
     assert abs(out[32][1] - out[64][1]) <= 2
     assert np.abs(out[32][0] - out[64][0]).max() / np.abs(out[64][0]).max() < 1e-7
+
+
+def test_headline_size_invariants():
+    """BASELINE configuration 4 (59^3 Q2 cells, the size bench.py runs): sizes of SURVEY.md section 8, bitwise
+    repeatable assembly, symmetric operator, a full Newmark step with the reference's Newton bookkeeping and a
+    true-residual check of its last linear solve, and agreement of a 2-slab decomposition"""
+    n = 59
+    G = M.Context(dim=3, degree=2, reps=(n, n, n))
+    assert (G.n, G.nnz, G.ncells) == (5055477, 952414353, 205379)
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    rc, info = G.newmark_step(tol_lin=1e-6, max_it_mult=1.0)
+    assert rc == 0 and info.converged == 1
+    assert info.assemblies == info.newton_iterations + 1  # nonlinear_elasticity.cc:446-469
+    assert 20 <= info.lin_its_total <= 80  # mesh-independent multigrid-PCG (a Jacobi-PCG needs > 1000 here)
+    u = G.get(M.V_U)
+    assert np.all(np.isfinite(u)) and np.all(u[G.constrained] == 0.0) and np.abs(u).max() > 0
+    # the state after the step: assemble twice -> identical bits (colouring, fixed reduction order)
+    G.update_acceleration()
+    rn1 = G.assemble()
+    r1 = G.get(M.V_RHS)
+    rn2 = G.assemble()
+    assert rn1 == rn2 and np.array_equal(r1, G.get(M.V_RHS))
+    rng = np.random.default_rng(99)
+    x, y = rng.standard_normal(G.n), rng.standard_normal(G.n)
+    Kx, Ky = G.spmv(x), G.spmv(y)
+    assert abs(y @ Kx - x @ Ky) / abs(y @ Kx) < 1e-11
+    G.set(M.V_NEWTON, np.zeros(G.n))
+    rc, its, res = G.cg_solve(rel_tol=1e-8)
+    assert rc == 0
+    true_res = np.linalg.norm(r1 - G.spmv(G.get(M.V_NEWTON)))
+    assert true_res <= 1.5e-8 * np.linalg.norm(r1) and abs(true_res - res) / res < 1e-3
+    # two slabs: same residual vector and the same Newton/CG bookkeeping for the same step
+    G2 = M.Context(dim=3, degree=2, reps=(n, n, n), slabs=2)
+    G2.set_interface_traction((0.0, -2e3, 0.0))
+    rc2, info2 = G2.newmark_step(tol_lin=1e-6, max_it_mult=1.0)
+    assert rc2 == 0 and info2.newton_iterations == info.newton_iterations
+    assert abs(info2.lin_its_total - info.lin_its_total) <= 2
+    assert np.abs(G2.get(M.V_U) - u).max() / np.abs(u).max() < 1e-5  # Residual = 1e-6 regime
