@@ -150,13 +150,10 @@ using namespace mi_detail;
 
 extern "C" {
 
-int mi_linear_setup(mi_ctx *c, double theta)
+// K, M, stepping matrix, load operator and body force of ONE slab: the host loops run over the slab's local cells
+// (ghost layer included), which completes every owned row exactly as the device assembly does
+static int linear_setup_member(mi_ctx *c, double theta)
 {
-  HIPCHK(c, hipSetDevice(c->device));
-  if (team_size(c) != 1)
-    return fail(c, MI_EINVAL, "the linear model is not available on a decomposed mesh");
-  if (!(theta >= 0.0 && theta <= 1.0))
-    return fail(c, MI_EINVAL, "theta must be in [0,1]");
   linear_destroy(c);
   c->linear      = new LinearModel;
   LinearModel &L = *c->linear;
@@ -336,6 +333,20 @@ int mi_linear_setup(mi_ctx *c, double theta)
   return MI_OK;
 }
 
+int mi_linear_setup(mi_ctx *c, double theta)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!(theta >= 0.0 && theta <= 1.0))
+    return fail(c, MI_EINVAL, "theta must be in [0,1]");
+  for (mi_ctx *m : c->team->members)
+    {
+      const int rc = linear_setup_member(m, theta);
+      if (rc)
+        return m == c ? rc : fail(c, rc, "%s", m->err.c_str());
+    }
+  return MI_OK;
+}
+
 int mi_linear_step(mi_ctx *c, int data_consistent, double abs_tol, int64_t max_it, int *its, double *res)
 {
   if (!c->linear)
@@ -343,74 +354,104 @@ int mi_linear_step(mi_ctx *c, int data_consistent, double abs_tol, int64_t max_i
   if (!(abs_tol > 0))
     return fail(c, MI_EINVAL, "absolute tolerance must be positive");
   HIPCHK(c, hipSetDevice(c->device));
-  LinearModel &L   = *c->linear;
-  const int    dim = c->dim, nif = int(c->mesh.iface_nodes.size());
-  // load at the interface dofs: face integral of the traction ("Stress", :383-384) or the nodal forces as
-  // they come ("Force", :385-388); interface sized, computed on the host from the last coupling data
-  double *load = c->vec(MI_V_NEWTON_UPDATE);
-  if (nif > 0)
+  Team      &T  = *c->team;
+  mi_ctx    *c0 = T.members[0];
+  const int  dim = c->dim;
+  std::vector<mi::LinearParams> ps;
+  for (mi_ctx *m : T.members)
     {
-      if (c->h_iface.size() != size_t(nif) * dim)
-        c->h_iface.assign(size_t(nif) * dim, 0.0);
-      double *stage = c->h_pinned + 64;
-      if (data_consistent)
-        for (int i = 0; i < nif; ++i)
-          for (int k = 0; k < dim; ++k)
-            {
-              double s = 0;
-              for (int32_t e = L.B_rowptr[size_t(i)]; e < L.B_rowptr[size_t(i) + 1]; ++e)
-                s += L.B_val[size_t(e)] * c->h_iface[size_t(L.B_col[size_t(e)]) * dim + k];
-              stage[i * dim + k] = s;
-            }
-      else
-        std::memcpy(stage, c->h_iface.data(), size_t(nif) * dim * sizeof(double));
-      HIPCHK(c, hipMemcpyAsync(c->d_iface_buf, stage, size_t(nif) * dim * sizeof(double), hipMemcpyHostToDevice,
-                               c->stream));
-      mi::launch_scatter_nodes(dim, load, c->d_iface_nodes, nif, c->d_iface_buf, c->stream);
+      LinearModel &L   = *m->linear;
+      const int    nif = int(m->mesh.iface_nodes.size());
+      // load at the interface dofs: face integral of the traction ("Stress", :383-384) or the nodal forces as
+      // they come ("Force", :385-388); interface sized, computed on the host from the last coupling data
+      // (c0->h_iface holds the GLOBAL interface array, iface_slot maps the slab's nodes into it)
+      double *load = m->vec(MI_V_NEWTON_UPDATE);
+      if (nif > 0)
+        {
+          if (c0->h_iface.size() != T.iface_global.size() * size_t(dim))
+            c0->h_iface.assign(T.iface_global.size() * size_t(dim), 0.0);
+          auto coupling = [&](int i, int k) { return c0->h_iface[size_t(m->iface_slot[size_t(i)]) * dim + k]; };
+          double *stage = m->h_pinned + 64;
+          for (int i = 0; i < nif; ++i)
+            for (int k = 0; k < dim; ++k)
+              {
+                double s = 0;
+                if (data_consistent)
+                  for (int32_t e = L.B_rowptr[size_t(i)]; e < L.B_rowptr[size_t(i) + 1]; ++e)
+                    s += L.B_val[size_t(e)] * coupling(L.B_col[size_t(e)], k);
+                else
+                  s = coupling(i, k);
+                stage[i * dim + k] = s;
+              }
+          HIPCHK(m, hipMemcpyAsync(m->d_iface_buf, stage, size_t(nif) * dim * sizeof(double), hipMemcpyHostToDevice,
+                                   m->stream));
+          mi::launch_scatter_nodes(dim, load, m->d_iface_nodes, nif, m->d_iface_buf, m->stream);
+        }
+      mi::LinearParams p{};
+      p.load  = load;
+      p.body  = L.body_force_enabled ? L.d_body : nullptr;
+      p.f_old = m->vec(MI_L_OLD_STRESS);
+      p.v     = m->vec(MI_L_VELOCITY);
+      p.d     = m->vec(MI_L_DISPLACEMENT);
+      p.v_old = m->vec(MI_L_OLD_VELOCITY);
+      p.d_old = m->vec(MI_L_OLD_DISPLACEMENT);
+      p.rhs   = m->vec(MI_L_SYSTEM_RHS);
+      p.w     = m->vec(MI_V_SOLUTION_DELTA);
+      p.theta = L.theta;
+      p.dt    = m->nm.delta_t;
+      p.n     = m->n; // pointwise on all local dofs: the ghost copies stay consistent
+      mi::launch_linear_rhs_prepare(p, m->stream);
+      ps.push_back(p);
     }
-  mi::LinearParams p{};
-  p.load  = load;
-  p.body  = L.body_force_enabled ? L.d_body : nullptr;
-  p.f_old = c->vec(MI_L_OLD_STRESS);
-  p.v     = c->vec(MI_L_VELOCITY);
-  p.d     = c->vec(MI_L_DISPLACEMENT);
-  p.v_old = c->vec(MI_L_OLD_VELOCITY);
-  p.d_old = c->vec(MI_L_OLD_DISPLACEMENT);
-  p.rhs   = c->vec(MI_L_SYSTEM_RHS);
-  p.w     = c->vec(MI_V_SOLUTION_DELTA);
-  p.theta = L.theta;
-  p.dt    = c->nm.delta_t;
-  p.n     = c->n;
-  mi::launch_linear_rhs_prepare(p, c->stream);
-  // M v_old and K w  (:411-420 with the two K products merged)
-  double *mv = c->work(W_R), *kw = c->work(W_Q);
-  c->active_sell_vals = L.d_M;
-  int t = tic(c, MI_T_SPMV);
-  enqueue_spmv(c, p.v_old, mv, nullptr, nullptr, nullptr);
-  toc(c, t);
-  c->active_sell_vals = L.d_K;
-  t                   = tic(c, MI_T_SPMV);
-  enqueue_spmv(c, p.w, kw, nullptr, nullptr, nullptr);
-  toc(c, t);
-  mi::launch_linear_rhs_finish(dim, p, mv, kw, c->d_cmask, c->stream);
+  // M v_old and K w  (:411-420 with the two K products merged); ghost planes of both operands are consistent
+  auto self = [](mi_ctx *m) { return m; };
+  int  rc;
+  for (mi_ctx *m : T.members)
+    m->active_sell_vals = m->linear->d_M;
+  int t = tic(c0, MI_T_SPMV);
+  rc    = team_spmv(
+    T, self, [](mi_ctx *m) { return m->vec(MI_L_OLD_VELOCITY); }, [](mi_ctx *m) { return m->work(W_R); }, nullptr);
+  toc(c0, t);
+  for (mi_ctx *m : T.members)
+    m->active_sell_vals = m->linear->d_K;
+  t = tic(c0, MI_T_SPMV);
+  if (!rc)
+    rc = team_spmv(
+      T, self, [](mi_ctx *m) { return m->vec(MI_V_SOLUTION_DELTA); }, [](mi_ctx *m) { return m->work(W_Q); }, nullptr);
+  toc(c0, t);
+  for (size_t k = 0; k < T.members.size() && !rc; ++k)
+    {
+      mi_ctx *m = T.members[k];
+      mi::launch_linear_rhs_finish(dim, ps[k], m->work(W_R), m->work(W_Q), m->d_cmask, m->stream);
+    }
   HIPCHK(c, hipGetLastError());
   // solve (:531-551): absolute tolerance, start vector = previous velocity
-  c->active_sell_vals = L.d_A;
-  c->active_dinv      = L.d_dinvA;
-  const int rc        = cg_run(c, MI_L_VELOCITY, MI_L_SYSTEM_RHS, -abs_tol, max_it, its, res);
-  c->active_sell_vals = nullptr;
-  c->active_dinv      = nullptr;
+  for (mi_ctx *m : T.members)
+    {
+      m->active_sell_vals = m->linear->d_A;
+      m->active_dinv      = m->linear->d_dinvA;
+    }
+  if (!rc)
+    rc = cg_run(c0, MI_L_VELOCITY, MI_L_SYSTEM_RHS, -abs_tol, max_it, its, res);
+  for (mi_ctx *m : T.members)
+    {
+      m->active_sell_vals = nullptr;
+      m->active_dinv      = nullptr;
+    }
   if (rc)
     return rc;
-  mi::launch_linear_update_displacement(p, c->stream); // :579-586
+  for (size_t k = 0; k < T.members.size(); ++k)
+    mi::launch_linear_update_displacement(ps[k], T.members[k]->stream); // :579-586
   HIPCHK(c, hipGetLastError());
-  return sync(c);
+  return sync(c0);
 }
 
 int mi_linear_matrix_get_csr(mi_ctx *c, int which, int64_t *rowptr, int32_t *col, double *val)
 {
   if (!c->linear || which < 0 || which > 2)
     return fail(c, MI_EINVAL, "linear model not set up or bad matrix id");
+  if (team_size(c) != 1)
+    return fail(c, MI_EINVAL, "matrix export is only available on an undecomposed mesh");
   const std::vector<double> &bv = which == 0 ? c->linear->hK : which == 1 ? c->linear->hM : c->linear->hA;
   const int                  D = c->dim, DD = D * D;
   const mi::HostMesh        &m = c->mesh;

@@ -152,6 +152,41 @@ def test_halo_overlap_is_bitwise_neutral(precond):
     assert _relmax(runs[0][3], G1.get(M.V_NEWTON)) < 1e-6
 
 
+@pytest.mark.parametrize("dim,p,reps,slabs", [(3, 1, (3, 3, 6), 3), (3, 2, (2, 2, 4), 2), (2, 3, (4, 6), 3)])
+def test_team_linear_model_steps(dim, p, reps, slabs):
+    """the linear theta-model (linear_elasticity.cc:378-586) on a decomposed mesh: host assembly per slab, both
+    products and the PCG team-wide; 4 steps incl. consistent loading, body force and the 'Force' path vs the oracle"""
+    import ctypes as C
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+    desc = O.make_desc(dim=dim, degree=p, reps=reps, hi=tuple(0.2 * r for r in reps), face_role=roles, mu=0.5e6, nu=0.4,
+                       rho=1000.0, body_force=(0.0, -9.81, 0.0), delta_t=0.005, theta=0.6)
+    P = O.LinearProblem(desc)
+    G = M.Context(dim=dim, degree=p, reps=reps, hi=tuple(0.2 * r for r in reps), face_role=roles, mu=0.5e6, nu=0.4,
+                  rho=1000.0, body_force=(0.0, -9.81, 0.0), delta_t=0.005, slabs=slabs)
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, desc.theta) == 0, L.mi_last_error(G.h)
+    ids = P.interface_nodes
+    rng = np.random.default_rng(11)
+    for step in range(4):
+        consistent = step != 2
+        t = 100.0 * rng.standard_normal((len(ids), dim))
+        P.vec(O.L_STRESS)[:] = 0
+        for c in range(dim):
+            P.vec(O.L_STRESS)[ids * dim + c] = t[:, c]
+        G.set_interface_traction(t)
+        assert P.step(O.SOLVER_DIRECT, consistent)[0] == 0
+        its, res = C.c_int(0), C.c_double(0)
+        rc = L.mi_linear_step(G.h, int(consistent), 1e-12, G.n * 4, C.byref(its), C.byref(res))
+        assert rc == 0, L.mi_last_error(G.h)
+        assert res.value <= 1e-12 and its.value > 0
+        for vo, vg in ((O.L_D, 0), (O.L_V, 2), (O.L_V_OLD, 3), (O.L_STRESS_OLD, 4)):
+            ref = P.vec(vo)
+            assert _relmax(G.get(vg), ref) < 1e-8
+    assert np.all(G.get(2)[P.constrained] == 0)
+
+
 def test_too_many_slabs_is_an_error():
     with pytest.raises(M.MiError) as e:
         M.Context(dim=3, degree=1, reps=(2, 2, 2), slabs=3)
