@@ -242,7 +242,9 @@ namespace mi
       s.local_face_role[f] = face_role[f];
     if (rank > 0)
       s.local_face_role[2 * zd] = 0; // interior cut, not a boundary
-    if (ghost_above)
+    // the top of the local box is an interior cut unless the ghost layer is the topmost cell layer of the mesh:
+    // then its far plane carries the real boundary role (its Dirichlet bits decide which columns the owned rows drop)
+    if (ghost_above && s.z1 + 1 < reps[zd])
       s.local_face_role[2 * zd + 1] = 0;
     return s;
   }

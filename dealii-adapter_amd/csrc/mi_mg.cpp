@@ -270,6 +270,13 @@ namespace mi_detail
           HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc + 14, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
           HIPCHK(c0, hipStreamSynchronize(c0->stream));
           const double nw = std::sqrt(c0->h_pinned[0]); // |D^-1 A v|, equal to lambda once |v| = 1
+          if (nw == 0.0)
+            {
+              // no unconstrained dof on this level (e.g. a one-cell coarse mesh between two clamped sides): the
+              // operator is its own diagonal there, D^-1 A = I
+              lam = 1.0;
+              break;
+            }
           if (!(nw > 0.0) || !std::isfinite(nw))
             return fail(c0, MI_EINVAL, "multigrid: power iteration broke down on level %d", int(l));
           lam = nw;

@@ -248,6 +248,8 @@ class Problem:
     @property
     def interface_nodes(self):
         k = lib().orc_n_interface_nodes(self.h)
+        if k == 0:  # an empty std::vector hands out a null pointer
+            return np.zeros(0, dtype=np.int32)
         return np.ctypeslib.as_array(lib().orc_interface_nodes(self.h), shape=(k,)).copy()
 
     def csr(self):
@@ -331,6 +333,8 @@ class LinearProblem:
     @property
     def interface_nodes(self):
         k = lib().orc_linear_n_interface_nodes(self.h)
+        if k == 0:
+            return np.zeros(0, dtype=np.int32)
         return np.ctypeslib.as_array(lib().orc_linear_interface_nodes(self.h), shape=(k,)).copy()
 
     def step(self, solver=SOLVER_DIRECT, data_consistent=True):
