@@ -85,3 +85,73 @@ def test_random_configuration_newmark_step(seed):
     for k in (M.V_U, M.V_V, M.V_A):
         ref = P.vec(k)
         assert np.abs(G.get(k) - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-300), (seed, k)
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_random_linear_model(seed):
+    """the linear theta-model on random configurations (incl. slabs): 3 steps with random coupling data, alternating
+    the 'Stress' (consistent) and 'Force' paths, against the oracle's direct solve"""
+    import ctypes as C
+    rng, dim, p, reps, lo, hi, roles, kw, perturb, slabs, h = _case(seed)
+    theta = float(rng.uniform(0.5, 1.0))
+    lin_kw = dict(mu=kw["mu"], nu=kw["nu"], rho=max(kw["rho"], 1.0), body_force=kw["body_force"], delta_t=kw["delta_t"])
+    P = O.LinearProblem(O.make_desc(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, theta=theta, **lin_kw))
+    G = M.Context(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, slabs=slabs, **lin_kw)
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, theta) == 0, L.mi_last_error(G.h)
+    ids = P.interface_nodes
+    for step in range(3):
+        consistent = step != 1
+        t = kw["mu"] * 1e-4 * rng.standard_normal((len(ids), dim))
+        P.vec(O.L_STRESS)[:] = 0
+        for c in range(dim):
+            P.vec(O.L_STRESS)[ids * dim + c] = t[:, c]
+        G.set_interface_traction(t)
+        assert P.step(O.SOLVER_DIRECT, consistent)[0] == 0
+        its, res = C.c_int(0), C.c_double(0)
+        scale = max(np.abs(P.vec(O.L_RHS)).max(), 1e-30)
+        rc = L.mi_linear_step(G.h, int(consistent), 1e-13 * scale, G.n * 10, C.byref(its), C.byref(res))
+        assert rc == 0, L.mi_last_error(G.h)
+        for vo, vg in ((O.L_D, 0), (O.L_V, 2)):
+            ref = P.vec(vo)
+            assert np.abs(G.get(vg) - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-300), (seed, step, vo)
+
+
+@pytest.mark.parametrize("seed", range(200, 214))
+def test_random_multigrid_solve(seed):
+    """multigrid-PCG on random mid-size configurations (anisotropic cell counts and sizes, distorted cells, random
+    Dirichlet sides, slabs): converges without the Jacobi fallback, to the same solution as Jacobi-PCG, in a bounded
+    number of iterations that does not depend on the number of slabs"""
+    rng = np.random.default_rng(seed)
+    dim = 3 if seed % 3 else 2
+    p = int(rng.integers(1, 3)) if dim == 3 else int(rng.integers(1, 4))
+    reps = tuple(int(rng.integers(4, 11 if dim == 3 else 25)) for _ in range(dim))
+    hcell = rng.uniform(0.02, 0.1, dim)
+    hi = tuple(float(hcell[d] * reps[d]) for d in range(dim))
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, int(rng.choice([0, O.FACE_CLAMPED, O.FACE_INTERFACE])), O.FACE_INTERFACE,
+             int(rng.choice([O.FACE_ZCLAMP, O.FACE_INTERFACE])), int(rng.choice([O.FACE_ZCLAMP, O.FACE_INTERFACE]))]
+    kw = dict(mu=float(10 ** rng.uniform(5, 7)), nu=float(rng.uniform(0.2, 0.45)), rho=float(rng.uniform(100, 3000)),
+              delta_t=float(10 ** rng.uniform(-3, -1)))
+    nverts = int(np.prod([r + 1 for r in reps]))
+    perturb = 0.1 * hcell.min() * rng.uniform(-1, 1, (nverts, dim))
+    slabs = int(rng.integers(2, 5))
+    sols, its = {}, {}
+    for tag, s, precond in (("mg1", 1, 1), ("mgN", slabs, 1), ("jac", 1, 0)):
+        G = M.Context(dim=dim, degree=p, reps=reps, hi=hi, face_role=roles, perturb=perturb, slabs=s, **kw)
+        G.set_tuning("precond", precond)
+        r2 = np.random.default_rng(seed + 1)
+        G.set(M.V_U, 0.01 * hcell.min() / p * r2.standard_normal(G.n) * ~G.constrained)
+        ids, _ = G.interface()
+        G.set_interface_traction(kw["mu"] * 1e-3 * r2.standard_normal((len(ids), dim)))
+        G.update_acceleration()
+        G.assemble()
+        rc, n_it, res = G.cg_solve(rel_tol=1e-9, max_it=20000 if precond == 0 else 150)
+        assert rc == 0, (seed, tag)
+        sols[tag], its[tag] = G.get(M.V_NEWTON), n_it
+    scale = np.abs(sols["jac"]).max()
+    assert np.abs(sols["mg1"] - sols["jac"]).max() / scale < 1e-6
+    assert np.abs(sols["mgN"] - sols["jac"]).max() / scale < 1e-6
+    assert abs(its["mgN"] - its["mg1"]) <= 2, (seed, its)
+    assert its["mg1"] <= 60, (seed, its, dim, p, reps)
