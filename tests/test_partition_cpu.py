@@ -207,3 +207,38 @@ def test_spmv_rows_interior_first(dim, p, reps, size):
             assert 0 < n_int < rows.size
     rows, n_int = M.partition_spmv_rows(md, 0, 1)
     assert n_int == rows.size  # undecomposed: a single launch over all rows
+
+
+def test_random_partitions_tile_and_order_rows():
+    """40 seeded random (dim, degree, cells, ranks): owned ranges tile the global node range, halo ranges pair up,
+    the SpMV rows are exactly the owned rows with the ghost-reading ones last"""
+    rng = np.random.default_rng(77)
+    for _ in range(40):
+        dim = int(rng.integers(2, 4))
+        p = int(rng.integers(1, 5 if dim == 2 else 3))
+        reps = tuple(int(rng.integers(1, 7)) for _ in range(dim))
+        size = int(rng.integers(1, reps[-1] + 1))
+        md = _md(dim, p, reps, tuple(0.1 * r for r in reps))
+        covered = 0
+        infos = [M.partition_describe(md, r, size) for r in range(size)]
+        for r, s in enumerate(infos):
+            assert s.node_offset + s.own_begin == covered
+            covered = s.node_offset + s.own_end
+            if r + 1 < size:
+                nxt = infos[r + 1]
+                assert (s.up_send_n, s.up_recv_n) == (nxt.down_recv_n, nxt.down_send_n) == (s.plane_nodes, p * s.plane_nodes)
+                assert s.node_offset + s.up_send == nxt.node_offset + nxt.down_recv
+                assert s.node_offset + s.up_recv == nxt.node_offset + nxt.down_send
+            rows, n_int = M.partition_spmv_rows(md, r, size)
+            real = rows[rows >= 0]
+            assert np.array_equal(np.sort(real), np.arange(s.own_begin, s.own_end)), (dim, p, reps, size, r)
+            plane = rows // s.plane_nodes
+            lo_plane, hi_plane = s.own_begin // s.plane_nodes, s.own_end // s.plane_nodes
+            bnd = np.zeros(rows.size, dtype=bool)
+            if s.down_recv_n > 0:
+                bnd |= (plane >= lo_plane) & (plane < lo_plane + p)
+            if s.up_recv_n > 0:
+                bnd |= plane == hi_plane - 1
+            ok = rows >= 0
+            assert np.array_equal((np.arange(rows.size) >= n_int)[ok], bnd[ok]), (dim, p, reps, size, r)
+        assert covered == infos[0].nnodes_global
