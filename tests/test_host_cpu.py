@@ -49,3 +49,22 @@ def test_no_device_is_a_loud_error(host_built, tmp_path):
         (tmp_path / f).write_text(open(os.path.join(case, f)).read())
     out = subprocess.run([os.path.join(HOST, "elasticity")], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 1 and "no HIP device" in out.stderr
+
+
+def test_host_compiles_against_precice_v3_api():
+    """-DMI_WITH_PRECICE swaps the replay participant for <precice/precice.hpp>.  libprecice is not installed here, so
+    the sources are type-checked (g++ -fsyntax-only) against a declaration-only copy of the v3 API restricted to the
+    14 calls the reference makes (tests/precice_api/precice/precice.hpp): string_view / span<const double> /
+    span<VertexID> arguments, const-qualification and return types of every call site"""
+    import subprocess
+    host = os.path.join(ROOT, "dealii-adapter_amd", "host")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    for dim in (2, 3):
+        for src in ("elasticity.cc", "source/nonlinear_elasticity/nonlinear_elasticity.cc",
+                    "source/linear_elasticity/linear_elasticity.cc"):
+            cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Wno-unused-parameter", "-DDIM=%d" % dim,
+                   "-DMI_WITH_PRECICE", "-I" + os.path.join(ROOT, "tests", "precice_api"), "-Iinclude",
+                   "-I" + os.path.join(ROOT, "include"), "-I.", "-I" + os.path.join(rocm, "include"),
+                   "-D__HIP_PLATFORM_AMD__", src]
+            out = subprocess.run(cmd, cwd=host, capture_output=True, text=True)
+            assert out.returncode == 0 and "error" not in out.stderr, out.stderr[-3000:]
