@@ -179,3 +179,33 @@ def test_headline_size_invariants():
     assert rc2 == 0 and info2.newton_iterations == info.newton_iterations
     assert abs(info2.lin_its_total - info.lin_its_total) <= 2
     assert np.abs(G2.get(M.V_U) - u).max() / np.abs(u).max() < 1e-5  # Residual = 1e-6 regime
+
+
+def test_contexts_release_their_device_memory():
+    """create / step / destroy many contexts (single, emulated slabs, multigrid levels, linear model, fp32 smoother
+    copy, snapshots): free device memory returns to where it started"""
+    import ctypes as C
+    import torch
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+
+    def cycle(k):
+        G = M.Context(dim=3, degree=2, reps=(6, 5, 6), slabs=1 + k % 3)
+        G.set_interface_traction((0.0, -1e3, 0.0))
+        if k % 4 == 1:
+            G.set_tuning("precond_storage", 32)
+        rc, info = G.newmark_step(tol_lin=1e-8)
+        assert rc == 0 and info.converged == 1
+        G.state_save()
+        if k % 2:
+            assert L.mi_linear_setup(G.h, 0.5) == 0
+        G.close()
+
+    cycle(0)  # first use pays one-off allocations of the runtime (code objects, RCCL-free pools)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(24):
+        cycle(k)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 64 << 20, "leaked %.1f MB over 24 contexts" % ((free0 - free1) / 2 ** 20)
