@@ -486,6 +486,32 @@ namespace mi_detail
         for (size_t k = 0; k < R; ++k)
           cgs[k].z = T.members[k]->work(W_Z) + T.members[k]->own0;
       }
+    int32_t *h_flags = reinterpret_cast<int32_t *>(c0->h_pinned + 8);
+    // small problems on one slab: the whole Jacobi-PCG in ONE launch (cg_small), one host synchronisation per solve
+    // (pays while one CU can stream the matrix from the L2 faster than three launches take: ~130 GB/s vs ~18 us,
+    // i.e. up to ~1 MB of matrix values; measured with tools/small_case_latency.py)
+    if (!dist && !use_mg && c0->small_cg && max_it > 0 && (c0->spmv_variant == 3 || c0->active_sell_vals) &&
+        c0->mesh.sell_nblk64 * 64 * int64_t(c0->dim * c0->dim) * 8 <= SMALL_CG_MAX_MATRIX_BYTES)
+      {
+        mi::launch_cg_small(c0->dim, sell_params(c0, nullptr, nullptr, nullptr, nullptr, nullptr), cgs[0],
+                            c0->vec(b_id), tol, int(std::min<int64_t>(max_it, 2000000000)), c0->stream);
+        mi::launch_zero_constrained(c0->dim, c0->vec(x_id), c0->d_cmask, c0->n, c0->stream); // :1208
+        HIPCHK(c0, hipGetLastError());
+        HIPCHK(c0, hipMemcpyAsync(h_flags, c0->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c0->stream));
+        HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+        toc(c0, tt);
+        int e = sync(c0);
+        if (e)
+          return e;
+        if (its)
+          *its = h_flags[1];
+        if (res)
+          *res = c0->h_pinned[SC_RES];
+        if (!h_flags[0])
+          return fail(c0, MI_ENOCONV_LIN, "CG did not reach tolerance %.3e within %lld iterations (residual %.3e)",
+                      std::fabs(tol), (long long)max_it, c0->h_pinned[SC_RES]);
+        return MI_OK;
+      }
     // z = M^-1 r by the team-wide V-cycle, then the partials of r.z (and their team totals)
     auto precondition = [&]() -> int {
       int e = mg_apply(T);
@@ -529,7 +555,6 @@ namespace mi_detail
     for (size_t k = 0; k < R; ++k)
       mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
 
-    int32_t *h_flags = reinterpret_cast<int32_t *>(c0->h_pinned + 8);
     int64_t  it      = 0;
     bool     done    = false;
     auto     poll    = [&]() -> int {
@@ -781,6 +806,8 @@ namespace mi_detail
       c->spmv_variant = atoi(v);
     if (const char *v = getenv("MI_SELL_UNROLL"))
       c->sell_unroll = atoi(v);
+    if (const char *v = getenv("MI_SMALL_CG"))
+      c->small_cg = atoi(v) != 0;
     return MI_OK;
   }
 
@@ -923,9 +950,12 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     }
   mi_ctx *c0 = T->members[0];
   {
-    int precond = 1;
+    // preconditioner: the multigrid V-cycle pays off from ~150k dofs (a V-cycle is ~110 small launches, i.e. a
+    // fixed ~0.8 ms per CG iteration whatever the size; measured crossover with Jacobi-PCG between 108k and 207k
+    // dofs, tools/small_case_latency.py); below that Jacobi.  mi_set_tuning("precond") / MI_PRECOND override.
+    int precond = T->n_global >= 150000 ? 1 : 0;
     if (const char *e = getenv("MI_PRECOND"))
-      precond = atoi(e);
+      precond = atoi(e) != 0;
     for (mi_ctx *m : T->members)
       {
         m->precond = precond;
@@ -1494,6 +1524,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
             m->grid_spmv_bnd = value;
           m->grid_spmv = m->grid_spmv_int + m->grid_spmv_bnd;
         }
+      else if (k == "small_cg" && (value == 0 || value == 1))
+        m->small_cg = value;
       else if (k == "halo_overlap" && (value == 0 || value == 1))
         c->team->overlap = value;
       else if (k == "asm_variant" && value >= 0 && value <= 8)

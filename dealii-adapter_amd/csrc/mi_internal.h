@@ -33,6 +33,7 @@ namespace mi_detail
     double        *partials;
     const int32_t *done;
   };
+  constexpr int64_t SMALL_CG_MAX_MATRIX_BYTES = 1 << 20;
   struct LinearModel; // mi_linear.cpp
   struct Multigrid;   // mi_mg.cpp
 
@@ -84,6 +85,7 @@ struct mi_ctx
   double   *d_sell_vals = nullptr;
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
   int       precond_storage = 64;
+  int       small_cg = 1; // matrices up to SMALL_CG_MAX_MATRIX_BYTES on one slab: whole Jacobi-PCG in one launch
   uint16_t *d_off   = nullptr;
   uint8_t  *d_cmask = nullptr;
   double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)

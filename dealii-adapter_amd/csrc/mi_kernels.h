@@ -134,6 +134,9 @@ namespace mi
   void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s);
   void launch_cg_set_tolerance(const CgParams &c, const double *part_bb, double rel_tol, hipStream_t s);
   void launch_cg_final_check(const CgParams &c, int it, hipStream_t s);
+  // whole Jacobi-PCG in one single-workgroup launch (small problems, one slab)
+  void launch_cg_small(int dim, const SellParams &p, const CgParams &c, const double *b, double rel_tol, int max_it,
+                       hipStream_t s);
   void launch_extract_dinv(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
                            hipStream_t s);
   void launch_masked_norm(int dim, const double *v, const uint8_t *cmask, int64_t n, double *part, int grid,

@@ -1378,6 +1378,159 @@ namespace mi
       }
   }
 
+  // ------------------------------------------------------------------ whole Jacobi-PCG in one launch (small problems)
+  // The reference's own geometries have 10^2..10^4 dofs (FSI3 flap: 1,100 at the shipped degree).  There a CG
+  // iteration is three 4-microsecond launches plus a poll every 16 iterations -- pure latency.  This kernel runs the
+  // complete solve (same recurrences, stopping rule and bookkeeping as cg_init_residual / cg_update_p / sell_spmv /
+  // cg_update_xr / cg_final_check) inside ONE workgroup of 1024 threads: vectors and matrix stay in the L2, phases
+  // are separated by workgroup barriers, reductions run in a fixed order (deterministic).
+  __device__ __forceinline__ double block_sum_1024(double v, double *s_red)
+  {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+      s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w)
+      t += s_red[w];
+    return t;
+  }
+
+  // y = K x over all slices of the slab; returns this thread's share of dotv . y (0 if dotv == null)
+  template <int D>
+  __device__ __forceinline__ double small_spmv(const SellParams &prm, const double *__restrict__ x, double *y,
+                                               const double *__restrict__ dotv)
+  {
+    constexpr int DD = D * D;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double    dsum = 0.0;
+    for (int sl = wave; sl < prm.nslices; sl += 16)
+      {
+        const int     len  = prm.len[sl];
+        const int64_t off  = prm.off[sl];
+        const int     node = prm.perm[int64_t(sl) * 64 + lane];
+        const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
+        const double *__restrict__ vp  = prm.vals + off * (DD * 64) + lane;
+        double acc[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          acc[i] = 0.0;
+        // U blocks in flight per lane: the row loop is a chain of L2 round trips otherwise (same summation order)
+        constexpr int U = (D == 2) ? 8 : 4;
+        int           k = 0;
+        for (; k + U <= len; k += U)
+          {
+            int32_t c[U];
+            double  v[U][DD], xx[U][D];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+              c[u] = cp[int64_t(k + u) * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int e = 0; e < DD; ++e)
+                v[u][e] = vp[(int64_t(k + u) * DD + e) * 64];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                xx[u][j] = x[int64_t(c[u]) * D + j];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j)
+                  acc[i] += v[u][i * D + j] * xx[u][j];
+          }
+        for (; k < len; ++k)
+          {
+            const int32_t c = cp[int64_t(k) * 64];
+            double        v[DD], xx[D];
+#pragma unroll
+            for (int e = 0; e < DD; ++e)
+              v[e] = vp[(int64_t(k) * DD + e) * 64];
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              xx[j] = x[int64_t(c) * D + j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                acc[i] += v[i * D + j] * xx[j];
+          }
+        if (node >= 0)
+#pragma unroll
+          for (int i = 0; i < D; ++i)
+            {
+              y[int64_t(node) * D + i] = acc[i];
+              if (dotv)
+                dsum += acc[i] * dotv[int64_t(node) * D + i];
+            }
+      }
+    return dsum;
+  }
+
+  template <int D>
+  __global__ __launch_bounds__(1024) void cg_small(SellParams prm, CgParams c, const double *__restrict__ b,
+                                                   double rel_tol, int max_it)
+  {
+    __shared__ double s_red[16];
+    const int tid = threadIdx.x;
+    const int n   = int(c.n);
+    // r0 = b - A x0, tolerance = rel_tol * ||b|| (or |rel_tol| absolute)   (:1171-1172)
+    small_spmv<D>(prm, c.x, c.q, nullptr);
+    __syncthreads();
+    double srr = 0.0, srz = 0.0, sbb = 0.0;
+    for (int i = tid; i < n; i += 1024)
+      {
+        const double bi = b[i], ri = bi - c.q[i];
+        c.r[i]          = ri;
+        srr += ri * ri;
+        srz += ri * ri * c.dinv[i];
+        sbb += bi * bi;
+      }
+    double       rr = block_sum_1024(srr, s_red), rz = block_sum_1024(srz, s_red);
+    const double bb = block_sum_1024(sbb, s_red);
+    const double tol = rel_tol >= 0.0 ? rel_tol * sqrt(bb) : -rel_tol;
+    double       rz_prev = 1.0, res = sqrt(rr);
+    int          it = 0, done = res <= tol;
+    while (!done && it < max_it)
+      {
+        ++it;
+        const double beta = (it == 1) ? 0.0 : rz / rz_prev;
+        rz_prev           = rz;
+        for (int i = tid; i < n; i += 1024)
+          c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
+        __syncthreads();
+        const double pq    = block_sum_1024(small_spmv<D>(prm, c.p, c.q, c.p), s_red);
+        const double alpha = rz_prev / pq;
+        srr = srz = 0.0;
+        for (int i = tid; i < n; i += 1024)
+          {
+            c.x[i] += alpha * c.p[i];
+            const double ri = c.r[i] - alpha * c.q[i];
+            c.r[i]          = ri;
+            srr += ri * ri;
+            srz += ri * ri * c.dinv[i];
+          }
+        rr   = block_sum_1024(srr, s_red);
+        rz   = block_sum_1024(srz, s_red);
+        res  = sqrt(rr);
+        done = res <= tol;
+      }
+    if (tid == 0)
+      {
+        c.sc[2]    = tol;
+        c.sc[3]    = res;
+        c.sc[4]    = sqrt(bb);
+        c.flags[0] = done;
+        c.flags[1] = it;
+      }
+  }
+
   // ------------------------------------------------------------------ small vector kernels
   // dinv = 1 / diag(K); constraints.distribute afterwards keeps constrained entries of x at 0
   template <int D>
@@ -1824,6 +1977,14 @@ namespace mi
   void launch_cg_set_tolerance(const CgParams &c, const double *part_bb, double rel_tol, hipStream_t s)
   {
     hipLaunchKernelGGL(cg_set_tolerance, dim3(1), dim3(256), 0, s, c, part_bb, rel_tol);
+  }
+  void launch_cg_small(int dim, const SellParams &p, const CgParams &c, const double *b, double rel_tol, int max_it,
+                       hipStream_t s)
+  {
+    if (dim == 3)
+      hipLaunchKernelGGL((cg_small<3>), dim3(1), dim3(1024), 0, s, p, c, b, rel_tol, max_it);
+    else
+      hipLaunchKernelGGL((cg_small<2>), dim3(1), dim3(1024), 0, s, p, c, b, rel_tol, max_it);
   }
   void launch_cg_final_check(const CgParams &c, int it, hipStream_t s)
   {
