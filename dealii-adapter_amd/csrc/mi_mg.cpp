@@ -57,6 +57,7 @@ namespace mi_detail
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
     int    coarsest_reps = 1;    // stop coarsening once no direction has more cells than this
+    int    coarsen_factor = 2;   // cells per direction shrink by this factor from level to level
     double coarse_ratio  = 60.0;
     int    power_its     = 15;   // first estimate
     int    power_its_update = 4; // refresh, continuing from the previous eigenvector
@@ -339,6 +340,8 @@ namespace mi_detail
       mg->smooth_ratio = std::max(2.0, atof(e));
     if (const char *e = getenv("MI_MG_COARSEST"))
       mg->coarsest_reps = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_FACTOR"))
+      mg->coarsen_factor = std::max(2, atoi(e));
     if (const char *e = getenv("MI_MG_COARSE_DEGREE"))
       mg->coarse_degree = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_COARSE_RATIO"))
@@ -360,7 +363,7 @@ namespace mi_detail
             for (int d = 0; d < dim; ++d)
               if (reps[d] > mg->coarsest_reps)
                 {
-                  reps[d] = (reps[d] + 1) / 2;
+                  reps[d] = std::max(mg->coarsest_reps, (reps[d] + mg->coarsen_factor - 1) / mg->coarsen_factor);
                   changed = true;
                 }
             if (!changed)
