@@ -1204,7 +1204,7 @@ namespace mi
     if (i < n)
       res[i] = b[i] - q[i];
   }
-  // y = mask(x): copy the dofs inside [own0, own0+own_n), zero elsewhere (block preconditioner input)
+  // y = mask(x): copy the dofs inside [own0, own0+own_n), zero elsewhere (right-hand side of the V-cycle)
   __global__ __launch_bounds__(256) void copy_owned(double *y, const double *__restrict__ x, int64_t n, int64_t own0,
                                                     int64_t own_n)
   {

@@ -78,7 +78,7 @@ def test_team_cg_matches_undecomposed(dim, p, reps, slabs):
     rc1, its1, res1 = G1.cg_solve(rel_tol=1e-8)
     assert rc == 0 and rc1 == 0 and abs(its - its1) <= 1
     assert _relmax(G.get(M.V_NEWTON), G1.get(M.V_NEWTON)) < 1e-6
-    G.set_tuning("precond", 1)  # slab-local V-cycles as a block preconditioner
+    G.set_tuning("precond", 1)  # team-wide V-cycle: the same operator for any number of slabs
     rc, its_mg, _ = G.cg_solve(rel_tol=1e-13)
     assert rc == 0
     P.update_acceleration()
