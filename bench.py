@@ -215,6 +215,8 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_unit": "GB per launch (PMC: TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1 KiB, profiles/r01/pmc_spmv_nt_n59.json)",
+                "algorithmic_GB_per_launch": bytes_bsr / 1e9,
                 "bytes_per_launch": bytes_bsr,
                 "launches_timed": spmv_n,
                 "avg_launch_ms": spmv_avg_ms,
