@@ -1,0 +1,54 @@
+"""The driver-facing contract of bench.py and __graft_entry__.py, exercised on a small mesh: one JSON line with the
+agreed keys, roofline and cpu_baseline objects, sane values; smoke() passes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # exactly ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_json_line_contract():
+    d = _run(["--cells", "8", "--steps", "2", "--warmup", "1", "--cpu-cells", "3"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["unit"] == "DoF-updates/s" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["scaling"] in ("weak", "strong") and "workload" in d["config"] and "model" not in d["config"]
+    n = d["config"]["n_dofs"]
+    assert n == 3 * 17 ** 3
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["traffic"] is None  # the PMC passes were collected for the 59^3 workload only
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_options_and_smoke():
+    d = _run(["--cells", "6", "--steps", "1", "--warmup", "1", "--cpu-cells", "0", "--slabs", "2", "--scaling", "strong",
+              "--precond", "jacobi"])
+    assert "cpu_baseline" not in d and d["scaling"] == "strong" and "2 slabs" in d["config"]["decomposition"]
+    d = _run(["--cells", "6", "--steps", "1", "--warmup", "1", "--cpu-cells", "0", "--slabs", "2", "--precond-storage", "f32"])
+    assert d["scaling"] == "weak" and d["config"]["n_dofs"] == 3 * 13 * 13 * 25
+    out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
