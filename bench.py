@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N GPUs: weak = every GPU gets its own cells^3 block of the beam (cells x cells x N*cells, default); "
                          "strong = the one cells^3 block is cut into N slabs")
+    ap.add_argument("--no-rccl", action="store_true",
+                    help="diagnostic: with N ranks every rank solves its own copy of the single-GPU problem (no RCCL "
+                         "communicator); exercises launcher, rendezvous and reporting on a box with fewer GPUs than ranks")
     ap.add_argument("--cpu-cells", type=int, default=16, help="cells per side of the CPU-baseline sample (0: skip)")
     args = ap.parse_args()
 
@@ -108,6 +111,7 @@ def main():
     M = _pkg()
     n = args.cells
     uid = None
+    replicas = world > 1 and args.no_rccl
     if world > 1:
         # control plane (rendezvous, unique-id broadcast, barriers, max over ranks) on gloo; the data path --
         # ghost-plane send/recv and scalar all-reduces of the CG -- runs on RCCL over xGMI inside the library
@@ -115,14 +119,14 @@ def main():
         dist.init_process_group("gloo")
         box = [M.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        uid = None if replicas else box[0]
     # z-slabs, one per GPU.  weak scaling: the block grows along z with the number of GPUs (cubic cells of the same
     # size, cells^3 of them per GPU: at N=1 exactly the 59^3 case the metric names); strong: the 59^3 block is cut
-    parts = world if world > 1 else args.slabs
+    parts = args.slabs if (world == 1 or replicas) else world
     nz = n * parts if args.scaling == "weak" else n
     G = M.Context(dim=3, degree=2, reps=(n, n, nz), lo=(0, 0, 0), hi=(1, 1, nz / n), mu=0.5e6, nu=0.4, rho=1000.0,
-                  beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=rank, world=world, unique_id=uid,
-                  slabs=args.slabs if world == 1 else 1)
+                  beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
+                  world=1 if replicas else world, unique_id=uid, slabs=args.slabs if (world == 1 or replicas) else 1)
     G.set_tuning("precond", 1 if args.precond == "mg" else 0)
     if args.precond_storage == "f32":
         G.set_tuning("precond_storage", 32)
@@ -164,7 +168,8 @@ def main():
         ms_step = 1e3 * elapsed / args.steps
         spmv_ms, spmv_n = tm["spmv"]
         spmv_avg_ms = spmv_ms / max(spmv_n, 1)
-        bytes_bsr = spmv_bytes(G.nnodes, nnzb, 3) // world  # bytes of the rows this rank owns
+        share = 1 if replicas else world
+        bytes_bsr = spmv_bytes(G.nnodes, nnzb, 3) // share  # bytes of the rows this rank owns
         achieved = bytes_bsr / (spmv_avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
         # HBM traffic of the same kernel on the same workload from the committed PMC passes (rocprofv3 --pmc cannot be
         # collected from inside this process); only quoted when the workload is the one that was profiled
@@ -174,14 +179,14 @@ def main():
             traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9  # GB per launch
         out = {
             "metric": "DoF-updates/sec per Newmark step (assembly+CG), 3D Q2 ~5M DoFs",
-            "value": G.n * args.steps / elapsed,
+            "value": G.n * (world if replicas else 1) * args.steps / elapsed,
             "unit": "DoF-updates/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": "replicas" if replicas else args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -196,7 +201,8 @@ def main():
                 "n_dofs": G.n,
                 "nnz": G.nnz,
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs emulated on one GPU" % args.slabs) if world == 1 else
-                "%d z-slabs (one per GPU), ghost-cell redundant assembly, RCCL send/recv halo + all-reduce" % world,
+                ("%d independent replicas (--no-rccl diagnostic)" % world if replicas else
+                 "%d z-slabs (one per GPU), ghost-cell redundant assembly, RCCL send/recv halo + all-reduce" % world),
                 "newton_iterations_per_step": newton / args.steps,
                 "cg_iterations_per_step": cg_its / args.steps,
                 "assemblies_per_step": assemblies / args.steps,
@@ -220,7 +226,7 @@ def main():
                 "bytes_per_launch": bytes_bsr,
                 "launches_timed": spmv_n,
                 "avg_launch_ms": spmv_avg_ms,
-                "achieved_scalar_csr_equivalent": spmv_bytes_scalar_csr(G.nnodes, nnzb, 3) / world / (spmv_avg_ms * 1e-3) / 1e9
+                "achieved_scalar_csr_equivalent": spmv_bytes_scalar_csr(G.nnodes, nnzb, 3) / share / (spmv_avg_ms * 1e-3) / 1e9
                 if spmv_n else 0.0,
             },
         }

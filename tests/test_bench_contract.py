@@ -52,3 +52,25 @@ def test_bench_options_and_smoke():
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_bench_under_the_launcher_two_ranks_control_plane():
+    """the driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.  A
+    one-GPU box cannot host two RCCL ranks, so `--no-rccl` lets both ranks run their own copy of the problem: this
+    exercises RANK/LOCAL_RANK/WORLD_SIZE handling, the device choice when fewer GPUs than ranks are visible, the
+    gloo rendezvous, the unique-id broadcast, barriers, max-over-ranks timing and rank-0-only reporting"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--cells", "6", "--no-rccl"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "replicas" and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * d["config"]["n_dofs"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
