@@ -220,7 +220,7 @@ namespace mi_detail
   // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
   // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
-                    int part, bool smoother)
+                    int part, bool smoother, const ChebFusion *cheb)
   {
     if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
       {
@@ -228,6 +228,15 @@ namespace mi_detail
         mi::SellParams p   = sell_params(c, x, y, dotv, partials, done);
         if (smoother && c->precond_storage == 32 && c->d_sell_vals32 && !c->active_sell_vals)
           p.vals32 = c->d_sell_vals32;
+        if (cheb)
+          {
+            p.cheb_b    = cheb->b;
+            p.cheb_dinv = cheb->dinv;
+            p.cheb_d    = cheb->d;
+            p.cheb_xout = cheb->xout;
+            p.cheb_c1   = cheb->c1;
+            p.cheb_c2   = cheb->c2;
+          }
         const int32_t  nin = int32_t(c->mesh.sell_nslices_interior), nbd = int32_t(c->mesh.sell_nslices) - nin;
         if (part != 2 && nin > 0)
           {
@@ -252,14 +261,16 @@ namespace mi_detail
   // y = K x on every slab of the team with the ghost planes of x exchanged on the way: the halo travels (RCCL: on
   // the team's communication stream) while the interior rows are computed; the boundary rows follow it.
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
-                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother)
+                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother,
+                const ChebFusion *cheb)
   {
     auto launch = [&](int part) {
       for (size_t k = 0; k < T.members.size(); ++k)
         {
           mi_ctx *m = T.members[k];
           enqueue_spmv(ctx_of(m), x_of(m), y_of(m), fusion ? fusion[k].dotv : nullptr,
-                       fusion ? fusion[k].partials : nullptr, fusion ? fusion[k].done : nullptr, part, smoother);
+                       fusion ? fusion[k].partials : nullptr, fusion ? fusion[k].done : nullptr, part, smoother,
+                       cheb ? &cheb[k] : nullptr);
         }
     };
     if (T.size == 1)

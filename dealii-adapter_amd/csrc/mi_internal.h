@@ -34,6 +34,13 @@ namespace mi_detail
     const int32_t *done;
   };
   constexpr int64_t SMALL_CG_MAX_MATRIX_BYTES = 1 << 20;
+  // Chebyshev-Jacobi step fused into the product (multigrid smoother): see mi::SellParams
+  struct ChebFusion
+  {
+    const double *b, *dinv;
+    double       *d, *xout;
+    double        c1, c2;
+  };
   struct LinearModel; // mi_linear.cpp
   struct Multigrid;   // mi_mg.cpp
 
@@ -144,7 +151,7 @@ namespace mi_detail
                              const int32_t *done);
   // smoother: the product belongs to the multigrid preconditioner and may use the fp32-rounded copy of the values
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
-                    int part = 0, bool smoother = false);
+                    int part = 0, bool smoother = false, const ChebFusion *cheb = nullptr);
   int  set_precond_storage(mi_ctx *c, int bits); // 64 | 32, for the context and its multigrid levels
   // Jacobi-PCG on the active matrix (all slabs of the team): x = vector x_id (warm start), b = vector b_id;
   // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
@@ -170,7 +177,8 @@ namespace mi_detail
                       const std::function<mi_ctx *(mi_ctx *)> &ctx_of = nullptr);
   int team_halo_end(Team &T);
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
-                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother = false);
+                const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother = false,
+                const ChebFusion *cheb = nullptr); // cheb: one entry per member
   int mg_set_storage(mi_ctx *c, int bits); // mi_mg.cpp: forwards to the level contexts
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);
 

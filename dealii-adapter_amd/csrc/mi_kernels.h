@@ -47,6 +47,11 @@ namespace mi
     const int32_t *col;  // [nblk64*64]
     const double  *vals; // [nblk64*DD*64]
     const float   *vals32; // same layout, rounded to fp32: the smoother's copy (null: use vals)
+    // fused Chebyshev-Jacobi epilogue (multigrid smoother; cheb_d == null: plain product).  Per owned row i:
+    //   res = cheb_b - (K x); d = c1 d + c2 dinv res; cheb_xout = x + d   (x itself stays: other rows still gather it)
+    const double  *cheb_b, *cheb_dinv;
+    double        *cheb_d, *cheb_xout;
+    double         cheb_c1, cheb_c2;
     const double  *x;
     double        *y;
     const double  *dotv;

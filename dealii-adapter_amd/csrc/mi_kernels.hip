@@ -872,7 +872,8 @@ namespace mi
   // DOT: the CG's q = K p with the fused partials of p.q -- a separate instantiation so that profilers list the
   //      product the roofline figure is quoted on apart from the preconditioner's products
   // F32: the matrix values come from the fp32-rounded copy (smoother only); all arithmetic stays fp64
-  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false, bool F32 = false>
+  // CHEB: Chebyshev-Jacobi update fused into the epilogue (see SellParams), y is not written
+  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false, bool F32 = false, bool CHEB = false>
   __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
@@ -956,9 +957,18 @@ namespace mi
 #pragma unroll
             for (int i = 0; i < D; ++i)
               {
-                prm.y[int64_t(node) * D + i] = acc[i];
+                const int64_t idx = int64_t(node) * D + i;
+                if constexpr (CHEB)
+                  {
+                    const double res  = prm.cheb_b[idx] - acc[i];
+                    const double dn   = prm.cheb_c1 * prm.cheb_d[idx] + prm.cheb_c2 * prm.cheb_dinv[idx] * res;
+                    prm.cheb_d[idx]    = dn;
+                    prm.cheb_xout[idx] = prm.x[idx] + dn;
+                  }
+                else
+                  prm.y[idx] = acc[i];
                 if (DOT && node >= prm.own_begin && node < prm.own_end)
-                  dsum += acc[i] * prm.dotv[int64_t(node) * D + i];
+                  dsum += acc[i] * prm.dotv[idx];
               }
           }
       }
@@ -1880,6 +1890,18 @@ namespace mi
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
   {
     const bool dot = p.dotv && p.partials;
+    if (p.cheb_d && !dot) // smoother step: product + Chebyshev update in one launch (default load pipeline only)
+      {
+        if (dim == 3 && p.vals32)
+          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, false, true, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (dim == 3)
+          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, false, false, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (p.vals32)
+          hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, false, true, true>), dim3(grid), dim3(256), 0, s, p);
+        else
+          hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p);
+        return;
+      }
     if (p.vals32 && !dot) // smoother products on the fp32-rounded copy
       dim == 3 ? sell_dispatch<3, false, true>(p, grid, s, unroll) : sell_dispatch<2, false, true>(p, grid, s, unroll);
     else if (dim == 3)

@@ -35,12 +35,14 @@ namespace mi_detail
   {
     mi_ctx *ctx  = nullptr; // level 0: the slab itself (not owned)
     Team   *team = nullptr; // levels >= 1 own a private single-slab team (shared stream)
-    double *ws   = nullptr; // workspace: b, x, d, q, ev, r  (6 local vectors; ev = running eigenvector estimate)
+    double *ws   = nullptr; // workspace: b, x, d, q, ev, r, x'  (7 local vectors; ev = running eigenvector estimate)
+    bool    x_swapped = false; // the fused smoother step writes x' = x + d into the other of the two x buffers
     bool    ev_ready = false;
     double  lmax = 0.0;     // estimate of the largest eigenvalue of D^-1 A
     MgTransfer to_coarse;   // to level l+1
     double *b() const { return ws; }
-    double *x() const { return ws + ctx->n; }
+    double *x() const { return ws + (x_swapped ? 6 : 1) * ctx->n; }
+    double *x_other() const { return ws + (x_swapped ? 1 : 6) * ctx->n; }
     double *d() const { return ws + 2 * ctx->n; }
     double *q() const { return ws + 3 * ctx->n; }
     double *ev() const { return ws + 4 * ctx->n; }
@@ -53,6 +55,7 @@ namespace mi_detail
     size_t n_dist        = 1;    // levels [0, n_dist) are distributed over the slabs of the team, the others replicated
     int    nu            = 2;    // Chebyshev degree of the pre- and post-smoother on the finest level
     int    nu_coarse     = 2;    // ... on the coarser levels
+    int    fuse          = 1;    // Chebyshev update in the epilogue of the product (one launch per smoother step)
     int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
@@ -209,16 +212,17 @@ namespace mi_detail
 
     // q = A_l x on level l of every slab: distributed levels exchange the ghost planes of x (overlapped with the
     // interior rows), the coarser levels are replicated
-    int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of)
+    int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of, const ChebFusion *cheb = nullptr)
     {
       if (is_dist(T, l))
         return team_spmv(
           T, [l](mi_ctx *m) { return m->mg->levels[l].ctx; }, x_of, [l](mi_ctx *m) { return m->mg->levels[l].q(); },
-          nullptr, true);
-      for (mi_ctx *m : T.members)
+          nullptr, true, cheb);
+      for (size_t k = 0; k < T.members.size(); ++k)
         {
+          mi_ctx  *m = T.members[k];
           MgLevel &L = m->mg->levels[l];
-          enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr, 0, true);
+          enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr, 0, true, cheb ? &cheb[k] : nullptr);
         }
       return MI_OK;
     }
@@ -334,6 +338,8 @@ namespace mi_detail
       mg->nu = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_NU_COARSE"))
       mg->nu_coarse = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_FUSE"))
+      mg->fuse = atoi(e) != 0;
     if (const char *e = getenv("MI_MG_KIND"))
       mg->kind = atoi(e) == 4 ? 4 : 1;
     if (const char *e = getenv("MI_MG_RATIO"))
@@ -404,8 +410,8 @@ namespace mi_detail
     for (size_t l = 0; l < mg->levels.size(); ++l)
       {
         MgLevel &L = mg->levels[l];
-        HIPCHK(c, hipMalloc((void **)&L.ws, size_t(6) * size_t(L.ctx->n) * sizeof(double)));
-        HIPCHK(c, hipMemsetAsync(L.ws, 0, size_t(6) * size_t(L.ctx->n) * sizeof(double), c->stream));
+        HIPCHK(c, hipMalloc((void **)&L.ws, size_t(7) * size_t(L.ctx->n) * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(L.ws, 0, size_t(7) * size_t(L.ctx->n) * sizeof(double), c->stream));
         if (l + 1 < mg->levels.size())
           {
             // slab -> replicated level: ownership-aware tables; slab -> slab and box -> box: plain local tables
@@ -483,11 +489,6 @@ namespace mi_detail
       for (int j = 0; j < k; ++j)
         {
           const bool first = (j == 0), skip_spmv = first && zero_start;
-          if (!skip_spmv)
-            {
-              if ((rc = level_spmv(T, l, x_of)))
-                return rc;
-            }
           double c1, c2;
           if (first)
             {
@@ -501,6 +502,26 @@ namespace mi_detail
               c2               = 2.0 * rho / delta;
               rho_old          = rho;
             }
+          bool fused = !skip_spmv && T.members[0]->mg->fuse;
+          for (mi_ctx *m : T.members)
+            fused = fused && m->mg->levels[l].ctx->spmv_variant == 3;
+          if (fused)
+            {
+              // one launch: q = A x, d = c1 d + c2 D^-1 (b - q), x' = x + d written to the other x buffer
+              std::vector<ChebFusion> cf;
+              for (mi_ctx *m : T.members)
+                {
+                  MgLevel &L = m->mg->levels[l];
+                  cf.push_back(ChebFusion{L.b(), L.ctx->work(W_DINV), L.d(), L.x_other(), c1, c2});
+                }
+              if ((rc = level_spmv(T, l, x_of, cf.data())))
+                return rc;
+              for (mi_ctx *m : T.members)
+                m->mg->levels[l].x_swapped = !m->mg->levels[l].x_swapped;
+              continue;
+            }
+          if (!skip_spmv && (rc = level_spmv(T, l, x_of)))
+            return rc;
           for (mi_ctx *m : T.members)
             {
               MgLevel      &L  = m->mg->levels[l];
