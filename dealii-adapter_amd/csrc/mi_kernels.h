@@ -49,6 +49,7 @@ namespace mi
     const float   *vals32; // same layout, rounded to fp32: the smoother's copy (null: use vals)
     // fused Chebyshev-Jacobi epilogue (multigrid smoother; cheb_d == null: plain product).  Per owned row i:
     //   res = cheb_b - (K x); d = c1 d + c2 dinv res; cheb_xout = x + d   (x itself stays: other rows still gather it)
+    // cheb_b set but cheb_d null: residual mode, y = cheb_b - K x
     const double  *cheb_b, *cheb_dinv;
     double        *cheb_d, *cheb_xout;
     double         cheb_c1, cheb_c2;

@@ -960,10 +960,15 @@ namespace mi
                 const int64_t idx = int64_t(node) * D + i;
                 if constexpr (CHEB)
                   {
-                    const double res  = prm.cheb_b[idx] - acc[i];
-                    const double dn   = prm.cheb_c1 * prm.cheb_d[idx] + prm.cheb_c2 * prm.cheb_dinv[idx] * res;
-                    prm.cheb_d[idx]    = dn;
-                    prm.cheb_xout[idx] = prm.x[idx] + dn;
+                    const double res = prm.cheb_b[idx] - acc[i];
+                    if (prm.cheb_d)
+                      {
+                        const double dn    = prm.cheb_c1 * prm.cheb_d[idx] + prm.cheb_c2 * prm.cheb_dinv[idx] * res;
+                        prm.cheb_d[idx]    = dn;
+                        prm.cheb_xout[idx] = prm.x[idx] + dn;
+                      }
+                    else
+                      prm.y[idx] = res; // residual mode: y = b - K x
                   }
                 else
                   prm.y[idx] = acc[i];
@@ -1890,7 +1895,7 @@ namespace mi
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
   {
     const bool dot = p.dotv && p.partials;
-    if (p.cheb_d && !dot) // smoother step: product + Chebyshev update in one launch (default load pipeline only)
+    if ((p.cheb_d || p.cheb_b) && !dot) // smoother step / residual fused into the product (default load pipeline only)
       {
         if (dim == 3 && p.vals32)
           hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, false, true, true>), dim3(grid), dim3(256), 0, s, p);

@@ -55,7 +55,9 @@ namespace mi_detail
     size_t n_dist        = 1;    // levels [0, n_dist) are distributed over the slabs of the team, the others replicated
     int    nu            = 2;    // Chebyshev degree of the pre- and post-smoother on the finest level
     int    nu_coarse     = 2;    // ... on the coarser levels
-    int    fuse          = 1;    // Chebyshev update in the epilogue of the product (one launch per smoother step)
+    int    fuse          = 1;    // Chebyshev update / residual in the epilogue of the product (one launch instead of two):
+                                 // 0 never, 1 on the latency-bound levels (<= fuse_max_nodes), 2 on every level
+    int64_t fuse_max_nodes = 100000;
     int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
@@ -339,7 +341,7 @@ namespace mi_detail
     if (const char *e = getenv("MI_MG_NU_COARSE"))
       mg->nu_coarse = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_FUSE"))
-      mg->fuse = atoi(e) != 0;
+      mg->fuse = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("MI_MG_KIND"))
       mg->kind = atoi(e) == 4 ? 4 : 1;
     if (const char *e = getenv("MI_MG_RATIO"))
@@ -477,6 +479,21 @@ namespace mi_detail
 
   namespace
   {
+    // whether level l runs its smoother steps and residual as fused products (see Multigrid::fuse)
+    bool fuse_level(Team &T, size_t l)
+    {
+      const Multigrid &mg0 = *T.members[0]->mg;
+      if (mg0.fuse == 0)
+        return false;
+      for (mi_ctx *m : T.members)
+        {
+          const mi_ctx *lc = m->mg->levels[l].ctx;
+          if (lc->spmv_variant != 3 || (mg0.fuse == 1 && lc->mesh.nnodes > mg0.fuse_max_nodes))
+            return false;
+        }
+      return true;
+    }
+
     // k Chebyshev-Jacobi steps on level l for A x = b over [lmax/ratio, lmax]; zero_start: x = 0 on entry.
     // Level 0 runs on all slabs in lockstep (halo exchange of x before every SpMV, update on the owned dofs).
     int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start)
@@ -502,9 +519,7 @@ namespace mi_detail
               c2               = 2.0 * rho / delta;
               rho_old          = rho;
             }
-          bool fused = !skip_spmv && T.members[0]->mg->fuse;
-          for (mi_ctx *m : T.members)
-            fused = fused && m->mg->levels[l].ctx->spmv_variant == 3;
+          bool fused = !skip_spmv && fuse_level(T, l);
           if (fused)
             {
               // one launch: q = A x, d = c1 d + c2 D^-1 (b - q), x' = x + d written to the other x buffer
@@ -607,13 +622,24 @@ namespace mi_detail
       auto ctx_l  = [l](mi_ctx *m) { return m->mg->levels[l].ctx; };
       auto ctx_c  = [l](mi_ctx *m) { return m->mg->levels[l + 1].ctx; };
       auto xc_of  = [l](mi_ctx *m) { return m->mg->levels[l + 1].x(); };
-      if ((rc = level_spmv(T, l, x_of)))
-        return rc;
-      for (mi_ctx *m : T.members)
+      if (fuse_level(T, l))
         {
-          MgLevel &L = m->mg->levels[l];
-          mi::launch_vec_residual(L.q() + L.ctx->own0, L.b() + L.ctx->own0, L.q() + L.ctx->own0, L.ctx->own_n,
-                                  L.ctx->stream); // q = b - A x (owned)
+          std::vector<ChebFusion> cf; // residual mode of the fused epilogue: q = b - A x on the owned rows
+          for (mi_ctx *m : T.members)
+            cf.push_back(ChebFusion{m->mg->levels[l].b(), nullptr, nullptr, nullptr, 0.0, 0.0});
+          if ((rc = level_spmv(T, l, x_of, cf.data())))
+            return rc;
+        }
+      else
+        {
+          if ((rc = level_spmv(T, l, x_of)))
+            return rc;
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel &L = m->mg->levels[l];
+              mi::launch_vec_residual(L.q() + L.ctx->own0, L.b() + L.ctx->own0, L.q() + L.ctx->own0, L.ctx->own_n,
+                                      L.ctx->stream); // q = b - A x (owned)
+            }
         }
       // restriction.  distributed -> distributed (same slabs): the ghost planes of the residual come from the
       // neighbours, every owned coarse node then sums its complete fine neighbourhood.  distributed -> replicated:
