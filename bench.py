@@ -212,9 +212,10 @@ def main():
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
             },
             "roofline": {
-                "kernel": "sell_spmv<3,2,0,1,true> (the CG's q = K p with fused p.q partials on the sliced-ELL copy of the "
-                          "block-CSR tangent, non-temporal matrix loads; the preconditioner's products run the "
-                          "<...,false> instantiation of the same kernel)",
+                "kernel": "sell_spmv<3,2,0,1,true,false,false> = <D=3, 2 blocks in flight, no ablation, non-temporal matrix "
+                          "loads, DOT=true, fp64 values, no fused smoother update>: the CG's q = K p with fused p.q partials on "
+                          "the sliced-ELL copy of the block-CSR tangent; the preconditioner's products run DOT=false "
+                          "instantiations of the same kernel",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
