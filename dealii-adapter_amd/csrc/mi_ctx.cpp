@@ -236,6 +236,7 @@ namespace mi_detail
             p.cheb_xout = cheb->xout;
             p.cheb_c1   = cheb->c1;
             p.cheb_c2   = cheb->c2;
+            p.cheb_blk  = cheb->blk;
           }
         const int32_t  nin = int32_t(c->mesh.sell_nslices_interior), nbd = int32_t(c->mesh.sell_nslices) - nin;
         if (part != 2 && nin > 0)
@@ -423,6 +424,12 @@ namespace mi_detail
       }
     toc(c0, t0);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
+    if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
+      {
+        if (!c->d_dinv_blk)
+          HIPCHK(c, hipMalloc((void **)&c->d_dinv_blk, size_t(c->mesh.nnodes) * c->dim * c->dim * sizeof(double)));
+        mi::launch_extract_dinv_blk(c->dim, c->d_vals, c->d_diagpos, c->d_dinv_blk, c->mesh.nnodes, c->stream);
+      }
     c->sell_stale = true; // the SpMV-side copy is refreshed by the first product that needs it (enqueue_spmv)
     HIPCHK(c, hipGetLastError());
     c->mg_stale = true; // the coarse operators belong to an older state
@@ -674,7 +681,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk};
     for (void *p : ptrs)
       if (p)
         hipFree(p);

@@ -40,6 +40,7 @@ namespace mi_detail
     const double *b, *dinv;
     double       *d, *xout;
     double        c1, c2;
+    int           blk = 0; // dinv = DxD blocks per node
   };
   struct LinearModel; // mi_linear.cpp
   struct Multigrid;   // mi_mg.cpp
@@ -90,6 +91,8 @@ struct mi_ctx
   int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr;
   int64_t  *d_sell_off = nullptr;
   double   *d_sell_vals = nullptr;
+  double   *d_dinv_blk = nullptr; // inverse diagonal blocks (block-Jacobi smoother), allocated when it is switched on
+  bool      want_dinv_blk = false;
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
   int       precond_storage = 64;
   int       small_cg = 1; // matrices up to SMALL_CG_MAX_MATRIX_BYTES on one slab: whole Jacobi-PCG in one launch

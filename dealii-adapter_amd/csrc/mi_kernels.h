@@ -53,6 +53,7 @@ namespace mi
     const double  *cheb_b, *cheb_dinv;
     double        *cheb_d, *cheb_xout;
     double         cheb_c1, cheb_c2;
+    int32_t        cheb_blk; // 1: cheb_dinv holds DxD inverse diagonal blocks per node (block-Jacobi)
     const double  *x;
     double        *y;
     const double  *dotv;
@@ -126,6 +127,11 @@ namespace mi
                           double s0, int64_t n, hipStream_t s);
   void launch_cheb4_step(double *x, double *d, double *r, const double *q, const double *dinv, double beta, double ca,
                          double cb, int64_t n, hipStream_t s);
+  void launch_extract_dinv_blk(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
+                               hipStream_t s);
+  void launch_blk_apply(int dim, double *out, const double *a, const double *dinv, int64_t nnodes, hipStream_t s);
+  void launch_cheb_step_blk(int dim, double *x, double *d, const double *b, const double *q, const double *dinv,
+                            double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);
   void launch_cheb_step(double *x, double *d, const double *b, const double *q, const double *dinv, double c1, double c2,
                         int64_t n, hipStream_t s);
   void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st);

@@ -954,21 +954,35 @@ namespace mi
           }
         if (node >= 0)
           {
+            double res[D];
+            if constexpr (CHEB)
+              {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                  res[i] = prm.cheb_b[int64_t(node) * D + i] - acc[i];
+              }
 #pragma unroll
             for (int i = 0; i < D; ++i)
               {
                 const int64_t idx = int64_t(node) * D + i;
                 if constexpr (CHEB)
                   {
-                    const double res = prm.cheb_b[idx] - acc[i];
                     if (prm.cheb_d)
                       {
-                        const double dn    = prm.cheb_c1 * prm.cheb_d[idx] + prm.cheb_c2 * prm.cheb_dinv[idx] * res;
+                        double s = prm.cheb_dinv[idx] * res[i];
+                        if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
+                          {
+                            s = 0.0;
+#pragma unroll
+                            for (int j = 0; j < D; ++j)
+                              s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
+                          }
+                        const double dn    = prm.cheb_c1 * prm.cheb_d[idx] + prm.cheb_c2 * s;
                         prm.cheb_d[idx]    = dn;
                         prm.cheb_xout[idx] = prm.x[idx] + dn;
                       }
                     else
-                      prm.y[idx] = res; // residual mode: y = b - K x
+                      prm.y[idx] = res[i]; // residual mode: y = b - K x
                   }
                 else
                   prm.y[idx] = acc[i];
@@ -1560,6 +1574,85 @@ namespace mi
     dinv[i]         = 1.0 / vals[int64_t(diagpos[n]) * (D * D) + c * D + c];
   }
 
+  // inverse of the DxD diagonal block of every node (block-Jacobi smoother of the multigrid).  Dirichlet rows and
+  // columns of a block are unit rows/columns up to the kept diagonal, so the block stays invertible.
+  template <int D>
+  __global__ __launch_bounds__(256) void extract_dinv_blk(const double *__restrict__ vals,
+                                                          const int32_t *__restrict__ diagpos, double *dinv, int64_t nnodes)
+  {
+    const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (n >= nnodes)
+      return;
+    const double *a = vals + int64_t(diagpos[n]) * (D * D);
+    double       *o = dinv + n * (D * D);
+    if constexpr (D == 2)
+      {
+        const double r = 1.0 / (a[0] * a[3] - a[1] * a[2]);
+        o[0]           = a[3] * r;
+        o[1]           = -a[1] * r;
+        o[2]           = -a[2] * r;
+        o[3]           = a[0] * r;
+      }
+    else
+      {
+        double A[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          A[k] = a[k];
+        inv3x3(A, det3x3(A), o);
+      }
+  }
+  // out = Dblk^-1 a (node blocks); out may alias a
+  template <int D>
+  __global__ __launch_bounds__(256) void blk_apply(double *out, const double *__restrict__ a,
+                                                   const double *__restrict__ dinv, int64_t nnodes)
+  {
+    const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (n >= nnodes)
+      return;
+    double v[D], r[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      v[i] = a[n * D + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      {
+        r[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          r[i] += dinv[n * (D * D) + i * D + j] * v[j];
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      out[n * D + i] = r[i];
+  }
+  // Chebyshev step with the block-Jacobi diagonal: one thread per node of [node0, node0 + nnodes)
+  template <int D>
+  __global__ __launch_bounds__(256) void cheb_step_blk(double *x, double *d, const double *__restrict__ b,
+                                                       const double *__restrict__ q, const double *__restrict__ dinv,
+                                                       double c1, double c2, int64_t node0, int64_t nnodes)
+  {
+    const int64_t k = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (k >= nnodes)
+      return;
+    const int64_t n = node0 + k;
+    double        res[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      res[i] = b[n * D + i] - (q ? q[n * D + i] : 0.0);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j)
+          s += dinv[n * (D * D) + i * D + j] * res[j];
+        const double dn = c1 * d[n * D + i] + c2 * s;
+        d[n * D + i]    = dn;
+        x[n * D + i]    = (q ? x[n * D + i] : 0.0) + dn;
+      }
+  }
+
   // masked l2 norm partials: sum over dofs whose constraint bit is clear (:549-576)
   template <int D>
   __global__ __launch_bounds__(256) void masked_norm_partials(const double *__restrict__ v,
@@ -1947,6 +2040,32 @@ namespace mi
                          double cb, int64_t n, hipStream_t s)
   {
     hipLaunchKernelGGL(cheb4_step, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, d, r, q, dinv, beta, ca, cb, n);
+  }
+  void launch_extract_dinv_blk(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
+                               hipStream_t s)
+  {
+    const int grid = int((nnodes + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((extract_dinv_blk<3>), dim3(grid), dim3(256), 0, s, vals, diagpos, dinv, nnodes);
+    else
+      hipLaunchKernelGGL((extract_dinv_blk<2>), dim3(grid), dim3(256), 0, s, vals, diagpos, dinv, nnodes);
+  }
+  void launch_blk_apply(int dim, double *out, const double *a, const double *dinv, int64_t nnodes, hipStream_t s)
+  {
+    const int grid = int((nnodes + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((blk_apply<3>), dim3(grid), dim3(256), 0, s, out, a, dinv, nnodes);
+    else
+      hipLaunchKernelGGL((blk_apply<2>), dim3(grid), dim3(256), 0, s, out, a, dinv, nnodes);
+  }
+  void launch_cheb_step_blk(int dim, double *x, double *d, const double *b, const double *q, const double *dinv,
+                            double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s)
+  {
+    const int grid = int((nnodes + 255) / 256);
+    if (dim == 3)
+      hipLaunchKernelGGL((cheb_step_blk<3>), dim3(grid), dim3(256), 0, s, x, d, b, q, dinv, c1, c2, node0, nnodes);
+    else
+      hipLaunchKernelGGL((cheb_step_blk<2>), dim3(grid), dim3(256), 0, s, x, d, b, q, dinv, c1, c2, node0, nnodes);
   }
   void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st)
   {

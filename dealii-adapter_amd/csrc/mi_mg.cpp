@@ -53,11 +53,12 @@ namespace mi_detail
   {
     std::vector<MgLevel> levels;
     size_t n_dist        = 1;    // levels [0, n_dist) are distributed over the slabs of the team, the others replicated
-    int    nu            = 2;    // Chebyshev degree of the pre- and post-smoother on the finest level
+    int    nu            = 3;    // Chebyshev degree of the pre- and post-smoother on the finest level
     int    nu_coarse     = 2;    // ... on the coarser levels
     int    fuse          = 1;    // Chebyshev update / residual in the epilogue of the product (one launch instead of two):
                                  // 0 never, 1 on the latency-bound levels (<= fuse_max_nodes), 2 on every level
     int64_t fuse_max_nodes = 100000;
+    int    block         = 1;    // 1: block-Jacobi diagonal (DxD node blocks) inside the Chebyshev smoother, 0: point Jacobi
     int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
@@ -267,7 +268,10 @@ namespace mi_detail
             {
               MgLevel &L = m->mg->levels[l];
               mi_ctx  *c = L.ctx;
-              mi::launch_vec_scale_mul(L.d(), L.q(), c->work(W_DINV), 1.0, c->n, c->stream); // w = D^-1 A v
+              if (mg0.block)
+                mi::launch_blk_apply(c->dim, L.d(), L.q(), c->d_dinv_blk, c->mesh.nnodes, c->stream);
+              else
+                mi::launch_vec_scale_mul(L.d(), L.q(), c->work(W_DINV), 1.0, c->n, c->stream); // w = D^-1 A v
               // |w|^2 over the owned dofs of the level -> scalar slot 14 of the slab
               mi::launch_masked_norm(c->dim, L.d() + c->own0, c->d_cmask + c->slab.own_begin, c->own_n, m->part(5),
                                      m->grid_vec, m->d_sc + 14, c->stream);
@@ -342,6 +346,8 @@ namespace mi_detail
       mg->nu_coarse = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_FUSE"))
       mg->fuse = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("MI_MG_BLOCK"))
+      mg->block = atoi(e) != 0;
     if (const char *e = getenv("MI_MG_KIND"))
       mg->kind = atoi(e) == 4 ? 4 : 1;
     if (const char *e = getenv("MI_MG_RATIO"))
@@ -423,6 +429,9 @@ namespace mi_detail
               return rc;
           }
       }
+    if (mg->block)
+      for (MgLevel &L : mg->levels)
+        L.ctx->want_dinv_blk = true; // filled by the next assembly of the level
     c->mg_stale = true;
     return MI_OK;
   }
@@ -436,6 +445,12 @@ namespace mi_detail
       return MI_OK;
     const size_t nl = c0->mg->levels.size();
     int          rc;
+    for (mi_ctx *m : T.members)
+      if (m->mg->block && !m->d_dinv_blk) // switched on after the fine tangent was assembled
+        {
+          HIPCHK(m, hipMalloc((void **)&m->d_dinv_blk, size_t(m->mesh.nnodes) * m->dim * m->dim * sizeof(double)));
+          mi::launch_extract_dinv_blk(m->dim, m->d_vals, m->d_diagpos, m->d_dinv_blk, m->mesh.nnodes, m->stream);
+        }
     for (mi_ctx *m : T.members)
       {
         // u_total = u + du of the slab (all local nodes: the ghost copies are kept consistent)
@@ -527,7 +542,10 @@ namespace mi_detail
               for (mi_ctx *m : T.members)
                 {
                   MgLevel &L = m->mg->levels[l];
-                  cf.push_back(ChebFusion{L.b(), L.ctx->work(W_DINV), L.d(), L.x_other(), c1, c2});
+                  if (m->mg->block)
+                    cf.push_back(ChebFusion{L.b(), L.ctx->d_dinv_blk, L.d(), L.x_other(), c1, c2, 1});
+                  else
+                    cf.push_back(ChebFusion{L.b(), L.ctx->work(W_DINV), L.d(), L.x_other(), c1, c2, 0});
                 }
               if ((rc = level_spmv(T, l, x_of, cf.data())))
                 return rc;
@@ -541,8 +559,12 @@ namespace mi_detail
             {
               MgLevel      &L  = m->mg->levels[l];
               const int64_t o0 = L.ctx->own0, on = L.ctx->own_n;
-              mi::launch_cheb_step(L.x() + o0, L.d() + o0, L.b() + o0, skip_spmv ? nullptr : L.q() + o0,
-                                   L.ctx->work(W_DINV) + o0, c1, c2, on, L.ctx->stream);
+              if (m->mg->block)
+                mi::launch_cheb_step_blk(L.ctx->dim, L.x(), L.d(), L.b(), skip_spmv ? nullptr : L.q(), L.ctx->d_dinv_blk,
+                                         c1, c2, o0 / L.ctx->dim, on / L.ctx->dim, L.ctx->stream);
+              else
+                mi::launch_cheb_step(L.x() + o0, L.d() + o0, L.b() + o0, skip_spmv ? nullptr : L.q() + o0,
+                                     L.ctx->work(W_DINV) + o0, c1, c2, on, L.ctx->stream);
             }
         }
       return MI_OK;

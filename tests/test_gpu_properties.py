@@ -154,7 +154,7 @@ def test_headline_size_invariants():
     rc, info = G.newmark_step(tol_lin=1e-6, max_it_mult=1.0)
     assert rc == 0 and info.converged == 1
     assert info.assemblies == info.newton_iterations + 1  # nonlinear_elasticity.cc:446-469
-    assert 20 <= info.lin_its_total <= 80  # mesh-independent multigrid-PCG (a Jacobi-PCG needs > 1000 here)
+    assert 10 <= info.lin_its_total <= 80  # mesh-independent multigrid-PCG (a Jacobi-PCG needs > 1000 here)
     u = G.get(M.V_U)
     assert np.all(np.isfinite(u)) and np.all(u[G.constrained] == 0.0) and np.abs(u).max() > 0
     # the state after the step: assemble twice -> identical bits (colouring, fixed reduction order)
