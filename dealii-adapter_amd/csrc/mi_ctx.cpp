@@ -968,10 +968,10 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     }
   mi_ctx *c0 = T->members[0];
   {
-    // preconditioner: the multigrid V-cycle pays off from ~150k dofs (a V-cycle is ~110 small launches, i.e. a
-    // fixed ~0.8 ms per CG iteration whatever the size; measured crossover with Jacobi-PCG between 108k and 207k
-    // dofs, tools/small_case_latency.py); below that Jacobi.  mi_set_tuning("precond") / MI_PRECOND override.
-    int precond = T->n_global >= 150000 ? 1 : 0;
+    // preconditioner: the multigrid V-cycle pays off from ~75k dofs (a V-cycle is ~100 small launches, i.e. a
+    // fixed ~0.8 ms per CG iteration whatever the size; measured crossover with Jacobi-PCG at 73k dofs,
+    // tools/small_case_latency.py); below that Jacobi.  mi_set_tuning("precond") / MI_PRECOND override.
+    int precond = T->n_global >= 75000 ? 1 : 0;
     if (const char *e = getenv("MI_PRECOND"))
       precond = atoi(e) != 0;
     for (mi_ctx *m : T->members)
