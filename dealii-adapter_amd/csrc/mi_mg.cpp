@@ -354,6 +354,10 @@ namespace mi_detail
       mg->smooth_ratio = std::max(2.0, atof(e));
     if (const char *e = getenv("MI_MG_COARSEST"))
       mg->coarsest_reps = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_SAFETY"))
+      mg->lmax_safety = std::max(1.0, atof(e));
+    if (const char *e = getenv("MI_MG_POWER_ITS"))
+      mg->power_its_update = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_FACTOR"))
       mg->coarsen_factor = std::max(2, atoi(e));
     if (const char *e = getenv("MI_MG_COARSE_DEGREE"))
