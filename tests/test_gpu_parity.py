@@ -139,6 +139,32 @@ def test_spmv_matches_reference_matrix(dim, p, reps):
     assert abs(z @ G.spmv(x) - x @ G.spmv(z)) / abs(z @ y) < 1e-12
 
 
+def test_element_kernel_variants_agree():
+    """the A/B instantiations of the 3D Q2 element kernel (quadrature chunk sizes, and the sum-factorised kernel that
+    contracts one lattice direction at a time) assemble the same tangent and residual"""
+    reps = (3, 3, 2)
+    nverts = int(np.prod([r + 1 for r in reps]))
+    perturb = 0.02 * np.random.default_rng(3).standard_normal((nverts, 3))
+    G = M.Context(dim=3, degree=2, reps=reps, hi=(0.6, 0.6, 0.4), perturb=perturb, body_force=(0.0, -9.81, 0.0))
+    rng = np.random.default_rng(4)
+    G.set(M.V_U, 2e-3 * rng.standard_normal(G.n) * ~G.constrained)
+    G.set(M.V_V_OLD, 0.1 * rng.standard_normal(G.n))
+    G.set_interface_traction(1e3 * rng.standard_normal((len(G.interface()[0]), 3)))
+    G.update_acceleration()
+    x = rng.standard_normal(G.n)
+    ref = None
+    for v in (0, 1, 2, 5):
+        G.set_tuning("asm_variant", v)
+        rn = G.assemble()
+        y, r = G.spmv(x), G.get(M.V_RHS)
+        if ref is None:
+            ref = (y, r, rn)
+            continue
+        assert np.abs(y - ref[0]).max() / np.abs(ref[0]).max() < 1e-13, v
+        assert np.abs(r - ref[1]).max() / np.abs(ref[1]).max() < 1e-13, v
+        assert abs(rn - ref[2]) / ref[2] < 1e-13
+
+
 def test_spmv_kernel_variants_agree():
     """sliced-ELL (production) and block-CSR (cross-check) kernels on the same matrix, several grids"""
     P, G = _pair(3, 2, (5, 4, 3), perturb_amp=0.05, seed=11)
