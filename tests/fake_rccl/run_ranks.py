@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Driver of tests/test_gpu_fake_rccl.py: N rank THREADS in one process go through the library's RCCL branch (one
+slab per rank, `mi_comm_desc` with a unique id) against the RCCL test double, and are compared with the undecomposed
+and the emulated-slab runs of the same problem.  Prints one JSON line."""
+import importlib.util
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+
+
+def load():
+    spec = importlib.util.spec_from_file_location("dealii_adapter_amd_fake", os.path.join(ROOT, "dealii-adapter_amd", "__init__.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["dealii_adapter_amd_fake"] = mod
+    spec.loader.exec_module(mod)
+    mod.LIB_PATH = os.path.join(HERE, "libmi_elasticity_fakerccl.so")  # same objects, RCCL replaced by the test double
+    return mod
+
+
+def linear_scenario(G, M):
+    """the linear theta-model: per-slab host assembly, both products and the PCG across the ranks"""
+    import ctypes as C
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, 0.6) == 0, L.mi_last_error(G.h)
+    rng = np.random.default_rng(21)
+    ids, _ = G.interface()
+    out = {}
+    for step in range(3):
+        G.set_interface_traction(100.0 * rng.standard_normal((len(ids), G.dim)))
+        its, res = C.c_int(0), C.c_double(0)
+        rc = L.mi_linear_step(G.h, int(step != 1), 1e-12, G.n * 4, C.byref(its), C.byref(res))
+        assert rc == 0, L.mi_last_error(G.h)
+    out["d"] = G.get(0)
+    out["v"] = G.get(2)
+    return out
+
+
+def scenario(G, M, kw, log):
+    """the same API sequence on every rank (all arrays global)"""
+    rng = np.random.default_rng(5)
+    ids, _ = G.interface()
+    out = {}
+    G.set_tuning("halo_overlap", kw.get("overlap", 1))
+    for precond in (0, 1):
+        G.set_tuning("precond", precond)
+        its = []
+        for step in range(2):
+            G.set_interface_traction((0.0, -1.5e3 * (step + 1), 0.0)[:G.dim])
+            rc, info = G.newmark_step(tol_lin=1e-10, max_it_mult=2.0)
+            assert rc == 0 and info.converged == 1, (rc, precond, step)
+            its.append(int(info.lin_its_total))
+        out["its%d" % precond] = its
+        out["u%d" % precond] = G.get(M.V_U)
+        out["if%d" % precond] = G.get_interface_displacement()
+    x = np.random.default_rng(9).standard_normal(G.n)
+    G.update_acceleration()
+    out["rn"] = G.assemble()
+    out["Kx"] = G.spmv(x)
+    G.state_save()
+    G.set(M.V_U, rng.standard_normal(G.n))
+    G.state_restore()
+    out["restored"] = G.get(M.V_U)
+    lin = linear_scenario(G, M)
+    out["lin_d"], out["lin_v"] = lin["d"], lin["v"]
+    return out
+
+
+def main():
+    world = int(sys.argv[1])
+    dim, p = int(sys.argv[2]), int(sys.argv[3])
+    reps = tuple(int(v) for v in sys.argv[4].split(","))
+    overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    M = load()
+    hi = tuple(0.1 * r for r in reps)
+    roles = [1, 7, 7, 7, 8, 7]
+    common = dict(dim=dim, degree=p, reps=reps, hi=hi, face_role=roles)
+    uid = M.comm_unique_id()
+    results, errors = [None] * world, []
+
+    def rank_main(r):
+        try:
+            G = M.Context(rank=r, world=world, unique_id=uid, **common)
+            results[r] = scenario(G, M, dict(overlap=overlap), None)
+            G.close()
+        except BaseException as e:  # noqa: BLE001 -- reported to the parent test
+            errors.append("rank %d: %r" % (r, e))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    if errors or any(t.is_alive() for t in threads):
+        print(json.dumps({"ok": False, "errors": errors, "hung": [t.is_alive() for t in threads]}), flush=True)
+        os._exit(1)
+    single = scenario(M.Context(**common), M, {}, None)
+    emu = scenario(M.Context(slabs=world, **common), M, {}, None)
+
+    def rel(a, b):
+        return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))
+
+    rep = {"ok": True, "world": world, "its_ranks": [results[r]["its0"] + results[r]["its1"] for r in range(world)],
+           "its_single": single["its0"] + single["its1"], "its_emulated": emu["its0"] + emu["its1"]}
+    keys = ("u0", "u1", "if0", "if1", "Kx", "restored", "lin_d", "lin_v")
+    rep["rank_spread"] = max(rel(results[r][k], results[0][k]) for r in range(1, world) for k in keys) if world > 1 else 0.0
+    rep["vs_single"] = {k: rel(results[0][k], single[k]) for k in keys}
+    rep["vs_emulated"] = {k: rel(results[0][k], emu[k]) for k in keys}
+    rep["rn"] = [results[r]["rn"] for r in range(world)] + [single["rn"], emu["rn"]]
+    print(json.dumps(rep))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,43 @@
+"""The library's RCCL branch on a one-GPU box.  RCCL refuses two ranks on one device, so the ranks are threads of
+one process and RCCL is replaced by a test double with the real prototypes (tests/fake_rccl/fake_rccl.cpp): what
+runs is the product's own multi-rank code -- one slab per rank, `ncclSend/ncclRecv` halo groups on the communication
+stream with its events, `ncclAllReduce` of scalars, vectors and global buffers, the order of collective calls on every
+rank (a mismatch times out in the double instead of hanging) -- compared with the undecomposed and the emulated runs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FAKE = os.path.join(ROOT, "tests", "fake_rccl")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fake_lib():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dealii-adapter_amd"), "-j4", "all"])
+    subprocess.check_call(["make", "-C", FAKE])
+    out = subprocess.run(["ldd", os.path.join(FAKE, "libmi_elasticity_fakerccl.so")], capture_output=True, text=True).stdout
+    assert "rccl" not in out  # the real library is not in the picture
+    return True
+
+
+@pytest.mark.parametrize("world,dim,p,reps,overlap", [(2, 3, 2, "3,2,5", 1), (3, 3, 2, "3,3,7", 1), (4, 3, 1, "4,3,9", 1),
+                                                      (2, 3, 2, "3,2,5", 0), (3, 2, 3, "4,9", 1)])
+def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, overlap):
+    out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap)],
+                         capture_output=True, text=True, timeout=900)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and lines, (out.stdout[-2000:], out.stderr[-3000:])
+    r = json.loads(lines[-1])
+    assert r["ok"], r
+    assert r["rank_spread"] == 0.0  # every rank returns the same global arrays, bit for bit
+    for k, v in r["vs_single"].items():
+        assert v < 1e-7, (k, v, r)  # CG tolerance 1e-10 on both sides
+    for k, v in r["vs_emulated"].items():
+        assert v < 1e-9, (k, v, r)  # same slabs, same reduction order up to the all-reduce's summation
+    for its in r["its_ranks"]:
+        assert its == r["its_ranks"][0]
+        assert all(abs(a - b) <= 1 for a, b in zip(its, r["its_emulated"]))
