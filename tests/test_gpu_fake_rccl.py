@@ -25,7 +25,7 @@ def fake_lib():
 
 
 @pytest.mark.parametrize("world,dim,p,reps,overlap", [(2, 3, 2, "3,2,5", 1), (3, 3, 2, "3,3,7", 1), (4, 3, 1, "4,3,9", 1),
-                                                      (2, 3, 2, "3,2,5", 0), (3, 2, 3, "4,9", 1)])
+                                                      (2, 3, 2, "3,2,5", 0), (3, 2, 3, "4,9", 1), (8, 3, 2, "3,3,17", 1)])
 def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, overlap):
     out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap)],
                          capture_output=True, text=True, timeout=900)
