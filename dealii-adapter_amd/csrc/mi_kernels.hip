@@ -78,6 +78,10 @@ namespace mi
 
   constexpr int RQ = 32; // doubles per quadrature-point record in LDS
   constexpr int RN = 10; // doubles per (qp,node) record: g[3], m[3], t[3] = tau g, n
+#ifndef MI_NDPAD
+#define MI_NDPAD 2
+#endif
+  constexpr int NDPAD = MI_NDPAD; // see assemble_cells
   // quadrature-point record layout
   constexpr int Q_M    = 0;  // 9: Jinv * Finv  (unit gradient -> spatial gradient)
   constexpr int Q_TAU  = 9;  // 6: tau      xx yy zz xy xz yz
@@ -255,7 +259,10 @@ namespace mi
     __shared__ double s_u[NPC * 3], s_a[NPC * 3], s_verts[NV * DIM];
     __shared__ int    s_conn[NPC];
     __shared__ __attribute__((aligned(16))) double s_qp[NQ * RQ];
-    __shared__ __attribute__((aligned(16))) double s_nd[QC * NPCP * RN];
+    // per quadrature point NPCP records of RN doubles, padded by NDPAD doubles: the two lanes of a tile read the same
+    // records of neighbouring points, and an unpadded point stride (a multiple of 32 B) put them on the same banks
+    constexpr int NDS = NPCP * RN + NDPAD;
+    __shared__ __attribute__((aligned(16))) double s_nd[QC * NDS];
 
     const int     tid  = threadIdx.x;
     const int64_t cell = prm.cell_begin + blockIdx.x;
@@ -275,7 +282,7 @@ namespace mi
       s_conn[tid] = prm.conn[cell * NPC + tid];
     if (tid < NV * DIM)
       s_verts[tid] = prm.cverts[cell * (NV * DIM) + tid];
-    for (int i = tid; i < QC * NPCP * RN; i += NT)
+    for (int i = tid; i < QC * NDS; i += NT)
       s_nd[i] = 0.0; // the padding node stays zero for the whole kernel
     __syncthreads();
     for (int i = tid; i < NPC * 3; i += NT)
@@ -419,7 +426,7 @@ namespace mi
 #pragma unroll
             for (int j = 0; j < 3; ++j)
               g[j] = dN[0] * r[Q_M + 0 * 3 + j] + dN[1] * r[Q_M + 1 * 3 + j] + dN[2] * r[Q_M + 2 * 3 + j];
-            double *o = &s_nd[(qq * NPCP + a) * RN];
+            double *o = &s_nd[qq * NDS + a * RN];
             sym_mul(&r[Q_TISO], g, t);
             sym_mul(&r[Q_TAU], g, v);
 #pragma unroll
@@ -440,7 +447,7 @@ namespace mi
               {
                 const double *r    = &s_qp[(chunk * QC + qq) * RQ];
                 const double  w    = r[Q_W], wcII = r[Q_WCII], cs2 = r[Q_CS2], wcs2 = w * cs2;
-                const double *nd   = &s_nd[qq * NPCP * RN];
+                const double *nd   = &s_nd[qq * NDS];
                 double        ha[2][3], gw[2][3], gc[2][3], na[2];
 #pragma unroll
                 for (int x = 0; x < 2; ++x)
@@ -502,7 +509,7 @@ namespace mi
             for (int qq = 0; qq < QC; ++qq)
               {
                 const double *r  = &s_qp[(chunk * QC + qq) * RQ];
-                const double *pa = &s_nd[(qq * NPCP + a) * RN];
+                const double *pa = &s_nd[qq * NDS + a * RN];
                 rres -= r[Q_W] * pa[6 + i] + (pa[9] * r[Q_NINV]) * r[Q_FACC + i]; // w (tau g_a)_i + N_a rho w (acc - b)_i
               }
           }
