@@ -30,11 +30,16 @@ def _pkg():
     return mod
 
 
-def spmv_bytes(nnodes, nnzb, dim):
-    """algorithmic HBM bytes of one block-CSR SpMV launch: every stored value and block column index once,
-    block row pointers, x read once, y written once (the fused dot's second read of p is not credited)"""
+def spmv_bytes(nnodes, nnzb, dim, generated_columns=None):
+    """algorithmic HBM bytes of one SpMV launch of the format actually used: every stored value once, the block
+    column indices once -- or, with generated columns (the default, `sell_icol`), 8 bytes of column-box description
+    per row instead --, 4 bytes of row bookkeeping per row, x read once, y written once (the fused dot's second read
+    of p is not credited)"""
+    if generated_columns is None:
+        generated_columns = os.environ.get("MI_SELL_ICOL", "1") != "0"
     n = nnodes * dim
-    return 8 * nnzb * dim * dim + 4 * nnzb + 4 * (nnodes + 1) + 8 * n + 8 * n
+    index_bytes = 8 * nnodes if generated_columns else 4 * nnzb
+    return 8 * nnzb * dim * dim + index_bytes + 4 * (nnodes + 1) + 8 * n + 8 * n
 
 
 def spmv_bytes_scalar_csr(nnodes, nnzb, dim):
@@ -174,7 +179,7 @@ def main():
         # HBM traffic of the same kernel on the same workload from the committed PMC passes (rocprofv3 --pmc cannot be
         # collected from inside this process); only quoted when the workload is the one that was profiled
         traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_nt_n59.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_icol_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9  # GB per launch
         out = {
@@ -212,8 +217,8 @@ def main():
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
             },
             "roofline": {
-                "kernel": "sell_spmv<3,2,0,1,true,false,false> = <D=3, 2 blocks in flight, no ablation, non-temporal matrix "
-                          "loads, DOT=true, fp64 values, no fused smoother update>: the CG's q = K p with fused p.q partials on "
+                "kernel": "sell_spmv<3,2,0,1,true,false,false,true> = <D=3, 2 blocks in flight, no ablation, non-temporal matrix "
+                          "loads, DOT=true, fp64 values, no fused smoother update, generated column indices>: the CG's q = K p with fused p.q partials on "
                           "the sliced-ELL copy of the block-CSR tangent; the preconditioner's products run DOT=false "
                           "instantiations of the same kernel",
                 "bound": "hbm",
@@ -222,7 +227,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "traffic_unit": "GB per launch (PMC: TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1 KiB, profiles/r01/pmc_spmv_nt_n59.json)",
+                "traffic_unit": "GB per launch (PMC: TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1 KiB, profiles/r01/pmc_spmv_icol_n59.json)",
                 "algorithmic_GB_per_launch": bytes_bsr / 1e9,
                 "bytes_per_launch": bytes_bsr,
                 "launches_timed": spmv_n,

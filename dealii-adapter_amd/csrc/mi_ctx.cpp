@@ -191,6 +191,9 @@ namespace mi_detail
     p.len       = c->d_sell_len;
     p.off       = c->d_sell_off;
     p.col       = c->d_sell_col;
+    p.rowbox    = c->sell_icol ? c->d_sell_box : nullptr;
+    p.nn0       = c->mesh.nn[0];
+    p.nn1       = c->mesh.nn[1];
     p.vals      = c->active_sell_vals ? c->active_sell_vals : c->d_sell_vals;
     p.x         = x;
     p.y         = y;
@@ -681,7 +684,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -759,6 +762,7 @@ namespace mi_detail
     UP(c->d_sell_perm, m.sell_perm)
     UP(c->d_sell_len, m.sell_len)
     UP(c->d_sell_off, m.sell_off)
+    UP(c->d_sell_box, m.sell_box)
     // local interface nodes -> slots of the global interface list; owned ones feed the displacement gather
     {
       std::vector<int32_t> own_nodes, own_slots;
@@ -824,6 +828,8 @@ namespace mi_detail
       c->spmv_variant = atoi(v);
     if (const char *v = getenv("MI_SELL_UNROLL"))
       c->sell_unroll = atoi(v);
+    if (const char *v = getenv("MI_SELL_ICOL"))
+      c->sell_icol = atoi(v) != 0;
     if (const char *v = getenv("MI_SMALL_CG"))
       c->small_cg = atoi(v) != 0;
     return MI_OK;
@@ -1542,6 +1548,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
             m->grid_spmv_bnd = value;
           m->grid_spmv = m->grid_spmv_int + m->grid_spmv_bnd;
         }
+      else if (k == "sell_icol" && (value == 0 || value == 1))
+        m->sell_icol = value;
       else if (k == "small_cg" && (value == 0 || value == 1))
         m->small_cg = value;
       else if (k == "halo_overlap" && (value == 0 || value == 1))

@@ -88,7 +88,8 @@ struct mi_ctx
           *d_faces = nullptr, *d_flags = nullptr;
   double   *d_cverts = nullptr, *d_tab = nullptr, *d_vals = nullptr, *d_vecs = nullptr, *d_work = nullptr,
          *d_saved = nullptr, *d_part = nullptr, *d_sc = nullptr, *d_iface_buf = nullptr;
-  int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr;
+  int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr, *d_sell_box = nullptr;
+  int       sell_icol = 1; // 1: the SpMV generates the column indices from the rows' column boxes, 0: reads them
   int64_t  *d_sell_off = nullptr;
   double   *d_sell_vals = nullptr;
   double   *d_dinv_blk = nullptr; // inverse diagonal blocks (block-Jacobi smoother), allocated when it is switched on

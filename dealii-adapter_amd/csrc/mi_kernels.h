@@ -45,6 +45,9 @@ namespace mi
     const int32_t *len;  // [nslices]
     const int64_t *off;  // [nslices+1]
     const int32_t *col;  // [nblk64*64]
+    const int32_t *rowbox; // optional [nslices*64][2]: first column and box widths of every row; when set the kernel
+                           // generates the column indices instead of reading `col` (lattice meshes: columns form a box)
+    int32_t        nn0, nn1; // lattice points along x and y (column = x + nn0 * (y + nn1 * z))
     const double  *vals; // [nblk64*DD*64]
     const float   *vals32; // same layout, rounded to fp32: the smoother's copy (null: use vals)
     // fused Chebyshev-Jacobi epilogue (multigrid smoother; cheb_d == null: plain product).  Per owned row i:

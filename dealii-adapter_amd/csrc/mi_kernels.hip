@@ -1252,7 +1252,8 @@ namespace mi
   //      product the roofline figure is quoted on apart from the preconditioner's products
   // F32: the matrix values come from the fp32-rounded copy (smoother only); all arithmetic stays fp64
   // CHEB: Chebyshev-Jacobi update fused into the epilogue (see SellParams), y is not written
-  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false, bool F32 = false, bool CHEB = false>
+  // ICOL: column indices generated from the row's column box (SellParams::rowbox) instead of read from memory
+  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false, bool F32 = false, bool CHEB = false, bool ICOL = false>
   __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
@@ -1279,6 +1280,32 @@ namespace mi
 #pragma unroll
         for (int i = 0; i < D; ++i)
           acc[i] = 0.0;
+        // column generator: x fastest inside the box, then y, then z
+        int32_t g_cur = 0, g_cx = 0, g_cy = 0, g_wx = 1, g_wy = 1, g_jy = 0, g_jz = 0;
+        if constexpr (ICOL)
+          {
+            const int32_t b0 = prm.rowbox[(int64_t(sl) * 64 + lane) * 2], b1 = prm.rowbox[(int64_t(sl) * 64 + lane) * 2 + 1];
+            g_cur            = b0;
+            g_wx             = b1 & 255;
+            g_wy             = (b1 >> 8) & 255;
+            g_jy             = prm.nn0 - g_wx;
+            g_jz             = prm.nn0 * (prm.nn1 - g_wy);
+          }
+        auto next_col = [&]() {
+          const int32_t c = g_cur;
+          ++g_cur;
+          if (++g_cx == g_wx)
+            {
+              g_cx = 0;
+              g_cur += g_jy;
+              if (++g_cy == g_wy)
+                {
+                  g_cy = 0;
+                  g_cur += g_jz;
+                }
+            }
+          return c;
+        };
         int k = 0;
         for (; k + U <= len; k += U)
           {
@@ -1286,7 +1313,12 @@ namespace mi
             double  v[U][DD], xx[U][D];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-              c[u] = (ABL == 2) ? 0 : (NTL == 1 ? __builtin_nontemporal_load(&cp[int64_t(k + u) * 64]) : cp[int64_t(k + u) * 64]);
+              {
+                if constexpr (ICOL)
+                  c[u] = next_col();
+                else
+                  c[u] = (ABL == 2) ? 0 : (NTL == 1 ? __builtin_nontemporal_load(&cp[int64_t(k + u) * 64]) : cp[int64_t(k + u) * 64]);
+              }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -1317,8 +1349,12 @@ namespace mi
           }
         for (; k < len; ++k)
           {
-            const int32_t c = cp[int64_t(k) * 64];
-            double        v[DD], xx[D];
+            int32_t c;
+            if constexpr (ICOL)
+              c = next_col();
+            else
+              c = cp[int64_t(k) * 64];
+            double v[DD], xx[D];
 #pragma unroll
             for (int e = 0; e < DD; ++e)
               v[e] = vp[(int64_t(k) * DD + e) * 64];
@@ -2345,6 +2381,31 @@ namespace mi
 
   // unroll: 1..4 blocks in flight per lane; 5..7 = 2..4 with non-temporal matrix loads (5 is the default),
   // 8 = 2 with non-temporal values only; -1, -2 timing-only ablations
+  // default load pipeline with generated column indices (SellParams::rowbox set)
+  template <int D, bool DOT, bool F32, bool CHEB>
+  static void sell_launch_icol(const SellParams &p, int grid, hipStream_t s)
+  {
+    if constexpr (D == 3)
+      hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
+  }
+  template <int D>
+  static void sell_dispatch_icol(const SellParams &p, int grid, hipStream_t s)
+  {
+    const bool dot = p.dotv && p.partials, cheb = (p.cheb_d || p.cheb_b) && !dot, f32 = p.vals32 && !dot;
+    if (dot)
+      sell_launch_icol<D, true, false, false>(p, grid, s);
+    else if (cheb && f32)
+      sell_launch_icol<D, false, true, true>(p, grid, s);
+    else if (cheb)
+      sell_launch_icol<D, false, false, true>(p, grid, s);
+    else if (f32)
+      sell_launch_icol<D, false, true, false>(p, grid, s);
+    else
+      sell_launch_icol<D, false, false, false>(p, grid, s);
+  }
+
   template <int D, bool DOT, bool F32 = false>
   static void sell_dispatch(const SellParams &p, int grid, hipStream_t s, int unroll)
   {
@@ -2370,6 +2431,11 @@ namespace mi
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
   {
     const bool dot = p.dotv && p.partials;
+    if (p.rowbox && unroll == 5) // production pipeline, columns generated
+      {
+        dim == 3 ? sell_dispatch_icol<3>(p, grid, s) : sell_dispatch_icol<2>(p, grid, s);
+        return;
+      }
     if ((p.cheb_d || p.cheb_b) && !dot) // smoother step / residual fused into the product (default load pipeline only)
       {
         if (dim == 3 && p.vals32)

@@ -306,6 +306,8 @@ namespace mi
     std::vector<int32_t> sell_perm;                         // [nslices*64] node of a slot, -1 = padding row
     std::vector<int32_t> sell_len;                          // [nslices] blocks per row in the slice
     std::vector<int64_t> sell_off;                          // [nslices+1] prefix sum of sell_len
+    std::vector<int32_t> sell_box;                          // [nslices*64][2] first column, widths (wx | wy << 8) of the
+                                                            // row's column box: columns need not be read from memory
 
     static void split(int64_t id, const int *ext, int dim, int *out)
     {
@@ -621,6 +623,22 @@ namespace mi
             sell_nslices_interior = int64_t(sell_len.size());
         }
       sell_nslices = int64_t(sell_len.size());
+      sell_box.assign(sell_perm.size() * 2, 0);
+      for (size_t slot = 0; slot < sell_perm.size(); ++slot)
+        {
+          const int32_t n = sell_perm[slot];
+          if (n < 0)
+            {
+              sell_box[2 * slot + 1] = 255 | (255 << 8); // padding row: columns 0, 1, 2, ... (values are zero)
+              continue;
+            }
+          int ni[3], a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+          split(n, nn, dim, ni);
+          for (int d = 0; d < dim; ++d)
+            couple_range(d, ni[d], a[d], b[d]);
+          sell_box[2 * slot]     = colidx[size_t(rowptr[size_t(n)])];
+          sell_box[2 * slot + 1] = (b[0] - a[0] + 1) | ((b[1] - a[1] + 1) << 8);
+        }
       sell_off.assign(size_t(sell_nslices) + 1, 0);
       for (int64_t sl = 0; sl < sell_nslices; ++sl)
         sell_off[size_t(sl) + 1] = sell_off[size_t(sl)] + sell_len[size_t(sl)];

@@ -230,7 +230,8 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * element-kernel ablations; "halo_overlap" 1 ghost-plane exchange on the communication stream next to the interior
  * rows of the SpMV (default), 0 in line on the compute stream; "precond_storage" 64 (default) | 32: the multigrid
  * smoother multiplies with an fp32-rounded copy of the level matrices (arithmetic, the CG's own product and its
- * residuals stay fp64); "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
+ * residuals stay fp64); "sell_icol" 1 (default): the SpMV generates the column indices of a row from its
+ * column box (lattice meshes) instead of reading them, 0: reads the index array; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
  * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 int mi_reset_timings(mi_ctx *ctx);

@@ -33,7 +33,8 @@ def main():
         entry = {"read_bytes": rd, "write_bytes": wr, "traffic_bytes_per_launch": rd + wr,
                  "FETCH_SIZE_x1024": c.get("FETCH_SIZE", 0.0) * 1024.0}
         if "sell_spmv" in k:
-            entry["algorithmic_bytes_per_launch"] = nnzb * 76 + nodes * 4 + nodes * 24 * 2
+            icol = os.environ.get("MI_SELL_ICOL", "1") != "0"  # generated column indices: 8 B per row instead of 4 B per block
+            entry["algorithmic_bytes_per_launch"] = nnzb * 72 + (nodes * 8 if icol else nnzb * 4) + nodes * 4 + nodes * 24 * 2
             entry["ratio"] = (rd + wr) / entry["algorithmic_bytes_per_launch"]
             out["kernel"] = k
             out["traffic_bytes_per_launch"] = rd + wr
