@@ -18,8 +18,10 @@ HEADER = os.path.join(ROOT, "include", "mi_elasticity.h")
 MI_OK, MI_EINVAL, MI_EHIP, MI_ENOCONV_LIN, MI_ENOCONV_NR, MI_ECOMM = 0, -1, -2, -3, -4, -5
 FACE_FREE, FACE_CLAMPED, FACE_INTERFACE, FACE_ZCLAMP = 0, 1, 7, 8
 (V_U, V_U_OLD, V_V, V_V_OLD, V_A, V_A_OLD, V_STRESS, V_DELTA, V_NEWTON, V_RHS) = range(10)
-(T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_SELL_COPY, T_COUNT) = range(9)
-TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step", "sell_copy"]
+(T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_SELL_COPY, T_ASSEMBLE_RESIDUAL,
+ T_COUNT) = range(10)
+TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step", "sell_copy",
+                "assemble_residual"]
 
 
 class MeshDesc(C.Structure):
@@ -107,6 +109,10 @@ def lib():
         L.mi_set_interface_traction.argtypes = [vp, C.c_int, dp]
         L.mi_get_interface_displacement.argtypes = [vp, C.c_int, dp]
         L.mi_assemble.argtypes = [vp, dp]
+        L.mi_assemble_residual.argtypes = [vp, dp]
+        L.mi_assemble_residual.restype = C.c_int
+        L.mi_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.mi_comm_info.restype = C.c_int
         L.mi_cg_solve.argtypes = [vp, C.c_double, C.c_int64, C.POINTER(C.c_int), dp]
         L.mi_apply_newton_update.argtypes = [vp, dp]
         L.mi_newmark_step.argtypes = [vp, C.POINTER(SolverDesc), C.POINTER(StepInfo)]
@@ -296,6 +302,17 @@ class Context:
         r = C.c_double(0)
         self._chk(lib().mi_assemble(self.h, C.byref(r)))
         return r.value
+
+    def assemble_residual(self):
+        r = C.c_double(0)
+        self._chk(lib().mi_assemble_residual(self.h, C.byref(r)))
+        return r.value
+
+    def comm_info(self):
+        """(slabs of the decomposition, ncclCommCount of the RCCL communicator or 0)"""
+        a, b = C.c_int(0), C.c_int(0)
+        self._chk(lib().mi_comm_info(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def cg_solve(self, rel_tol=1e-6, max_it=None):
         its, res = C.c_int(0), C.c_double(0)

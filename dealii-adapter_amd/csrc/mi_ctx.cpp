@@ -405,15 +405,17 @@ namespace mi_detail
     return MI_OK;
   }
 
-  // the enqueue part of assemble_system for one slab (no host synchronisation)
-  int enqueue_assembly(mi_ctx *c)
+  // the enqueue part of assemble_system for one slab (no host synchronisation).
+  // residual_only: system_rhs alone (same numbers as the full pass); the tangent, its diagonal and the SpMV-side
+  // copy keep the state of the last full assembly
+  int enqueue_assembly(mi_ctx *c, bool residual_only)
   {
-    const int64_t dd = int64_t(c->dim) * c->dim;
-    (void)dd; // tangent_matrix = 0 (:1054) is implied: the first cell that touches a block stores instead of adding
+    // tangent_matrix = 0 (:1054) is implied: the first cell that touches a block stores instead of adding
     HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SYSTEM_RHS), 0, size_t(c->n) * sizeof(double), c->stream)); // :1055
     mi::AsmParams p  = asm_params(c);
+    p.residual_only  = residual_only ? 1 : 0;
     mi_ctx       *c0 = c->team->members[0];
-    const int     t0 = tic(c0, MI_T_ASSEMBLE_CELLS);
+    const int     t0 = tic(c0, residual_only ? MI_T_ASSEMBLE_RESIDUAL : MI_T_ASSEMBLE_CELLS);
     for (int col = 0; col < c->mesh.ncolours; ++col)
       {
         p.cell_begin = c->mesh.colour_begin[col];
@@ -426,6 +428,11 @@ namespace mi_detail
           return fail(c, MI_EINVAL, "no face kernel for dim=%d degree=%d", c->dim, c->degree);
       }
     toc(c0, t0);
+    if (residual_only)
+      {
+        HIPCHK(c, hipGetLastError());
+        return MI_OK;
+      }
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -528,6 +535,10 @@ namespace mi_detail
           *its = h_flags[1];
         if (res)
           *res = c0->h_pinned[SC_RES];
+        c0->cg_breakdown = h_flags[0] == 2;
+        if (h_flags[0] == 2)
+          return fail(c0, MI_ENOCONV_LIN, "CG broke down after %d iterations (non-finite residual or p.Ap <= 0; residual %.3e)",
+                      int(h_flags[1]), c0->h_pinned[SC_RES]);
         if (!h_flags[0])
           return fail(c0, MI_ENOCONV_LIN, "CG did not reach tolerance %.3e within %lld iterations (residual %.3e)",
                       std::fabs(tol), (long long)max_it, c0->h_pinned[SC_RES]);
@@ -648,6 +659,10 @@ namespace mi_detail
       *its = h_flags[1];
     if (res)
       *res = c0->h_pinned[SC_RES];
+    c0->cg_breakdown = h_flags[0] == 2;
+    if (h_flags[0] == 2)
+      return fail(c0, MI_ENOCONV_LIN, "CG broke down after %d iterations (non-finite residual or p.Ap <= 0; residual %.3e)",
+                  int(h_flags[1]), c0->h_pinned[SC_RES]);
     if (!done)
       return fail(c0, MI_ENOCONV_LIN, "CG did not reach tolerance %.3e within %lld iterations (residual %.3e)",
                   std::fabs(tol), (long long)max_it, c0->h_pinned[SC_RES]);
@@ -722,8 +737,6 @@ namespace mi_detail
       {
         return fail(c, MI_EINVAL, "%s", e.what());
       }
-    if (md->dim == 3 && md->degree > 2)
-      return fail(c, MI_EINVAL, "3D elements above degree 2 are not supported by the device kernels");
     const mi::HostMesh &m = c->mesh;
     c->n     = m.ndofs;
     c->own0  = c->slab.own_begin * c->dim;
@@ -1199,7 +1212,7 @@ int mi_update_acceleration(mi_ctx *c)
   return MI_OK;
 }
 
-int mi_assemble(mi_ctx *c, double *res_norm)
+static int assemble_impl(mi_ctx *c, bool residual_only, double *res_norm)
 {
   HIPCHK(c, hipSetDevice(c->device));
   Team     &T  = *c->team;
@@ -1207,7 +1220,7 @@ int mi_assemble(mi_ctx *c, double *res_norm)
   const int t  = tic(c0, MI_T_ASSEMBLE_TOTAL);
   for (mi_ctx *m : T.members)
     {
-      const int rc = enqueue_assembly(m);
+      const int rc = enqueue_assembly(m, residual_only);
       if (rc)
         return rc;
     }
@@ -1217,6 +1230,37 @@ int mi_assemble(mi_ctx *c, double *res_norm)
   if (res_norm)
     *res_norm = nrm;
   return rc;
+}
+
+int mi_assemble(mi_ctx *c, double *res_norm)
+{
+  return assemble_impl(c, false, res_norm);
+}
+
+int mi_assemble_residual(mi_ctx *c, double *res_norm)
+{
+  return assemble_impl(c, true, res_norm);
+}
+
+int mi_comm_info(const mi_ctx *c, int *team_size, int *rccl_ranks)
+{
+  if (!c)
+    return MI_EINVAL;
+  const Team &T = *c->team;
+  if (team_size)
+    *team_size = T.size;
+  if (rccl_ranks)
+    {
+      *rccl_ranks = 0;
+      if (T.nccl)
+        {
+          int n = 0;
+          if (ncclCommCount(static_cast<ncclComm_t>(T.nccl), &n) != ncclSuccess)
+            return MI_ECOMM;
+          *rccl_ranks = n;
+        }
+    }
+  return MI_OK;
 }
 
 int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res)
@@ -1231,7 +1275,10 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
     }
   // warm start: SolverCG starts from the passed vector (:1184-1187)
   int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res);
-  if (rc == MI_ENOCONV_LIN && mg_active(c))
+  // a breakdown (NaN state, indefinite tangent) is final, as with deal.II's SolverControl: no second attempt from a
+  // poisoned iterate
+  const bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
+  if (rc == MI_ENOCONV_LIN && mg_active(c) && !broke)
     {
       // safety net: should the V-cycle ever stall (e.g. an eigenvalue bound gone stale under a violent state
       // change), continue from the current iterate with the Jacobi preconditioner instead of giving up
@@ -1296,7 +1343,12 @@ int mi_newmark_step(mi_ctx *c, const mi_solver_desc *s, mi_step_info *info)
     {
       if ((rc = mi_update_acceleration(c))) // :444
         return rc;
-      if ((rc = mi_assemble(c, &error_residual))) // :446-449
+      // :446-449.  The convergence test (:459-463) needs the update criterion AND the residual criterion; the first
+      // is known before the assembly.  Only when it holds can this assembly be the last one of the step, whose tangent
+      // is never multiplied: then the residual alone is formed first (same numbers), and the tangent follows only if
+      // the residual criterion fails.
+      const bool update_ok = newton_iteration > 0 && (error_update_norm <= s->tol_u || error_update <= 1e-15);
+      if ((rc = update_ok ? mi_assemble_residual(c, &error_residual) : mi_assemble(c, &error_residual)))
         return rc;
       info->assemblies++;
       if (newton_iteration == 0)
@@ -1304,12 +1356,13 @@ int mi_newmark_step(mi_ctx *c, const mi_solver_desc *s, mi_step_info *info)
       error_residual_norm = error_residual;
       if (error_residual_0 != 0.0)
         error_residual_norm /= error_residual_0;
-      if (newton_iteration > 0 && ((error_update_norm <= s->tol_u || error_update <= 1e-15) &&
-                                   (error_residual_norm <= s->tol_f || error_residual <= 5e-9))) // :459-463
+      if (update_ok && (error_residual_norm <= s->tol_f || error_residual <= 5e-9)) // :459-463
         {
           info->converged = 1;
           break;
         }
+      if (update_ok && (rc = mi_assemble(c, &error_residual))) // not converged after all: the tangent is needed
+        return rc;
       int    its = 0;
       double res = 0;
       rc = mi_cg_solve(c, s->tol_lin, int64_t(double(mi_n_dofs(c)) * s->max_iterations_lin), &its, &res); // :472

@@ -102,6 +102,7 @@ struct mi_ctx
   double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
   size_t    h_pinned_doubles = 0;
   bool      have_saved = false;
+  bool      cg_breakdown = false; // the last solve stopped on a non-finite residual or p.Ap <= 0
 
   int grid_vec = 0, grid_spmv = 0, grid_spmv_int = 0, grid_spmv_bnd = 0; // grid_spmv = _int + _bnd (partials)
   int spmv_variant = 3, maxrow = 0, sell_unroll = 5, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
@@ -165,7 +166,7 @@ namespace mi_detail
   int  create_member(Team &T, const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int rank,
                      mi_ctx **out);
   void destroy_team(Team *T);
-  int  enqueue_assembly(mi_ctx *c);
+  int  enqueue_assembly(mi_ctx *c, bool residual_only = false);
   // multigrid (mi_mg.cpp)
   int  mg_setup(mi_ctx *c); // build the level hierarchy of a slab (once)
   void mg_destroy(mi_ctx *c);

@@ -22,6 +22,7 @@ namespace mi
     int64_t         cell_begin;
     int32_t         cell_count;
     int32_t         variant; // kernel variant for A/B timing
+    int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
   };
 
   struct SpmvParams

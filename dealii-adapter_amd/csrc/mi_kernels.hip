@@ -246,14 +246,20 @@ namespace mi
   //   per chunk of QC points: phase B (qp,node) records g, m, v, n -> LDS; main loop; residual
   //   epilogue: read-modify-write of the cell's blocks into the global block-CSR (colouring => race free)
   // ABL (timing only, results wrong): 1 = no tangent scatter, 2 = no main loop and no scatter, 3 = scatter only
+  // ABL = 4 (production): RESIDUAL ONLY -- phases A/B and the residual, bit-identical with the full kernel's residual;
+  //          the tangent is neither formed nor touched.  Serves the Newton convergence check (:446-469), whose
+  //          assembly is never multiplied when the check passes.
   template <int DIM, int P, int QSPLIT, int NT, int QC, int MINW = 1, int ABL = 0>
   __global__ __launch_bounds__(NT, MINW) void assemble_cells(AsmParams prm)
   {
     using E = Elem<DIM, P>;
     constexpr int NPC = E::NPC, NPCP = E::NPCP, NQ = E::NQ, NQ1 = E::NQ1, NP1 = E::NP1, DD = E::DD, NV = E::NV;
     static_assert(NQ % QC == 0, "chunk must divide the number of quadrature points");
-    static_assert(E::NTILES * QSPLIT <= NT, "not enough threads for the tile grid");
+    static_assert(NT % QSPLIT == 0, "the lanes of a tile must not straddle the workgroup");
     static_assert(NPC * DIM <= NT, "residual needs one thread per local dof");
+    // the tile grid is covered in NPASS passes of TPP tiles (one pass for every element up to 3D Q2; 3D Q3/Q4 have
+    // 528 / 2016 tiles: each pass repeats the cheap phase B and accumulates its own tiles)
+    constexpr int TPP = NT / QSPLIT, NPASS = (ABL == 4) ? 1 : (E::NTILES + TPP - 1) / TPP;
 
     __shared__ double s_N1[NQ1 * NP1], s_dN1[NQ1 * NP1], s_qw[NQ1], s_qx[NQ1];
     __shared__ double s_u[NPC * 3], s_a[NPC * 3], s_verts[NV * DIM];
@@ -391,8 +397,12 @@ namespace mi
       }
     __syncthreads();
 
+    double rres = 0.0; // residual entry of local dof tid (threads tid < NPC*DIM), accumulated in pass 0
+#pragma unroll 1
+    for (int pass = 0; pass < NPASS; ++pass)
+      {
     // ---- tile of this thread
-    const int  tile   = tid / QSPLIT, qslot = tid % QSPLIT;
+    const int  tile   = pass * TPP + tid / QSPLIT, qslot = tid % QSPLIT;
     const bool active = tile < E::NTILES;
     int        ta = 0, tb = 0;
     if (active)
@@ -410,7 +420,6 @@ namespace mi
 #pragma unroll
       for (int k = 0; k < DD; ++k)
         K[b][k] = 0.0;
-    double rres = 0.0; // residual entry of local dof tid (threads tid < NPC*DIM)
 
     for (int chunk = 0; chunk < NQ / QC; ++chunk)
       {
@@ -441,7 +450,7 @@ namespace mi
         __syncthreads();
 
         // ---- main loop: accumulate the 2x2 tile over this lane's share of the chunk
-        if (active && ABL != 2 && ABL != 3)
+        if (active && ABL != 2 && ABL != 3 && ABL != 4)
           {
             for (int qq = qslot; qq < QC; qq += QSPLIT)
               {
@@ -503,7 +512,7 @@ namespace mi
               }
           }
         // ---- residual (:984-995 collapsed by partition of unity): r_a -= w (tau g_a) + N_a rho w (acc - b)
-        if (tid < NPC * DIM)
+        if (tid < NPC * DIM && pass == 0)
           {
             const int a = tid / DIM, i = tid - a * DIM;
             for (int qq = 0; qq < QC; ++qq)
@@ -517,16 +526,19 @@ namespace mi
       }
 
     // ---- reduce the QSPLIT partial tiles
+    if constexpr (ABL != 4)
+      {
 #pragma unroll
-    for (int o = 1; o < QSPLIT; o <<= 1)
+        for (int o = 1; o < QSPLIT; o <<= 1)
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int k = 0; k < DD; ++k)
-          K[b][k] += __shfl_xor(K[b][k], o, 64);
+            for (int k = 0; k < DD; ++k)
+              K[b][k] += __shfl_xor(K[b][k], o, 64);
+      }
 
     // ---- residual scatter (:769-773; constrained rows get no rhs)
-    if (tid < NPC * DIM)
+    if (tid < NPC * DIM && pass == 0)
       {
         const int     a = tid / DIM, i = tid - a * DIM;
         const int32_t A = s_conn[a];
@@ -545,7 +557,7 @@ namespace mi
           for (int k = 0; k < DD; ++k)
             asm volatile("" ::"v"(K[b][k]));
       }
-    if (active && ABL != 1 && ABL != 2)
+    if (active && ABL != 1 && ABL != 2 && ABL != 4)
       {
         const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
 #pragma unroll
@@ -594,6 +606,7 @@ namespace mi
               }
           }
       }
+      } // pass
   }
 
 
@@ -1497,7 +1510,7 @@ namespace mi
   }
 
   // ------------------------------------------------------------------ CG vector kernels (Jacobi-PCG)
-  // scalars: sc[0..1] rz ping-pong, sc[2] tolerance (absolute), sc[3] final residual; flags: [0] done, [1] its
+  // scalars: sc[0..1] rz ping-pong, sc[2] tolerance (absolute), sc[3] final residual; flags: [0] 1 converged / 2 breakdown (non-finite residual or p.Ap <= 0), [1] its
   //
   // cg_update_p (iteration it >= 1): totals of the previous update's partials give ||r||^2 and r.z;
   // decide convergence (SolverControl: ||r|| <= tol), else p = z + beta p with z = dinv*r.
@@ -1509,6 +1522,17 @@ namespace mi
     const double rr = c.totals ? c.totals[0] : reduce_partials<256>(c.part_rr, c.npart, s_red);
     const double rz = c.totals ? c.totals[1] : reduce_partials<256>(c.part_rz, c.npart, s_red);
     const double res = sqrt(rr);
+    if (!(rr == rr) || !(rz == rz) || rr > 1.79e308 || fabs(rz) > 1.79e308)
+      {
+        // breakdown: a non-finite residual never passes `res <= tol` (SolverControl fails on NaN at once)
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+          {
+            c.flags[0] = 2;
+            c.flags[1] = it - 1;
+            c.sc[3]    = res;
+          }
+        return;
+      }
     if (res <= c.sc[2])
       {
         if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -1545,6 +1569,16 @@ namespace mi
     if (c.flags[0])
       return;
     const double pq    = c.totals ? c.totals[2] : reduce_partials<256>(c.part_pq, c.npart_pq, s_red);
+    if (!(pq > 0.0) || pq > 1.79e308)
+      {
+        // breakdown: p.Ap <= 0 (indefinite tangent or preconditioner) or non-finite; every workgroup sees the same pq
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+          {
+            c.flags[0] = 2;
+            c.flags[1] = it - 1;
+          }
+        return;
+      }
     const double alpha = c.sc[it & 1] / pq;
     if (c.hist && blockIdx.x == 0 && threadIdx.x == 0)
       c.hist[2 * (it - 1)] = alpha;
@@ -1819,6 +1853,8 @@ namespace mi
         c.flags[1] = it;
         if (res <= c.sc[2])
           c.flags[0] = 1;
+        else if (!(rr == rr) || rr > 1.79e308)
+          c.flags[0] = 2;
       }
   }
 
@@ -1941,6 +1977,8 @@ namespace mi
     const double tol = rel_tol >= 0.0 ? rel_tol * sqrt(bb) : -rel_tol;
     double       rz_prev = 1.0, res = sqrt(rr);
     int          it = 0, done = res <= tol;
+    if (!(rr == rr) || !(rz == rz) || rr > 1.79e308)
+      done = 2; // breakdown (non-finite start residual)
     while (!done && it < max_it)
       {
         ++it;
@@ -1950,6 +1988,12 @@ namespace mi
           c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
         __syncthreads();
         const double pq    = block_sum_1024(small_spmv<D>(prm, c.p, c.q, c.p), s_red);
+        if (!(pq > 0.0) || pq > 1.79e308)
+          {
+            done = 2; // breakdown: p.Ap <= 0 or non-finite
+            --it;
+            break;
+          }
         const double alpha = rz_prev / pq;
         srr = srz = 0.0;
         for (int i = tid; i < n; i += 1024)
@@ -1964,6 +2008,8 @@ namespace mi
         rz   = block_sum_1024(srz, s_red);
         res  = sqrt(rr);
         done = res <= tol;
+        if (!(rr == rr) || !(rz == rz) || rr > 1.79e308)
+          done = 2;
       }
     if (tid == 0)
       {
@@ -2265,15 +2311,25 @@ namespace mi
     hipLaunchKernelGGL((assemble_cells<DIM, P, QSPLIT, NT, QC, MINW, ABL>), dim3(p.cell_count), dim3(NT), 0, s, p);
   }
 
+  // full kernel or its residual-only form (AsmParams::residual_only)
+  template <int DIM, int P, int QSPLIT, int NT, int QC>
+  static void launch_asm_sel(const AsmParams &p, hipStream_t s)
+  {
+    if (p.residual_only)
+      launch_asm<DIM, P, QSPLIT, NT, QC, 1, 4>(p, s);
+    else
+      launch_asm<DIM, P, QSPLIT, NT, QC>(p, s);
+  }
+
   int launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s)
   {
     if (p.cell_count <= 0)
       return 0;
-    // <DIM, P, QSPLIT, NT, QC>: NT >= NTILES*QSPLIT and >= NPC*DIM; QC divides NQ
+    // <DIM, P, QSPLIT, NT, QC>: NT >= NPC*DIM; QC divides NQ; NTILES*QSPLIT <= NT for a single pass over the tiles
     if (dim == 3 && degree == 2)
       {
         // 105 tiles x 2 lanes, 64 quadrature points in chunks of QC; variants for A/B timing (mi_set_tuning "asm_variant")
-        switch (p.variant)
+        switch (p.residual_only ? 0 : p.variant)
           {
             case 1:
               launch_asm<3, 2, 2, 256, 16>(p, s); // 54 kB LDS, 2 workgroups per CU: 23.6 ms per assembly at 5M DoFs
@@ -2294,19 +2350,23 @@ namespace mi
               launch_asm<3, 2, 2, 256, 8, 1, 3>(p, s); // timing only: phases A/B + residual + scatter
               break;
             default:
-              launch_asm<3, 2, 2, 256, 8>(p, s); // 36 kB LDS, 3 workgroups per CU: 19.5 ms
+              launch_asm_sel<3, 2, 2, 256, 8>(p, s); // 36 kB LDS, 3 workgroups per CU: 19.5 ms
           }
       }
     else if (dim == 3 && degree == 1)
-      launch_asm<3, 1, 4, 64, 27>(p, s); // 10 tiles x 4
+      launch_asm_sel<3, 1, 4, 64, 27>(p, s); // 10 tiles x 4
+    else if (dim == 3 && degree == 3)
+      launch_asm_sel<3, 3, 1, 576, 5>(p, s); // 528 tiles, 125 points in chunks of 5: 61 kB LDS, one pass
+    else if (dim == 3 && degree == 4)
+      launch_asm_sel<3, 4, 1, 512, 2>(p, s); // 2016 tiles in 4 passes, 216 points in chunks of 2
     else if (dim == 2 && degree == 1)
-      launch_asm<2, 1, 4, 64, 9>(p, s); // 3 tiles
+      launch_asm_sel<2, 1, 4, 64, 9>(p, s); // 3 tiles
     else if (dim == 2 && degree == 2)
-      launch_asm<2, 2, 4, 64, 16>(p, s); // 15 tiles x 4
+      launch_asm_sel<2, 2, 4, 64, 16>(p, s); // 15 tiles x 4
     else if (dim == 2 && degree == 3)
-      launch_asm<2, 3, 2, 128, 25>(p, s); // 36 tiles x 2
+      launch_asm_sel<2, 3, 2, 128, 25>(p, s); // 36 tiles x 2
     else if (dim == 2 && degree == 4)
-      launch_asm<2, 4, 2, 192, 18>(p, s); // 91 tiles x 2
+      launch_asm_sel<2, 4, 2, 192, 18>(p, s); // 91 tiles x 2
     else
       return -1;
     return 0;
@@ -2325,6 +2385,8 @@ namespace mi
     }
     MI_NF(3, 2)
     MI_NF(3, 1)
+    MI_NF(3, 3)
+    MI_NF(3, 4)
     MI_NF(2, 1)
     MI_NF(2, 2)
     MI_NF(2, 3)

@@ -478,7 +478,7 @@ namespace mi
                 cv[v * dim + d] = vx[size_t(id) * dim + d];
             }
           int32_t *cn = &conn[size_t(pos) * npc];
-          int      lat[64][3];
+          int      lat[125][3]; // up to 3D Q4
           for (int a = 0; a < npc; ++a)
             {
               int ai[3];

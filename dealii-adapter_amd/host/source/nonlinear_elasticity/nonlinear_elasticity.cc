@@ -242,9 +242,17 @@ namespace Nonlinear_Elasticity
 
         device->check(mi_update_acceleration(ctx), "mi_update_acceleration"); // :444
 
+        // the convergence test below needs the update criterion AND the residual criterion.  Only when the first holds
+        // (known before the assembly) can this be the last assembly of the step, whose tangent is never multiplied:
+        // then the residual alone is formed (same numbers) and the tangent follows only if the test fails.
+        const bool update_ok =
+          newton_iteration > 0 && (error_update_norm.u <= parameters.tol_u || error_update.u <= 1e-15);
         timer.enter_subsection("Assemble linear system");
         std::cout << " ASM " << std::flush;
-        device->check(mi_assemble(ctx, &error_residual.u), "mi_assemble"); // :446-449
+        if (update_ok)
+          device->check(mi_assemble_residual(ctx, &error_residual.u), "mi_assemble_residual");
+        else
+          device->check(mi_assemble(ctx, &error_residual.u), "mi_assemble"); // :446-449
         timer.leave_subsection();
 
         if (newton_iteration == 0)
@@ -259,6 +267,12 @@ namespace Nonlinear_Elasticity
             std::cout << " CONVERGED! " << std::endl;
             print_conv_footer();
             break;
+          }
+        if (update_ok) // not converged after all: the tangent of this state is needed for the next solve
+          {
+            timer.enter_subsection("Assemble linear system");
+            device->check(mi_assemble(ctx, &error_residual.u), "mi_assemble");
+            timer.leave_subsection();
           }
 
         timer.enter_subsection("Linear solver");

@@ -92,6 +92,8 @@ int mi_partition_describe(const mi_mesh_desc *mesh, int rank, int size, mi_parti
 int mi_partition_spmv_rows(const mi_mesh_desc *mesh, int rank, int size, int64_t *n_slices, int64_t *n_interior_slices,
                            int32_t *rows, int64_t capacity);
 int mi_comm_unique_id(void *out128); /* ncclGetUniqueId */
+/* slabs of the decomposition this context belongs to, and ncclCommCount of its RCCL communicator (0: none) */
+int mi_comm_info(const mi_ctx *ctx, int *team_size, int *rccl_ranks);
 
 /* parameters.cc:61-99 ("Solver" subsection) */
 typedef struct
@@ -143,6 +145,11 @@ int mi_newton_begin_step(mi_ctx *ctx);              /* solution_delta = 0 (:121)
 int mi_update_acceleration(mi_ctx *ctx);            /* :444 -> :592-599                                   */
 int mi_assemble(mi_ctx *ctx, double *res_norm);     /* :446 -> :1044-1087 incl. Neumann :791-859, scatter
                                                        :760-774; *res_norm = get_error_residual :549-560  */
+/* the same system_rhs and norm WITHOUT the tangent (bit-identical residual; tangent, Jacobi diagonal and multigrid
+ * hierarchy keep the state of the last mi_assemble): for the assembly that only feeds the convergence test of
+ * :459-463 -- callers use it when the update criterion already holds and fall back to mi_assemble if the residual
+ * criterion fails.  No reference counterpart (the reference always builds both, :1078-1084). */
+int mi_assemble_residual(mi_ctx *ctx, double *res_norm);
 int mi_cg_solve(mi_ctx *ctx, double rel_tol, int64_t max_it, int *its, double *res);
                                                     /* :472 -> :1153-1191 (Jacobi-PCG, warm start) + :1208 */
 int mi_apply_newton_update(mi_ctx *ctx, double *upd_norm); /* get_error_update :564-576; delta += update :487 */
@@ -216,6 +223,7 @@ enum
   MI_T_NEWMARK,
   MI_T_STEP,               /* whole mi_newmark_step                           */
   MI_T_SELL_COPY,          /* block-CSR -> sliced-ELL copy before the first product with a new tangent */
+  MI_T_ASSEMBLE_RESIDUAL,  /* all colours of one residual-only pass (mi_assemble_residual)              */
   MI_T_COUNT
 };
 typedef struct

@@ -156,6 +156,14 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
   return g->barrier() ? ncclSuccess : ncclSystemError;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+  if (!comm || !count)
+    return ncclInvalidArgument;
+  *count = comm->g->n;
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
   delete comm;

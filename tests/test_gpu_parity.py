@@ -67,7 +67,7 @@ def test_mesh_numbering_matches_oracle():
     assert np.array_equal(ids, P.interface_nodes) and np.allclose(xyz, P.coords[ids], atol=1e-15)
 
 
-@pytest.mark.parametrize("dim,p", [(2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 2)])
+@pytest.mark.parametrize("dim,p", [(2, 1), (2, 2), (2, 3), (2, 4), (3, 1), (3, 2), (3, 3), (3, 4)])
 def test_single_cell_tangent_and_residual(dim, p):
     """one distorted cell, no constraints: K_e and r_e against the as-written reference loop"""
     P, G = _pair(dim, p, (1,) * dim, perturb_amp=0.08, seed=10 + p, roles=[O.FACE_INTERFACE] * 6,
@@ -85,7 +85,8 @@ def test_single_cell_tangent_and_residual(dim, p):
 
 
 @pytest.mark.parametrize("dim,p,reps", [(2, 1, (5, 4)), (2, 2, (4, 3)), (2, 3, (3, 3)), (2, 4, (2, 3)),
-                                        (3, 1, (3, 4, 2)), (3, 2, (3, 2, 3)), (3, 2, (1, 1, 5))])
+                                        (3, 1, (3, 4, 2)), (3, 2, (3, 2, 3)), (3, 2, (1, 1, 5)), (3, 3, (2, 3, 2)),
+                                        (3, 4, (2, 1, 2))])
 def test_global_assembly_with_constraints_and_traction(dim, p, reps):
     """all colours, Dirichlet rows (clamped + z-clamp), Neumann faces with the pull-back quirk"""
     roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
@@ -105,6 +106,30 @@ def test_global_assembly_with_constraints_and_traction(dim, p, reps):
     # a second assembly reproduces the first bit for bit (colouring => deterministic summation order)
     G.assemble()
     assert np.array_equal(G.csr().data, K_g.data) and np.array_equal(G.get(M.V_RHS), r_g)
+
+
+@pytest.mark.parametrize("dim,p,reps", [(2, 3, (4, 3)), (3, 1, (3, 3, 2)), (3, 2, (3, 2, 3)), (3, 3, (2, 2, 2))])
+def test_residual_only_assembly_is_bitwise_the_full_residual(dim, p, reps):
+    """mi_assemble_residual (the pass behind the Newton convergence check): same system_rhs and norm, bit for bit,
+    and the tangent, its SpMV copy and the Jacobi diagonal keep the state of the last full assembly"""
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+    P, G = _pair(dim, p, reps, perturb_amp=0.05, seed=3, roles=roles)
+    _randomise_state(P, G, seed=4)
+    G.update_acceleration()
+    rn_full = G.assemble()
+    r_full, K_full = G.get(M.V_RHS), G.csr().data.copy()
+    x = np.random.default_rng(1).standard_normal(G.n)
+    y_full = G.spmv(x)
+    # move the state, residual-only pass: rhs follows the new state, the tangent stays
+    _randomise_state(P, G, seed=5)
+    G.update_acceleration()
+    rn_res = G.assemble_residual()
+    r_res = G.get(M.V_RHS)
+    assert np.array_equal(G.csr().data, K_full) and np.array_equal(G.spmv(x), y_full)
+    rn_new = G.assemble()
+    assert rn_res == rn_new and np.array_equal(r_res, G.get(M.V_RHS))
+    assert not np.array_equal(r_res, r_full) and rn_res != rn_full
+    assert not np.array_equal(G.csr().data, K_full)
 
 
 def test_neumann_only_residual_isolated():
@@ -256,7 +281,31 @@ def test_cg_reports_non_convergence():
     assert rc == M.MI_ENOCONV_LIN and its == 3 and res > 0
 
 
-@pytest.mark.parametrize("scenario,dim,p", [("FSI3", 2, 1), ("FSI3", 2, 3), ("PF", 2, 2), ("FSI3", 3, 1), ("PF", 3, 2)])
+@pytest.mark.parametrize("path", ["small", "jacobi", "multigrid"])
+def test_cg_breakdown_is_reported_at_once(path):
+    """a NaN right-hand side (or an indefinite operator) must end the solve immediately, as deal.II's SolverControl
+    does, instead of running to n_dofs * multiplier iterations"""
+    P, G = _pair(3, 1, (6, 6, 6) if path == "multigrid" else (3, 3, 3))
+    _randomise_state(P, G, seed=9)
+    G.set_tuning("precond", 1 if path == "multigrid" else 0)
+    G.set_tuning("small_cg", 1 if path == "small" else 0)
+    G.update_acceleration()
+    G.assemble()
+    rhs = G.get(M.V_RHS)
+    rhs[7] = np.nan
+    G.set(M.V_RHS, rhs)
+    rc, its, res = G.cg_solve(rel_tol=1e-10)
+    assert rc == M.MI_ENOCONV_LIN and its <= 1
+    assert b"broke down" in M.lib().mi_last_error(G.h)
+    # the context stays usable: a clean assembly + solve converges afterwards
+    G.set(M.V_NEWTON, np.zeros(G.n))
+    G.assemble()
+    rc, its, res = G.cg_solve(rel_tol=1e-10)
+    assert rc == 0 and its > 1
+
+
+@pytest.mark.parametrize("scenario,dim,p", [("FSI3", 2, 1), ("FSI3", 2, 3), ("PF", 2, 2), ("FSI3", 3, 1), ("PF", 3, 2),
+                                            ("FSI3", 3, 3), ("PF", 3, 4)])
 def test_newmark_steps_interface_displacement(scenario, dim, p):
     """the reference's own geometries: 4 Newmark steps under a ramped traction; interface displacements matched
     by vertex coordinate against the oracle run with the reference solver configuration (CG+SSOR)"""
@@ -325,7 +374,7 @@ def test_state_checkpoint_roundtrip():
 
 def test_rejects_bad_arguments():
     with pytest.raises(M.MiError) as e:
-        M.Context(dim=3, degree=3, reps=(2, 2, 2))
+        M.Context(dim=3, degree=5, reps=(2, 2, 2))
     assert e.value.code == M.MI_EINVAL
     with pytest.raises(M.MiError):
         M.Context(dim=3, degree=1, reps=(2, 2, 2), nu=0.5)

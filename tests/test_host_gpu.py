@@ -114,7 +114,8 @@ def test_executable_nonlinear_implicit_checkpointing(tmp_path):
 
 
 @pytest.mark.parametrize("name,windows,traction", [("pf_neo_3d_direct", 2, lambda k: (25.0, 0.0, 0.0)),
-                                                   ("block_neo_3d_q2", 2, lambda k: (0.0, -2e3 * (k + 1) / 10.0, 0.0))])
+                                                   ("block_neo_3d_q2", 2, lambda k: (0.0, -2e3 * (k + 1) / 10.0, 0.0)),
+                                                   ("fsi3_neo_3d_q3", 2, lambda k: (0.0, -40.0, 0.0))])
 def test_executable_nonlinear_3d(tmp_path, name, windows, traction):
     _, rows = _run_case(name, "elasticity3d", tmp_path)
     get = _prm(name)
@@ -225,25 +226,28 @@ def test_linear_model_matrices_and_steps(dim, p, reps):
 
 
 @pytest.mark.parametrize("name,exe,dim", [("fsi3_linear_2d_shipped", "elasticity", 2),
+                                          ("fsi3_linear_3d_shipped", "elasticity3d", 3),
                                           ("block_linear_3d_q1_cg", "elasticity3d", 3)])
 def test_executable_linear(tmp_path, name, exe, dim):
-    """config 1 (shipped settings: linear, Direct, degree 3, 2D FSI3) and a small config 2 (3D Q1 block, CG)"""
+    """config 1 (shipped settings: linear, Direct, degree 3, FSI3) under -DDIM=2 and -DDIM=3 (parameters.prm:19-22,
+    CMakeLists.txt:15-18), and a small config 2 (3D Q1 block, CG)"""
     stdout, rows = _run_case(name, exe, tmp_path)
     get = _prm(name)
     P = O.LinearProblem(_scenario_desc(get, dim, theta=0.5))
     ids = P.interface_nodes
+    oracle_direct = P.n < 4000  # the oracle's banded LU; beyond that its CG + SSOR at the reference's absolute 1e-10
     dt, exp = float(get("Time step size")), []
     for k in range(len(rows)):
-        t = (0.0, -40.0 * min(1.0, (k + 1) / 2.0)) if dim == 2 else (0.0, -200.0, 0.0)
+        t = (0.0, -40.0 * min(1.0, (k + 1) / 2.0), 0.0)[:dim] if "shipped" in name else (0.0, -200.0, 0.0)
         P.vec(O.L_STRESS)[:] = 0
         for c in range(dim):
             P.vec(O.L_STRESS)[ids * dim + c] = t[c]
-        rc, _, _ = P.step(O.SOLVER_DIRECT if P.n < 4000 else O.SOLVER_CG_SSOR, True)
+        rc, _, _ = P.step(O.SOLVER_DIRECT if oracle_direct else O.SOLVER_CG_SSOR, True)
         assert rc == 0
         exp.append(((k + 1) * dt, P.vec(O.L_D).reshape(-1, dim)[ids].copy()))
     assert len(rows) >= 3
     # CG with the reference's absolute tolerance 1e-10 on both sides: velocities agree to ~1e-10/|A|, so compare at 1e-6
     for r, (t, u) in zip(rows, exp):
         got = r[1:].reshape(-1, dim)
-        assert np.abs(got - u).max() / np.abs(u).max() < (1e-8 if get("Solver type") == "Direct" else 1e-6)
+        assert np.abs(got - u).max() / np.abs(u).max() < (1e-8 if get("Solver type") == "Direct" and oracle_direct else 1e-6)
     assert "No of iterations" in stdout and "Solve system" in stdout
