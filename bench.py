@@ -3,20 +3,30 @@
 neo-Hookean solver on a synthetic 3D Q2 block (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+works as a bare command for every N: with N > 1 and no WORLD_SIZE in the environment it starts the N ranks itself
+as child processes (`python -m torch.distributed.run ...`, before anything touches the GPU) and relays rank 0's
+JSON line; under an external `torch.distributed.run` it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as usual.
 
 A step = one full Newmark step on the resident mesh under the ramped constant interface traction
 (0,-2e3,0) Pa (ramp over the first 10 steps).  Rank 0 prints ONE JSON line.
+
+N > 1: the headline workload is BASELINE configuration 4 as written -- the ONE 59^3-cell block (5,055,477 DoFs)
+domain-decomposed over the N GPUs ("scaling": "strong"); the weak-scaling number (one 59^3 block per GPU) is
+measured afterwards and reported as a second field, `weak_scaling`.
 """
 import argparse
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")
 
 
 def _pkg():
@@ -48,29 +58,151 @@ def spmv_bytes_scalar_csr(nnodes, nnzb, dim):
     return 12 * nnzb * dim * dim + 4 * (n + 1) + 16 * n
 
 
-def cpu_baseline(n_cells_side, threads):
-    """one Newmark step of the CPU oracle (restatement of the reference algorithm: WorkStream-style
-    assembly over all host threads, CG + SSOR(0.65)) on a bounded sample of the same workload"""
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def socket0_cores():
+    """one logical CPU per physical core of the first socket, restricted to the CPUs this process may use;
+    returns (cpus, model name)"""
+    allowed = sorted(os.sched_getaffinity(0))
+    pkg_of, first_sibling = {}, {}
+    for c in allowed:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            pkg_of[c] = int(open(base + "physical_package_id").read())
+            sib = open(base + "thread_siblings_list").read().strip()
+            first_sibling[c] = int(sib.replace("-", ",").split(",")[0])
+        except (OSError, ValueError):
+            pkg_of[c], first_sibling[c] = 0, c
+    pkg0 = min(pkg_of.values())
+    cpus = sorted({first_sibling[c] for c in allowed if pkg_of[c] == pkg0 and first_sibling[c] in pkg_of})
+    model = "unknown CPU"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return cpus or allowed, model
+
+
+def cpu_baseline_worker(cells, its_a, its_b, full):
+    """runs in a CHILD process that never touches the GPU: pins itself to one socket (one thread per physical core)
+    BEFORE the oracle's OpenMP runtime starts, then times the CPU restatement of the reference algorithm on BASELINE
+    configuration 3 (cells = 34: 985,527 DoFs).  Prints one JSON object.
+      full = 0: bounded sample -- one assembly, `its_a` CG+SSOR(0.65) iterations, `its_b` CG+Jacobi iterations
+      full = 1: whole first Newmark step with (A) CG+SSOR(0.65) and (B) CG+Jacobi (minutes; tools/cpu_baseline_full.py)"""
+    cpus, model = socket0_cores()
+    os.sched_setaffinity(0, cpus)
+    os.environ["OMP_PROC_BIND"] = "close"
+    os.environ["OMP_PLACES"] = "cores"
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    O.lib().orc_set_threads(threads)
-    d = O.make_desc(dim=3, degree=2, reps=(n_cells_side,) * 3)
-    P = O.Problem(d)
-    P.set_interface_traction((0.0, -2e2, 0.0))  # first ramp step
-    t0 = time.perf_counter()
-    rc, info = P.newmark_step(O.SOLVER_CG_SSOR, tol_lin=1e-6, max_it_mult=1.0)
-    dt = time.perf_counter() - t0
-    assert rc == 0
-    return {
-        "value": P.n / dt,
-        "unit": "DoF-updates/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": "1 Newmark step, 3D Q2 block %d^3 cells (%d DoFs), CG+SSOR(0.65) tol 1e-6, %d Newton its, "
-                  "%d CG its, assembly %.1fs + solve %.1fs; restatement of the reference algorithm, not the "
-                  "deal.II binary" % (n_cells_side, P.n, info.newton_iterations, info.lin_its_total,
-                                      info.t_assemble, info.t_solve),
-    }
+    O.lib().orc_set_threads(len(cpus))
+    out = {"cells": cells, "cores": len(cpus), "threads": len(cpus), "cpu_model": model,
+           "pinned_cpus": "%d-%d" % (cpus[0], cpus[-1]) if cpus == list(range(cpus[0], cpus[-1] + 1)) else cpus}
+
+    def fresh():
+        P = O.Problem(O.make_desc(dim=3, degree=2, reps=(cells,) * 3))
+        P.set_interface_traction((0.0, -2e2, 0.0))  # first ramp step
+        return P
+
+    P = fresh()
+    out["n_dofs"], out["nnz"] = int(P.n), int(P.nnz)
+    if full:
+        for key, solver in (("A_cg_ssor", O.SOLVER_CG_SSOR), ("B_cg_jacobi", O.SOLVER_CG_JACOBI)):
+            P = fresh()
+            t0 = time.perf_counter()
+            rc, info = P.newmark_step(solver, tol_lin=1e-6, max_it_mult=1.0)
+            dt = time.perf_counter() - t0
+            out[key] = {"rc": rc, "t_step_s": dt, "t_assemble_s": info.t_assemble, "t_solve_s": info.t_solve,
+                        "newton_iterations": info.newton_iterations, "assemblies": info.assemblies,
+                        "cg_iterations": info.lin_its_total, "dof_updates_per_s": P.n / dt}
+            print(json.dumps(out), file=sys.stderr, flush=True)
+    else:
+        P.update_acceleration()
+        t0 = time.perf_counter()
+        P.assemble()
+        out["t_assembly_s"] = time.perf_counter() - t0
+        for key, solver, its in (("A_cg_ssor", O.SOLVER_CG_SSOR, its_a), ("B_cg_jacobi", O.SOLVER_CG_JACOBI, its_b)):
+            P.vec(O.V_NEWTON)[:] = 0.0
+            t0 = time.perf_counter()
+            _, done, _ = P.solve_linear(solver, tol_lin=1e-30, max_it_mult=(its + 0.5) / P.n)
+            out[key] = {"iterations_timed": done, "t_per_iteration_s": (time.perf_counter() - t0) / max(done, 1)}
+    print(json.dumps(out))
+
+
+def cpu_baseline(cells, its_a, its_b):
+    """bounded CPU sample on the metric's neighbouring configuration 3 (34^3 Q2 cells), one pinned socket.  Per-unit
+    times are measured live; the unit counts of a whole step (assemblies, CG iterations -- deterministic for this
+    algorithm) come from the full run of the same code committed in profiles/r02/cpu_baseline_config3_full.json"""
+    small = cells <= 12  # seconds of CPU work: time the whole step instead of a sample
+    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                        "%d,%d,%d,%d" % (cells, its_a, its_b, 1 if small else 0)], capture_output=True, text=True, timeout=1500)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"value": None, "unit": "DoF-updates/s", "cores": 0, "kind": "port",
+                "sample": "CPU sample failed: " + (p.stderr or p.stdout)[-300:]}
+    s = json.loads(lines[-1])
+    if small:
+        a, b = s["A_cg_ssor"], s["B_cg_jacobi"]
+        return {"value": a["dof_updates_per_s"], "value_cg_jacobi": b["dof_updates_per_s"], "unit": "DoF-updates/s",
+                "cores": s["cores"], "threads": s["threads"], "kind": "port", "cpu_model": s["cpu_model"],
+                "pinned_cpus": s["pinned_cpus"], "n_dofs": s["n_dofs"],
+                "sample": "whole first Newmark step of a 3D Q2 block %d^3 cells (%d DoFs) on ONE pinned socket (%s, %d cores): (A) "
+                          "CG+SSOR(0.65) %d Newton / %d CG iterations in %.2f s, (B) CG+Jacobi %d / %d in %.2f s; restatement "
+                          "of the reference algorithm (oracle/), not the deal.II binary"
+                          % (cells, s["n_dofs"], s["cpu_model"], s["cores"], a["newton_iterations"], a["cg_iterations"],
+                             a["t_step_s"], b["newton_iterations"], b["cg_iterations"], b["t_step_s"])}
+    counts = None
+    if os.path.exists(CPU_FULL_RUN):
+        full = json.load(open(CPU_FULL_RUN))
+        if full.get("cells") == cells and "A_cg_ssor" in full:
+            counts = full
+    ta, tia, tib = s["t_assembly_s"], s["A_cg_ssor"]["t_per_iteration_s"], s["B_cg_jacobi"]["t_per_iteration_s"]
+    out = {"unit": "DoF-updates/s", "cores": s["cores"], "kind": "port", "threads": s["threads"],
+           "cpu_model": s["cpu_model"], "pinned_cpus": s["pinned_cpus"], "config": "3 (34^3 Q2 cells)" if cells == 34 else
+           "%d^3 Q2 cells" % cells, "n_dofs": s["n_dofs"], "t_assembly_s": ta, "t_cg_ssor_iteration_s": tia,
+           "t_cg_jacobi_iteration_s": tib}
+    what = ("BASELINE configuration 3 (3D Q2 block %d^3 cells, %d DoFs, %d nnz), first ramp step, ONE socket pinned (%s, %d "
+            "cores, %d threads): measured live = 1 assembly (%.1f s, threaded over cells, ordered scatter), %d CG+SSOR(0.65) "
+            "iterations (%.2f s each; SSOR sweeps serial as in deal.II), %d CG+Jacobi iterations (%.3f s each)"
+            % (cells, s["n_dofs"], s["nnz"], s["cpu_model"], s["cores"], s["threads"], ta,
+               s["A_cg_ssor"]["iterations_timed"], tia, s["B_cg_jacobi"]["iterations_timed"], tib))
+    if counts:
+        a, b = counts["A_cg_ssor"], counts["B_cg_jacobi"]
+        t_a = a["assemblies"] * ta + a["cg_iterations"] * tia
+        t_b = b["assemblies"] * ta + b["cg_iterations"] * tib
+        out["value"] = s["n_dofs"] / t_a
+        out["value_cg_jacobi"] = s["n_dofs"] / t_b
+        out["step_estimate_s"] = {"A_cg_ssor": t_a, "B_cg_jacobi": t_b}
+        out["full_run"] = {"file": os.path.relpath(CPU_FULL_RUN, ROOT), "A_t_step_s": a["t_step_s"], "B_t_step_s": b["t_step_s"],
+                           "A_dof_updates_per_s": a["dof_updates_per_s"], "B_dof_updates_per_s": b["dof_updates_per_s"]}
+        what += ("; value = DoFs / (assemblies x t_assembly + CG iterations x t_iteration) with the step's unit counts from the "
+                 "full run of the same code in %s: (A) CG+SSOR %d assemblies + %d iterations (that run: %.0f s per step), "
+                 "(B) CG+Jacobi %d + %d (%.0f s)" % (os.path.relpath(CPU_FULL_RUN, ROOT), a["assemblies"], a["cg_iterations"],
+                                                     a["t_step_s"], b["assemblies"], b["cg_iterations"], b["t_step_s"]))
+    else:
+        out["value"] = None
+        what += "; no committed full run for this size: per-unit times only"
+    out["sample"] = what + "; restatement of the reference algorithm (oracle/), not the deal.II binary"
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- GPU side
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """start the N ranks as child processes of this (GPU-free) process and pass their exit code on"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -86,14 +218,25 @@ def main():
                     help="f32: the multigrid smoother multiplies with an fp32-rounded copy of the level matrices (the CG's "
                          "own product, residuals, vectors and all arithmetic stay fp64); opt-in, not the headline setting")
     ap.add_argument("--slabs", type=int, default=1, help="diagnostic: cut the mesh into this many slabs on ONE GPU")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N GPUs: weak = every GPU gets its own cells^3 block of the beam (cells x cells x N*cells, default); "
-                         "strong = the one cells^3 block is cut into N slabs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N GPUs: strong = the one cells^3 block (BASELINE configuration 4) is cut into N parts (default); "
+                         "weak = every GPU gets its own cells^3 block of a beam (cells x cells x N*cells)")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the second (weak-scaling) measurement")
     ap.add_argument("--no-rccl", action="store_true",
                     help="diagnostic: with N ranks every rank solves its own copy of the single-GPU problem (no RCCL "
                          "communicator); exercises launcher, rendezvous and reporting on a box with fewer GPUs than ranks")
-    ap.add_argument("--cpu-cells", type=int, default=16, help="cells per side of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--cpu-cells", type=int, default=34,
+                    help="cells per side of the CPU-baseline sample (34 = BASELINE configuration 3; 0: skip)")
+    ap.add_argument("--cpu-its", type=str, default="8,30", help="CG iterations timed by the CPU sample: SSOR,Jacobi")
+    ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.cpu_worker:  # child of cpu_baseline(): CPU only
+        c, a, b, full = (int(x) for x in args.cpu_worker.split(","))
+        cpu_baseline_worker(c, a, b, full)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU in this process
 
     import torch
     import torch.distributed as dist
@@ -103,85 +246,89 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world),
-                  file=sys.stderr)
+            print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     # one process per GPU; a launcher that narrows the visible devices to one per process is honoured
     ndev = torch.cuda.device_count()
     if ndev == 0:
         print("bench.py: no GPU visible (the hot path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    replicas = world > 1 and args.no_rccl
+    if world > 1 and not replicas and ndev < world:
+        print("bench.py: %d ranks but %d visible GPUs (RCCL needs one GPU per rank; --no-rccl runs replicas)" % (world, ndev),
+              file=sys.stderr)
+        sys.exit(2)
     device = local_rank if local_rank < ndev else 0
     torch.cuda.set_device(device)
     M = _pkg()
     n = args.cells
     uid = None
-    replicas = world > 1 and args.no_rccl
     if world > 1:
         # control plane (rendezvous, unique-id broadcast, barriers, max over ranks) on gloo; the data path --
         # ghost-plane send/recv and scalar all-reduces of the CG -- runs on RCCL over xGMI inside the library
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
-        box = [M.comm_unique_id() if rank == 0 else None]
+        box = [M.comm_unique_id() if rank == 0 and not replicas else None]
         dist.broadcast_object_list(box, src=0)
         uid = None if replicas else box[0]
-    # z-slabs, one per GPU.  weak scaling: the block grows along z with the number of GPUs (cubic cells of the same
-    # size, cells^3 of them per GPU: at N=1 exactly the 59^3 case the metric names); strong: the 59^3 block is cut
     parts = args.slabs if (world == 1 or replicas) else world
-    nz = n * parts if args.scaling == "weak" else n
-    G = M.Context(dim=3, degree=2, reps=(n, n, nz), lo=(0, 0, 0), hi=(1, 1, nz / n), mu=0.5e6, nu=0.4, rho=1000.0,
-                  beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
-                  world=1 if replicas else world, unique_id=uid, slabs=args.slabs if (world == 1 or replicas) else 1)
-    G.set_tuning("precond", 1 if args.precond == "mg" else 0)
-    if args.precond_storage == "f32":
-        G.set_tuning("precond_storage", 32)
-    nnzb = G.nnz // 9
     traction = (0.0, -2e3, 0.0)
-
-    def one_step(k):
-        ramp = min(1.0, (k + 1) / 10.0)
-        G.set_interface_traction(tuple(ramp * t for t in traction))
-        _, info = G.newmark_step(tol_lin=args.tol_lin, max_it_mult=1.0)
-        return info
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_step(k)
-    G.set_profiling(True)
-    G.reset_timings()
-    barrier()
-    t0 = time.perf_counter()
-    newton = cg_its = assemblies = 0
-    for k in range(args.steps):
-        info = one_step(args.warmup + k)
-        newton += info.newton_iterations
-        cg_its += info.lin_its_total
-        assemblies += info.assemblies
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    tm = G.timings()
+    def measure(scaling, cells, steps, warmup, uid_):
+        """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
+        nz = cells * parts if scaling == "weak" else cells
+        G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
+                      rho=1000.0, beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
+                      world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
+        G.set_tuning("precond", 1 if args.precond == "mg" else 0)
+        if args.precond_storage == "f32":
+            G.set_tuning("precond_storage", 32)
 
+        def one_step(k):
+            ramp = min(1.0, (k + 1) / 10.0)
+            G.set_interface_traction(tuple(ramp * t for t in traction))
+            _, info = G.newmark_step(tol_lin=args.tol_lin, max_it_mult=1.0)
+            return info
+
+        for k in range(warmup):
+            one_step(k)
+        G.set_profiling(True)
+        G.reset_timings()
+        barrier()
+        t0 = time.perf_counter()
+        newton = cg_its = assemblies = 0
+        for k in range(steps):
+            info = one_step(warmup + k)
+            newton += info.newton_iterations
+            cg_its += info.lin_its_total
+            assemblies += info.assemblies
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        r = {"G": G, "elapsed": elapsed, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
+             "tm": G.timings(), "comm": G.comm_info()}
+        return r
+
+    R = measure(args.scaling, n, args.steps, args.warmup, uid)
+    G, elapsed, tm, nz = R["G"], R["elapsed"], R["tm"], R["nz"]
+    out = None
     if rank == 0:
+        nnzb = G.nnz // 9
         ms_step = 1e3 * elapsed / args.steps
         spmv_ms, spmv_n = tm["spmv"]
         spmv_avg_ms = spmv_ms / max(spmv_n, 1)
         share = 1 if replicas else world
         bytes_bsr = spmv_bytes(G.nnodes, nnzb, 3) // share  # bytes of the rows this rank owns
         achieved = bytes_bsr / (spmv_avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
-        # HBM traffic of the same kernel on the same workload from the committed PMC passes (rocprofv3 --pmc cannot be
-        # collected from inside this process); only quoted when the workload is the one that was profiled
-        traffic = None
-        pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_icol_n59.json")
-        if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
-            traffic = json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9  # GB per launch
+        # whole-step view: the algorithmic bytes of every fine-level product and assembly of a step / the step time
         out = {
             "metric": "DoF-updates/sec per Newmark step (assembly+CG), 3D Q2 ~5M DoFs",
             "value": G.n * (world if replicas else 1) * args.steps / elapsed,
@@ -196,11 +343,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %dx%dx%d cells (%d^3 per GPU), %d DoFs, %d nnz, "
+                "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %dx%dx%d cells, %d DoFs, %d nnz, "
                             "Newton+Newmark, %s-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
-                            % (n, n, nz, n, G.n, G.nnz, "multigrid" if args.precond == "mg" else "Jacobi", args.tol_lin),
-                "preconditioner": "geometric multigrid V-cycle (Chebyshev-Jacobi smoothing, re-assembled coarse levels; Q2 and "
-                                  "Q1 levels of the fine cells distributed over the slabs, coarser levels replicated)"
+                            % (n, n, nz, G.n, G.nnz, "multigrid" if args.precond == "mg" else "Jacobi", args.tol_lin),
+                "preconditioner": "geometric multigrid V-cycle (Chebyshev block-Jacobi smoothing, re-assembled coarse levels; Q2 "
+                                  "and Q1 levels of the fine cells distributed over the slabs, coarser levels replicated)"
                 if args.precond == "mg" else "Jacobi",
                 "preconditioner_storage": args.precond_storage,
                 "n_dofs": G.n,
@@ -208,13 +355,18 @@ def main():
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs emulated on one GPU" % args.slabs) if world == 1 else
                 ("%d independent replicas (--no-rccl diagnostic)" % world if replicas else
                  "%d z-slabs (one per GPU), ghost-cell redundant assembly, RCCL send/recv halo + all-reduce" % world),
-                "newton_iterations_per_step": newton / args.steps,
-                "cg_iterations_per_step": cg_its / args.steps,
-                "assemblies_per_step": assemblies / args.steps,
+                "team_size": R["comm"][0],
+                "rccl_ranks": R["comm"][1],
+                "newton_iterations_per_step": R["newton"] / args.steps,
+                "cg_iterations_per_step": R["cg_its"] / args.steps,
+                "assemblies_per_step": R["assemblies"] / args.steps,
                 "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
                 "ms_cg_per_step": tm["cg_total"][0] / args.steps,
                 "ms_sell_copy_per_step": tm["sell_copy"][0] / args.steps,
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
+                "ms_assemble_residual_only_pass": tm["assemble_residual"][0] / max(tm["assemble_residual"][1], 1),
+                "tangent_assemblies_per_step": tm["assemble_cells"][1] / args.steps,
+                "residual_only_passes_per_step": tm["assemble_residual"][1] / args.steps,
             },
             "roofline": {
                 "kernel": "sell_spmv<3,2,0,1,true,false,false,true> = <D=3, 2 blocks in flight, no ablation, non-temporal matrix "
@@ -226,8 +378,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_unit": "GB per launch (PMC: TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1 KiB, profiles/r01/pmc_spmv_icol_n59.json)",
+                # HBM bytes from PMC counters cannot be collected from inside this process: the per-launch figure of the
+                # committed counter passes is quoted under its own name, `traffic` itself stays null
+                "traffic": None,
                 "algorithmic_GB_per_launch": bytes_bsr / 1e9,
                 "bytes_per_launch": bytes_bsr,
                 "launches_timed": spmv_n,
@@ -236,9 +389,56 @@ def main():
                 if spmv_n else 0.0,
             },
         }
-        if args.cpu_cells > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_cells, os.cpu_count() or 1)
-        print(json.dumps(out))
+        # whole-step view next to the per-kernel fraction: algorithmic bytes of all fine-level products (CG + smoother),
+        # tangent assemblies (8 nnz + connectivity + gathers + rhs), residual-only passes and layout copies of
+        # one step / the step's wall time
+        n_prod = (spmv_n + tm["spmv_precond"][1]) / args.steps
+        asm_bytes = 8 * G.nnz + 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n
+        res_bytes = 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n
+        step_bytes = (n_prod * spmv_bytes(G.nnodes, nnzb, 3) + tm["assemble_cells"][1] / args.steps * asm_bytes +
+                      tm["assemble_residual"][1] / args.steps * res_bytes + tm["sell_copy"][1] / args.steps * 16 * G.nnz +
+                      120 * G.n) / share
+        out["roofline"]["whole_step"] = {
+            "fine_level_products_per_step": n_prod, "algorithmic_GB_per_step": step_bytes / 1e9,
+            "GB_per_s": step_bytes / 1e9 / (ms_step * 1e-3), "frac": step_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
+            "ms_fine_products_precond_per_step": tm["spmv_precond"][0] / args.steps,
+            "ms_fine_products_cg_per_step": spmv_ms / args.steps}
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_spmv_n59.json")
+        if not os.path.exists(pmc_file):
+            pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_icol_n59.json")
+        if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
+            out["roofline"]["traffic_from_committed_profile"] = {
+                "GB_per_launch": json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9,
+                "source": os.path.relpath(pmc_file, ROOT),
+                "how": "rocprofv3 --pmc, one counter per pass: TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1 KiB (tools/pmc_spmv.sh)"}
+    del G, R
+    # ---- second field for N > 1: weak scaling (one cells^3 block per GPU)
+    if world > 1 and not replicas and not args.no_weak and args.scaling == "strong":
+        uid2 = None
+        box = [M.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        uid2 = box[0]
+        W = measure("weak", n, args.steps, args.warmup, uid2)
+        if rank == 0:
+            out["weak_scaling"] = {"value": W["G"].n * args.steps / W["elapsed"], "unit": "DoF-updates/s",
+                                   "ms_per_step": 1e3 * W["elapsed"] / args.steps, "n_dofs": W["G"].n,
+                                   "workload": "%dx%dx%d cells (%d^3 per GPU)" % (n, n, W["nz"], n),
+                                   "cg_iterations_per_step": W["cg_its"] / args.steps}
+        del W
+    if rank == 0 and world == 1 and args.cpu_cells > 0:
+        # the GPU on the CPU sample's own configuration, beside it
+        its_a, its_b = (int(x) for x in args.cpu_its.split(","))
+        if args.cpu_cells != n or args.slabs != 1:
+            S = measure("strong", args.cpu_cells, 3, 1, None)
+            gpu_same = {"value": S["G"].n * 3 / S["elapsed"], "ms_per_step": 1e3 * S["elapsed"] / 3, "n_dofs": S["G"].n,
+                        "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1}
+            del S
+        else:
+            gpu_same = {"value": out["value"], "ms_per_step": out["ms_per_step"], "n_dofs": out["config"]["n_dofs"]}
+        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, its_a, its_b)
+        out["cpu_baseline"]["gpu_same_config"] = gpu_same
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

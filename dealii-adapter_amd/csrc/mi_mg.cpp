@@ -217,17 +217,21 @@ namespace mi_detail
     // interior rows), the coarser levels are replicated
     int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of, const ChebFusion *cheb = nullptr)
     {
+      const int t  = (l == 0) ? tic(T.members[0], MI_T_SPMV_PRECOND) : -1; // fine-level products, for the byte accounting
+      int       rc = MI_OK;
       if (is_dist(T, l))
-        return team_spmv(
+        rc = team_spmv(
           T, [l](mi_ctx *m) { return m->mg->levels[l].ctx; }, x_of, [l](mi_ctx *m) { return m->mg->levels[l].q(); },
           nullptr, true, cheb);
-      for (size_t k = 0; k < T.members.size(); ++k)
-        {
-          mi_ctx  *m = T.members[k];
-          MgLevel &L = m->mg->levels[l];
-          enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr, 0, true, cheb ? &cheb[k] : nullptr);
-        }
-      return MI_OK;
+      else
+        for (size_t k = 0; k < T.members.size(); ++k)
+          {
+            mi_ctx  *m = T.members[k];
+            MgLevel &L = m->mg->levels[l];
+            enqueue_spmv(L.ctx, x_of(m), L.q(), nullptr, nullptr, nullptr, 0, true, cheb ? &cheb[k] : nullptr);
+          }
+      toc(T.members[0], t);
+      return rc;
     }
 
     // power iteration for lambda_max(D^-1 A); level 0 is distributed over the team, the others are replicated

@@ -127,7 +127,7 @@ namespace mi
     for (int64_t c = 0; c < ncells; ++c)
       {
         const int ci[3] = {int(c % rr[0]), int((c / rr[0]) % rr[1]), int(c / (int64_t(rr[0]) * rr[1]))};
-        int       ai[64][3];
+        int       ai[125][3]; // up to 3D Q4
         for (int a = 0; a < npc; ++a)
           {
             ai[a][0] = a % np1;

@@ -38,16 +38,40 @@ def test_bench_json_line_contract():
     assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert r["traffic"] is None  # the PMC passes were collected for the 59^3 workload only
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    for k in ("value", "unit", "cores", "kind", "sample", "gpu_same_config"):
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == d["unit"] and c["cores"] >= 1 and c["value"] > 0
+    assert "pinned" in c["sample"] and c["gpu_same_config"]["n_dofs"] == 3 * 7 ** 3
+    w = r["whole_step"]
+    assert w["fine_level_products_per_step"] >= d["config"]["cg_iterations_per_step"] and 0 < w["frac"] < 1
+    assert d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 0 and d["config"]["team_size"] == 1
+
+
+def test_bench_gpus_2_as_a_bare_command():
+    """`python bench.py --gpus N` is what the driver runs: with no WORLD_SIZE in the environment bench.py starts the
+    N ranks itself (child processes, before anything touches the GPU) and relays rank 0's single JSON line.  On the
+    one-GPU box the ranks are replicas (--no-rccl); without that switch it refuses loudly instead of hanging in RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-rccl", "--cells", "6", "--steps", "2",
+           "--warmup", "1"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "replicas" and d["config"]["rccl_ranks"] == 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run(cmd[:4] + cmd[5:], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+        assert out.returncode != 0 and "visible GPUs" in out.stderr
 
 
 def test_bench_options_and_smoke():
     d = _run(["--cells", "6", "--steps", "1", "--warmup", "1", "--cpu-cells", "0", "--slabs", "2", "--scaling", "strong",
               "--precond", "jacobi"])
     assert "cpu_baseline" not in d and d["scaling"] == "strong" and "2 slabs" in d["config"]["decomposition"]
-    d = _run(["--cells", "6", "--steps", "1", "--warmup", "1", "--cpu-cells", "0", "--slabs", "2", "--precond-storage", "f32"])
+    d = _run(["--cells", "6", "--steps", "1", "--warmup", "1", "--cpu-cells", "0", "--slabs", "2", "--precond-storage", "f32",
+              "--scaling", "weak"])
     assert d["scaling"] == "weak" and d["config"]["n_dofs"] == 3 * 13 * 13 * 25
     out = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, capture_output=True,
                          text=True, timeout=600)
