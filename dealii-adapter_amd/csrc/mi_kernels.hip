@@ -1005,8 +1005,8 @@ namespace mi
         s_qw[tid] = prm.tab1d[2 * NQ1 * NP1 + tid];
         s_qx[tid] = prm.tab1d[2 * NQ1 * NP1 + NQ1 + tid];
       }
-    if (tid < NPC)
-      s_conn[tid] = prm.conn[int64_t(cell) * NPC + tid];
+    for (int i = tid; i < NPC; i += 64) // 3D Q4 has 125 nodes per cell
+      s_conn[i] = prm.conn[int64_t(cell) * NPC + i];
     if (tid < NV * DIM)
       s_verts[tid] = prm.cverts[int64_t(cell) * (NV * DIM) + tid];
     __syncthreads();
