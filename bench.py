@@ -403,6 +403,14 @@ def main():
             "GB_per_s": step_bytes / 1e9 / (ms_step * 1e-3), "frac": step_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
             "ms_fine_products_precond_per_step": tm["spmv_precond"][0] / args.steps,
             "ms_fine_products_cg_per_step": spmv_ms / args.steps}
+        if world == 1 and args.slabs == 1:
+            # streaming calibration in the SAME process: a pure read of the 8*nnz-byte block-CSR value array (the box's
+            # achievable HBM ceiling; boxes of the pool differ on the gather-heavy product, not on this kernel)
+            G.set_tuning("spmv_variant", 13)
+            ms_cal = G.bench_spmv(10)
+            G.set_tuning("spmv_variant", 3)
+            out["roofline"]["calibration_stream_read"] = {"ms": ms_cal, "GB": 8 * G.nnz / 1e9,
+                                                          "GB_per_s": 8 * G.nnz / ms_cal / 1e6}
         pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_spmv_n59.json")
         if not os.path.exists(pmc_file):
             pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_icol_n59.json")

@@ -1405,7 +1405,9 @@ namespace mi
                             for (int j = 0; j < D; ++j)
                               s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
                           }
-                        const double dn    = prm.cheb_c1 * prm.cheb_d[idx] + prm.cheb_c2 * s;
+                        // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a
+                        // solve that broke down)
+                        const double dn    = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * prm.cheb_d[idx] : 0.0) + prm.cheb_c2 * s;
                         prm.cheb_d[idx]    = dn;
                         prm.cheb_xout[idx] = prm.x[idx] + dn;
                       }
@@ -1554,12 +1556,13 @@ namespace mi
     const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
     if (c.hist && blockIdx.x == 0 && threadIdx.x == 0)
       c.hist[2 * (it - 1) + 1] = beta;
+    // it == 1: the old p is not read (0 * NaN would keep the remains of a solve that broke down alive)
     if (c.z)
       for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-        c.p[i] = c.z[i] + beta * c.p[i];
+        c.p[i] = c.z[i] + (it == 1 ? 0.0 : beta * c.p[i]);
     else
       for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-        c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
+        c.p[i] = c.dinv[i] * c.r[i] + (it == 1 ? 0.0 : beta * c.p[i]);
   }
 
   // cg_update_xr: alpha = rz / (p.Ap); x += alpha p; r -= alpha Ap; partials of ||r||^2 and r.dinv.r
@@ -1629,7 +1632,7 @@ namespace mi
     if (i >= n)
       return;
     const double res = b[i] - (q ? q[i] : 0.0);
-    const double dn  = c1 * d[i] + c2 * dinv[i] * res;
+    const double dn  = (c1 != 0.0 ? c1 * d[i] : 0.0) + c2 * dinv[i] * res; // first step: old d not read
     d[i]             = dn;
     x[i]             = (q ? x[i] : 0.0) + dn; // first step starts from x = 0
   }
@@ -1985,7 +1988,7 @@ namespace mi
         const double beta = (it == 1) ? 0.0 : rz / rz_prev;
         rz_prev           = rz;
         for (int i = tid; i < n; i += 1024)
-          c.p[i] = c.dinv[i] * c.r[i] + beta * c.p[i];
+          c.p[i] = c.dinv[i] * c.r[i] + (it == 1 ? 0.0 : beta * c.p[i]);
         __syncthreads();
         const double pq    = block_sum_1024(small_spmv<D>(prm, c.p, c.q, c.p), s_red);
         if (!(pq > 0.0) || pq > 1.79e308)
@@ -2108,7 +2111,7 @@ namespace mi
 #pragma unroll
         for (int j = 0; j < D; ++j)
           s += dinv[n * (D * D) + i * D + j] * res[j];
-        const double dn = c1 * d[n * D + i] + c2 * s;
+        const double dn = (c1 != 0.0 ? c1 * d[n * D + i] : 0.0) + c2 * s; // first step: old d not read
         d[n * D + i]    = dn;
         x[n * D + i]    = (q ? x[n * D + i] : 0.0) + dn;
       }
