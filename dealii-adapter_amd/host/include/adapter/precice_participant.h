@@ -10,6 +10,11 @@
 //   <!-- replay: read-data = ramp 10 0 -2000 0 -->      traction vector, linear ramp over 10 windows
 //   <!-- replay: read-data = constant 0 -40 0 -->       constant traction vector
 //   <!-- replay: read-data = trace forces.txt -->       rows "t fx fy fz", linear interpolation in t
+//   <!-- replay: read-data = vertex-trace forces.txt --> a recorded per-vertex trace (e.g. the fluid forces of a Turek-Hron
+//                                                       FSI3 run): rows "t vertex fx fy [fz]" (dimensions values), vertex =
+//                                                       the id handed out by setMeshVertices (position order); every time
+//                                                       frame lists every vertex; linear interpolation in t per vertex
+//   <!-- replay: write-vertices = vertices.txt -->      "vertex x y [z]" of the coupling mesh, for producing such traces
 //   <!-- replay: iterations = 3 -->                     coupling iterations per window (implicit schemes)
 //   <!-- replay: write-log = solid-displacement.log --> one row per completed window: t, then all written values
 // Scheme, dimensions, time-window-size and max-time (or max-time-windows) are read from the usual tags.
@@ -96,6 +101,30 @@ namespace precice
                 v >> base_[0] >> base_[1] >> base_[2];
               else if (mode_ == "ramp")
                 v >> ramp_ >> base_[0] >> base_[1] >> base_[2];
+              else if (mode_ == "vertex-trace")
+                {
+                  std::string file;
+                  v >> file;
+                  std::ifstream tf(file);
+                  if (!tf)
+                    throw std::runtime_error("replay participant: trace file <" + file + "> not found");
+                  std::string row;
+                  while (std::getline(tf, row))
+                    {
+                      if (row.empty() || row[0] == '#')
+                        continue;
+                      std::stringstream r(row);
+                      VertexSample      p{};
+                      r >> p.t >> p.vertex;
+                      for (int d = 0; d < dims_; ++d)
+                        r >> p.f[d];
+                      if (!r)
+                        throw std::runtime_error("replay participant: malformed row in <" + file + ">: " + row);
+                      vertex_rows_.push_back(p);
+                    }
+                  if (vertex_rows_.empty())
+                    throw std::runtime_error("replay participant: empty trace file <" + file + ">");
+                }
               else if (mode_ == "trace")
                 {
                   std::string file;
@@ -127,6 +156,8 @@ namespace precice
             }
           else if (key == "write-log")
             v >> log_file_;
+          else if (key == "write-vertices")
+            v >> vertices_file_;
           else
             throw std::runtime_error("replay participant: unknown directive <" + key + ">");
         }
@@ -144,6 +175,20 @@ namespace precice
       positions_.assign(positions.data(), positions.data() + positions.size());
       for (std::size_t i = 0; i < ids.size(); ++i)
         ids[i] = int(i);
+      if (!vertices_file_.empty())
+        {
+          std::ofstream vf(vertices_file_);
+          vf << "# vertex x y" << (dims_ == 3 ? " z" : "") << "\n" << std::setprecision(17);
+          for (std::size_t i = 0; i < ids.size(); ++i)
+            {
+              vf << i;
+              for (int d = 0; d < dims_; ++d)
+                vf << ' ' << positions[i * dims_ + d];
+              vf << '\n';
+            }
+        }
+      if (mode_ == "vertex-trace")
+        build_vertex_frames();
     }
 
     bool requiresInitialData() { return false; }
@@ -173,9 +218,30 @@ namespace precice
     {
       if (values.size() != ids.size() * std::size_t(dims_))
         throw std::runtime_error("readData: values/ids size mismatch");
+      const double scale = (implicit_ && iteration_ + 1 < iterations_) ? 1.0 - std::pow(0.5, iteration_ + 1) : 1.0;
+      if (mode_ == "vertex-trace")
+        {
+          // per-vertex linear interpolation between the two recorded frames around the read time
+          const double t  = time_ + relativeReadTime;
+          std::size_t  hi = 0;
+          while (hi < frame_t_.size() && frame_t_[hi] < t)
+            ++hi;
+          const std::size_t a = hi == 0 ? 0 : hi - 1, b = hi < frame_t_.size() ? hi : frame_t_.size() - 1;
+          const double      w = (a == b || hi == 0) ? (hi == 0 ? 1.0 : 0.0) : (t - frame_t_[a]) / (frame_t_[b] - frame_t_[a]);
+          const std::size_t stride = n_vertices_ * std::size_t(dims_);
+          for (std::size_t i = 0; i < ids.size(); ++i)
+            {
+              const std::size_t vtx = std::size_t(ids[i]);
+              if (vtx >= n_vertices_)
+                throw std::runtime_error("readData: vertex id outside the coupling mesh");
+              for (int d = 0; d < dims_; ++d)
+                values[i * dims_ + d] = scale * ((1 - w) * frames_[a * stride + vtx * dims_ + d] +
+                                                 w * frames_[b * stride + vtx * dims_ + d]);
+            }
+          return;
+        }
       double f[3];
       traction_at(time_ + relativeReadTime, f);
-      const double scale = (implicit_ && iteration_ + 1 < iterations_) ? 1.0 - std::pow(0.5, iteration_ + 1) : 1.0;
       for (std::size_t i = 0; i < ids.size(); ++i)
         for (int d = 0; d < dims_; ++d)
           values[i * dims_ + d] = scale * f[d];
@@ -246,6 +312,39 @@ namespace precice
     {
       double t, f[3];
     };
+    struct VertexSample
+    {
+      double t;
+      long   vertex;
+      double f[3];
+    };
+    // rows of a vertex trace -> dense frames [time][vertex][dim]; every frame must list every vertex exactly once
+    void build_vertex_frames()
+    {
+      frame_t_.clear();
+      for (const VertexSample &p : vertex_rows_)
+        if (frame_t_.empty() || p.t > frame_t_.back() + 1e-14 * std::max(1.0, std::abs(p.t)))
+          frame_t_.push_back(p.t);
+        else if (p.t < frame_t_.back() - 1e-14 * std::max(1.0, std::abs(p.t)))
+          throw std::runtime_error("replay participant: vertex trace rows must be ordered by time");
+      const std::size_t stride = n_vertices_ * std::size_t(dims_);
+      frames_.assign(frame_t_.size() * stride, 0.0);
+      std::vector<int> seen(frame_t_.size() * n_vertices_, 0);
+      std::size_t      k = 0;
+      for (const VertexSample &p : vertex_rows_)
+        {
+          while (p.t > frame_t_[k] + 1e-14 * std::max(1.0, std::abs(p.t)))
+            ++k;
+          if (p.vertex < 0 || std::size_t(p.vertex) >= n_vertices_)
+            throw std::runtime_error("replay participant: vertex trace names a vertex outside the coupling mesh");
+          for (int d = 0; d < dims_; ++d)
+            frames_[k * stride + std::size_t(p.vertex) * dims_ + d] = p.f[d];
+          seen[k * n_vertices_ + std::size_t(p.vertex)]++;
+        }
+      for (int c : seen)
+        if (c != 1)
+          throw std::runtime_error("replay participant: every frame of a vertex trace must list every vertex exactly once");
+    }
     void traction_at(double t, double f[3]) const
     {
       f[0] = f[1] = f[2] = 0.0;
@@ -287,6 +386,9 @@ namespace precice
     std::size_t             n_vertices_ = 0;
     std::vector<double>     positions_, last_written_;
     std::vector<TracePoint> trace_;
+    std::vector<VertexSample> vertex_rows_;
+    std::vector<double>       frame_t_, frames_;
+    std::string               vertices_file_;
     std::ofstream           log_;
   };
 } // namespace precice

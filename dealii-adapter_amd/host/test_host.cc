@@ -282,6 +282,43 @@ int main()
     ad.advance(u, 0.01);
     CHECK(throws([&] { ad.reload_old_state_if_required(two, time); }, "not the same as previously saved"));
   }
+  // per-vertex trace replay: rows "t vertex fx fy", linear interpolation in time per vertex, constant outside the
+  // recorded range; the coupling-mesh vertices are written out for whoever records such a trace
+  {
+    write_file("t_vtrace.xml", R"(<precice-configuration dimensions="2">
+  <!-- replay: read-data = vertex-trace t_vtrace.txt -->
+  <!-- replay: write-vertices = t_vertices.txt -->
+  <coupling-scheme:serial-explicit><max-time-windows value="4" /><time-window-size value="0.01" /></coupling-scheme:serial-explicit>
+</precice-configuration>)");
+    write_file("t_vtrace.txt", "# t vertex fx fy\n0.01 0 1 10\n0.01 1 2 20\n0.01 2 3 30\n0.03 0 3 30\n0.03 1 4 40\n0.03 2 5 50\n");
+    precice::Participant pp("Solid", "t_vtrace.xml", 0, 1);
+    std::vector<double>  pos = {0.0, 0.0, 0.5, 0.0, 1.0, 0.25}, val(6);
+    std::vector<int>     ids(3);
+    pp.setMeshVertices("m", pos, ids);
+    pp.initialize();
+    pp.readData("m", "Stress", ids, 0.01, val); // t = 0.01: first frame
+    CHECK(val[0] == 1 && val[1] == 10 && val[4] == 3 && val[5] == 30);
+    pp.advance(0.01);
+    pp.readData("m", "Stress", ids, 0.01, val); // t = 0.02: half way
+    CHECK(std::abs(val[0] - 2.0) < 1e-13 && std::abs(val[3] - 30.0) < 1e-12 && std::abs(val[5] - 40.0) < 1e-12);
+    pp.advance(0.01);
+    pp.advance(0.01);
+    pp.readData("m", "Stress", ids, 0.01, val); // t = 0.04: beyond the last frame
+    CHECK(val[0] == 3 && val[5] == 50);
+    std::ifstream vf("t_vertices.txt");
+    std::string   line;
+    int           rows = 0;
+    while (std::getline(vf, line))
+      rows += (!line.empty() && line[0] != '#');
+    CHECK(rows == 3);
+    write_file("t_vtrace_bad.txt", "0.01 0 1 10\n0.01 1 2 20\n");
+    write_file("t_vtrace_bad.xml", R"(<precice-configuration dimensions="2">
+  <!-- replay: read-data = vertex-trace t_vtrace_bad.txt -->
+  <coupling-scheme:serial-explicit><max-time-windows value="1" /><time-window-size value="0.01" /></coupling-scheme:serial-explicit>
+</precice-configuration>)");
+    precice::Participant bad("Solid", "t_vtrace_bad.xml", 0, 1);
+    CHECK(throws([&] { bad.setMeshVertices("m", pos, ids); }, "every vertex exactly once"));
+  }
   std::printf(g_fail ? "HOST TESTS FAILED (%d)\n" : "HOST TESTS OK\n", g_fail);
   return g_fail ? 1 : 0;
 }

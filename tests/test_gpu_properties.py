@@ -209,3 +209,57 @@ def test_contexts_release_their_device_memory():
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 64 << 20, "leaked %.1f MB over 24 contexts" % ((free0 - free1) / 2 ** 20)
+
+
+def test_config2_linear_model_at_full_size():
+    """BASELINE configuration 2: linear_elasticity 3D Q1 cantilever, 40^3 cells = 206,763 DoFs (15,944,049 nnz), prescribed
+    constant traction.  Size-independent properties of the device path (the oracle's direct solver is out of reach
+    here): symmetry of K and M, rigid translations in the kernel of K, total mass, the solved theta-steps' true residual
+    against the exported stepping matrix, the displacement update, and energy balance of the theta = 1/2 scheme."""
+    import ctypes as C
+    import scipy.sparse as sp
+    n, dt, theta, rho = 40, 0.005, 0.5, 1000.0
+    roles = [O.FACE_CLAMPED] + [O.FACE_INTERFACE] * 5
+    G = M.Context(dim=3, degree=1, reps=(n, n, n), lo=(0, 0, 0), hi=(10.0, 1.0, 1.0), face_role=roles, rho=rho, delta_t=dt)
+    assert G.n == 206763 and G.nnz == 15944049  # SURVEY.md section 8 size table
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.mi_linear_matrix_get_csr.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                           C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, theta) == 0, L.mi_last_error(G.h)
+
+    def mat(which):
+        rp, col, val = np.zeros(G.n + 1, dtype=np.int64), np.zeros(G.nnz, dtype=np.int32), np.zeros(G.nnz)
+        assert L.mi_linear_matrix_get_csr(G.h, which, rp.ctypes.data_as(C.POINTER(C.c_int64)),
+                                          col.ctypes.data_as(C.POINTER(C.c_int32)), M._dp(val)) == 0
+        return sp.csr_matrix((val, col, rp), shape=(G.n, G.n))
+
+    K, Mm, S = mat(0), mat(1), mat(2)
+    for A in (K, Mm, S):
+        assert abs(A - A.T).max() / abs(A).max() < 1e-13
+    for c in range(3):  # a rigid translation carries no strain energy; the mass of every component is rho * volume
+        e = np.zeros(G.n)
+        e[c::3] = 1.0
+        assert np.abs(K @ e).max() / abs(K).max() < 1e-11
+        assert abs(e @ (Mm @ e) / (rho * 10.0) - 1.0) < 1e-12
+    con = G.constrained
+    assert np.array_equal(S.diagonal()[con], (Mm + (theta * dt) ** 2 * K).diagonal()[con])  # boundary values keep the diagonal
+    G.set_interface_traction((0.0, -200.0, 0.0))
+    d_old, v_old = np.zeros(G.n), np.zeros(G.n)
+    energy = [0.0]
+    for step in range(3):
+        its, res = C.c_int(0), C.c_double(0)
+        assert L.mi_linear_step(G.h, 1, 1e-10, G.n, C.byref(its), C.byref(res)) == 0, L.mi_last_error(G.h)
+        d, v, rhs, f = G.get(0), G.get(2), G.get(9), G.get(4)  # displacement, velocity, system_rhs, F_n+1 (old_stress)
+        assert its.value > 0 and res.value <= 1e-10
+        assert np.linalg.norm(S @ v - rhs) <= 2e-10 and np.all(v[con] == 0)       # the reference's absolute 1e-10 (:542)
+        assert np.abs(d - (d_old + dt * (theta * v + (1 - theta) * v_old))).max() <= 1e-15 * max(1.0, np.abs(d).max())
+        # theta = 1/2 conserves energy: E_n+1 - E_n = work of the mean load along the displacement increment
+        f_prev = f if step > 0 else np.zeros(G.n)  # F_0 = 0 (:243)
+        E = 0.5 * v @ (Mm @ v) + 0.5 * d @ (K @ d)
+        work = 0.5 * (f + f_prev) @ (d - d_old)
+        assert abs((E - energy[-1]) - work) <= 1e-6 * max(abs(work), 1e-30), (step, E - energy[-1], work)
+        energy.append(E)
+        d_old, v_old = d, v
+    assert energy[-1] > 0
