@@ -131,6 +131,8 @@ def lib():
         L.mi_comm_unique_id.argtypes = [C.c_void_p]
         L.mi_set_tuning.argtypes = [vp, C.c_char_p, C.c_int]
         L.mi_set_tuning.restype = C.c_int
+        L.mi_get_tuning.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+        L.mi_get_tuning.restype = C.c_int
         L.mi_bench_spmv.argtypes = [vp, C.c_int, dp]
         L.mi_bench_assemble.argtypes = [vp, C.c_int, dp]
         for f in ("mi_get_node_coords", "mi_get_constrained", "mi_get_interface_nodes", "mi_set_interface_traction",
@@ -364,6 +366,11 @@ class Context:
 
     def set_tuning(self, key, value):
         self._chk(lib().mi_set_tuning(self.h, key.encode(), int(value)))
+
+    def get_tuning(self, key):
+        v = C.c_int(0)
+        self._chk(lib().mi_get_tuning(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def reset_timings(self):
         self._chk(lib().mi_reset_timings(self.h))

@@ -142,6 +142,7 @@ namespace mi_detail
     for (int i = 0; i < 3; ++i)
       p.body[i] = c->mat.body_force[i];
     p.variant = c->asm_variant;
+    p.ke      = c->d_ke;
     return p;
   }
 
@@ -225,7 +226,19 @@ namespace mi_detail
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
                     int part, bool smoother, const ChebFusion *cheb)
   {
-    if (c->spmv_variant == 3 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
+    // product with the unassembled element tangents: the smoother's fine-level products (and, for tests, any plain
+    // product under "spmv_variant" 4); not for fused epilogues, fused dot products or the linear model's operators
+    if (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals && part == 0 &&
+        (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4))
+      {
+        hipMemsetAsync(y, 0, size_t(c->n) * sizeof(double), c->stream);
+        mi::EbeParams e{c->d_ke, c->d_conn, x, y};
+        for (int col = 0; col < c->mesh.ncolours; ++col)
+          mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]),
+                              c->stream);
+        return;
+      }
+    if (c->spmv_variant == 3 || c->spmv_variant == 4 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
       {
         refresh_sell(c);
         mi::SellParams p   = sell_params(c, x, y, dotv, partials, done);
@@ -433,6 +446,7 @@ namespace mi_detail
         HIPCHK(c, hipGetLastError());
         return MI_OK;
       }
+    c->ke_valid = c->d_ke && !(c->dim == 3 && c->degree == 2 && c->asm_variant != 0 && c->asm_variant != 1 && c->asm_variant != 2);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -443,6 +457,20 @@ namespace mi_detail
     c->sell_stale = true; // the SpMV-side copy is refreshed by the first product that needs it (enqueue_spmv)
     HIPCHK(c, hipGetLastError());
     c->mg_stale = true; // the coarse operators belong to an older state
+    return MI_OK;
+  }
+
+  // storage for the unassembled element tangents, where the smoother can use them (filled by the next full assembly)
+  int ensure_element_tangents(mi_ctx *c)
+  {
+    const bool want = c->ebe && c->team->size == 1 && c->dim == 3 && c->degree == 2 && c->precond == 1 && c->mg &&
+                      c->mesh.nnodes > 100000; // below that the smoother runs fused on the assembled matrix
+    if (want && !c->d_ke)
+      {
+        HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+        c->ke_valid = false;
+        c->mg_stale = c->mg_force = true;
+      }
     return MI_OK;
   }
 
@@ -699,7 +727,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1003,6 +1031,15 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
               return bail(rc, m->err);
           }
       }
+  }
+  // element tangents for the smoother (see ebe_spmv): 3D Q2 on an undecomposed mesh with the multigrid preconditioner
+  // (a slab would multiply its ghost layer twice, and small problems run the fused smoother on the assembled matrix)
+  if (const char *e = getenv("MI_EBE"))
+    c0->ebe = atoi(e) != 0;
+  {
+    const int rc = ensure_element_tangents(c0);
+    if (rc != MI_OK)
+      return bail(rc, c0->err);
   }
   // global interface scratch + coordinates of the global interface nodes (summed over the owners)
   {
@@ -1587,8 +1624,18 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
   const std::string k(key ? key : "");
   for (mi_ctx *m : c->team->members)
     {
-      if (k == "spmv_variant" && (value == 1 || value == 3 || (value >= 11 && value <= 14)))
+      if (k == "spmv_variant" && (value == 1 || value == 3 || value == 4 || (value >= 11 && value <= 14)))
         m->spmv_variant = value;
+      else if (k == "smoother_operator" && (value == 0 || value == 1))
+        m->ebe = value;
+      else if (k == "element_tangents" && value == 1) // tests: keep them whatever the size / preconditioner
+        {
+          if (m->team->size != 1 || m->dim != 3 || m->degree != 2)
+            return fail(c, MI_EINVAL, "element tangents exist for undecomposed 3D Q2 meshes only");
+          if (!m->d_ke)
+            HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+          m->ke_valid = false;
+        }
       else if (k == "xcd_remap" && (value == 0 || value == 1))
         m->xcd_remap = value;
       else if (k == "sell_unroll" && value >= -2 && value <= 8 && value != 0)
@@ -1626,10 +1673,33 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
               if (rc)
                 return fail(c, rc, "%s", m->err.c_str());
             }
+          if (value == 1)
+            {
+              const int rc = ensure_element_tangents(m);
+              if (rc)
+                return rc;
+            }
         }
       else
         return fail(c, MI_EINVAL, "unknown tuning key '%s' or value %d out of range", k.c_str(), value);
     }
+  return MI_OK;
+}
+
+int mi_get_tuning(mi_ctx *c, const char *key, int *value)
+{
+  const std::string k(key ? key : "");
+  mi_ctx           *m = c->team->members[0];
+  if (!value)
+    return fail(c, MI_EINVAL, "null argument");
+  if (k == "smoother_operator_active") // 1: the smoother's fine-level products run on the element tangents
+    *value = (m->d_ke && m->ebe && m->precond == 1 && m->precond_storage == 64) ? 1 : 0;
+  else if (k == "precond")
+    *value = m->precond;
+  else if (k == "spmv_variant")
+    *value = m->spmv_variant;
+  else
+    return fail(c, MI_EINVAL, "unknown tuning key '%s'", k.c_str());
   return MI_OK;
 }
 

@@ -94,6 +94,9 @@ struct mi_ctx
   double   *d_sell_vals = nullptr;
   double   *d_dinv_blk = nullptr; // inverse diagonal blocks (block-Jacobi smoother), allocated when it is switched on
   bool      want_dinv_blk = false;
+  double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
+  bool      ke_valid = false; // d_ke belongs to the current tangent
+  int       ebe = 1;          // tuning "smoother_operator": 1 element tangents where available, 0 assembled matrix
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
   int       precond_storage = 64;
   int       small_cg = 1; // matrices up to SMALL_CG_MAX_MATRIX_BYTES on one slab: whole Jacobi-PCG in one launch
@@ -167,6 +170,7 @@ namespace mi_detail
                      mi_ctx **out);
   void destroy_team(Team *T);
   int  enqueue_assembly(mi_ctx *c, bool residual_only = false);
+  int  ensure_element_tangents(mi_ctx *c);
   // multigrid (mi_mg.cpp)
   int  mg_setup(mi_ctx *c); // build the level hierarchy of a slab (once)
   void mg_destroy(mi_ctx *c);

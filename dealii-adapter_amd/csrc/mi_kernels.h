@@ -23,6 +23,17 @@ namespace mi
     int32_t         cell_count;
     int32_t         variant; // kernel variant for A/B timing
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
+    double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
+                            // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
+  };
+
+  // product with the unassembled element tangents (see ebe_spmv in mi_kernels.hip)
+  struct EbeParams
+  {
+    const double  *ke;
+    const int32_t *conn; // [ncells][27] colour-sorted
+    const double  *x;
+    double        *y;    // += (zeroed by the caller)
   };
 
   struct SpmvParams
@@ -122,6 +133,8 @@ namespace mi
                             int face_count, hipStream_t s);
   void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
+  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s);
+  constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s);
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,

@@ -587,6 +587,14 @@ namespace mi
                   vab[i * DIM + j] = v;
                   vba[j * DIM + i] = v;
                 }
+            if constexpr (DIM == 3 && P == 2)
+              if (prm.ke) // the cell's own (masked) block, before it is summed into the global matrix
+                {
+                  double *__restrict__ kq = prm.ke + cell * (int64_t(DD) * EBE_NBLK) + (a * (a + 1) / 2 + b);
+#pragma unroll
+                  for (int k = 0; k < DD; ++k)
+                    kq[k * EBE_NBLK] = vab[k];
+                }
             if (!first_ab)
 #pragma unroll
               for (int k = 0; k < DD; ++k)
@@ -1426,6 +1434,70 @@ namespace mi
         const double tot = block_sum<256>(dsum, s_red);
         if (threadIdx.x == 0)
           prm.partials[prm.part0 + b] = tot;
+      }
+  }
+
+  // ------------------------------------------------------------------ product with unassembled element tangents
+  // y += sum over the cells of one colour of P_e^T K_e P_e x, with K_e stored as its 378 lower-triangle node-pair
+  // blocks (3D Q2), layout [cell][e][block]: a wave reads 512 contiguous bytes per load, every stored number is read
+  // once and used for both K_ab x_b and K_ab^T x_a.  The symmetric half of the element tangents is 5.59 GB at 5 M dofs
+  // against the 7.62 GB of the assembled matrix, which is why the multigrid smoother (86 % of the fine-level products of
+  // a time step) multiplies with this form; the CG's own product stays on the assembled matrix.
+  // One workgroup per cell: thread = block (a >= b); the 6 partial results per block go through LDS and are summed per
+  // local dof in a fixed order (deterministic); cells of one colour share no node, so the update of y is race free.
+  // Constrained rows/columns were masked when the blocks were stored (exactly the values that entered the global matrix).
+  __global__ __launch_bounds__(384) void ebe_spmv(EbeParams prm, int64_t cell0)
+  {
+    constexpr int NPC = 27, NBLK = EBE_NBLK;
+    __shared__ double s_x[NPC * 3];
+    __shared__ double s_p[NBLK * 6 + 6];
+    __shared__ int    s_conn[NPC];
+    const int     tid  = threadIdx.x;
+    const int64_t cell = cell0 + blockIdx.x;
+    const double *__restrict__ kp = prm.ke + cell * (9 * int64_t(NBLK)) + tid;
+    const bool act = tid < NBLK;
+    double     k[9];
+    if (act)
+      {
+#pragma unroll
+        for (int e = 0; e < 9; ++e)
+          k[e] = __builtin_nontemporal_load(&kp[e * NBLK]); // streamed once
+      }
+    if (tid < NPC)
+      s_conn[tid] = prm.conn[cell * NPC + tid];
+    __syncthreads();
+    if (tid < NPC * 3)
+      s_x[tid] = prm.x[int64_t(s_conn[tid / 3]) * 3 + tid % 3];
+    __syncthreads();
+    if (act)
+      {
+        int a = int((sqrtf(8.0f * float(tid) + 1.0f) - 1.0f) * 0.5f); // block index -> (a, b), a >= b
+        while ((a + 1) * (a + 2) / 2 <= tid)
+          ++a;
+        while (a * (a + 1) / 2 > tid)
+          --a;
+        const int    b = tid - a * (a + 1) / 2;
+        const double xa0 = s_x[a * 3], xa1 = s_x[a * 3 + 1], xa2 = s_x[a * 3 + 2];
+        const double xb0 = s_x[b * 3], xb1 = s_x[b * 3 + 1], xb2 = s_x[b * 3 + 2];
+        double      *p = &s_p[tid * 6];
+        p[0]           = k[0] * xb0 + k[1] * xb1 + k[2] * xb2; // K_ab x_b
+        p[1]           = k[3] * xb0 + k[4] * xb1 + k[5] * xb2;
+        p[2]           = k[6] * xb0 + k[7] * xb1 + k[8] * xb2;
+        const double s = (a == b) ? 0.0 : 1.0;                 // the diagonal block counts once
+        p[3]           = s * (k[0] * xa0 + k[3] * xa1 + k[6] * xa2); // K_ab^T x_a
+        p[4]           = s * (k[1] * xa0 + k[4] * xa1 + k[7] * xa2);
+        p[5]           = s * (k[2] * xa0 + k[5] * xa1 + k[8] * xa2);
+      }
+    __syncthreads();
+    if (tid < NPC * 3)
+      {
+        const int a = tid / 3, i = tid - a * 3;
+        double    s = 0.0;
+        for (int b = 0; b <= a; ++b)
+          s += s_p[(a * (a + 1) / 2 + b) * 6 + i];
+        for (int c = a + 1; c < NPC; ++c)
+          s += s_p[(c * (c + 1) / 2 + a) * 6 + 3 + i];
+        prm.y[int64_t(s_conn[a]) * 3 + i] += s;
       }
   }
 
@@ -2519,6 +2591,11 @@ namespace mi
       dot ? sell_dispatch<3, true>(p, grid, s, unroll) : sell_dispatch<3, false>(p, grid, s, unroll);
     else
       dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
+  }
+  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s)
+  {
+    if (cell_count > 0)
+      hipLaunchKernelGGL(ebe_spmv, dim3(cell_count), dim3(384), 0, s, p, cell_begin);
   }
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s)

@@ -190,6 +190,55 @@ def test_element_kernel_variants_agree():
         assert abs(rn - ref[2]) / ref[2] < 1e-13
 
 
+def test_element_tangent_product_matches_the_assembled_matrix():
+    """the multigrid smoother's operator on big undecomposed 3D Q2 meshes: the masked element tangents stored by the
+    assembly (lower-triangle node-pair blocks) multiplied cell by cell give the same product as the assembled matrix,
+    including constrained rows/columns and their diagonal rule; deterministic; follows every new tangent"""
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+    P, G = _pair(3, 2, (4, 3, 5), perturb_amp=0.05, seed=21, roles=roles)
+    G.set_tuning("element_tangents", 1)
+    _randomise_state(P, G, seed=22)
+    P.update_acceleration()
+    P.assemble()
+    G.update_acceleration()
+    G.assemble()
+    rng = np.random.default_rng(23)
+    for _ in range(2):
+        x = rng.standard_normal(G.n)
+        y_ref = P.csr() @ x
+        G.set_tuning("spmv_variant", 3)
+        y_sell = G.spmv(x)
+        G.set_tuning("spmv_variant", 4)
+        y_ebe = G.spmv(x)
+        assert _relmax(y_sell, y_ref) < 1e-13 and _relmax(y_ebe, y_ref) < 1e-13
+        assert np.array_equal(G.spmv(x), y_ebe)  # fixed summation order
+        _randomise_state(P, G, seed=24)  # a new tangent: the element blocks follow
+        P.update_acceleration()
+        P.assemble()
+        G.update_acceleration()
+        G.assemble()
+
+
+def test_smoother_operator_choice_only_changes_the_preconditioner():
+    """multigrid-PCG with the smoother on the element tangents vs on the assembled matrix: the same operator up to
+    rounding, so the same iteration counts and the same converged solution"""
+    G = M.Context(dim=3, degree=2, reps=(24, 24, 24))  # 352,947 dofs, 117,649 nodes: above the 100k-node switch
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    assert G.get_tuning("smoother_operator_active") == 1
+    res = {}
+    for op in (1, 0):
+        G.set_tuning("smoother_operator", op)
+        G.set(M.V_NEWTON, np.zeros(G.n))
+        G.newton_begin_step()
+        G.update_acceleration()
+        G.assemble()
+        rc, its, r = G.cg_solve(rel_tol=1e-10)
+        assert rc == 0
+        res[op] = (its, G.get(M.V_NEWTON))
+    assert abs(res[0][0] - res[1][0]) <= 1 and 0 < res[1][0] < 40
+    assert _relmax(res[1][1], res[0][1]) < 1e-8
+
+
 def test_spmv_kernel_variants_agree():
     """sliced-ELL (production) and block-CSR (cross-check) kernels on the same matrix, several grids"""
     P, G = _pair(3, 2, (5, 4, 3), perturb_amp=0.05, seed=11)
