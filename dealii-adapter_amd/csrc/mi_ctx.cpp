@@ -228,9 +228,14 @@ namespace mi_detail
   {
     // product with the unassembled element tangents: the smoother's fine-level products (and, for tests, any plain
     // product under "spmv_variant" 4); not for fused epilogues, fused dot products or the linear model's operators
-    if (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals && part == 0 &&
+    if (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals &&
         (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4))
       {
+        // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
+        // by layer: the whole product waits for the ghost planes of x (part 2 = after the halo exchange); the rows of
+        // the ghost planes receive partial sums that nobody reads
+        if (part == 1)
+          return;
         hipMemsetAsync(y, 0, size_t(c->n) * sizeof(double), c->stream);
         mi::EbeParams e{c->d_ke, c->d_conn, x, y};
         for (int col = 0; col < c->mesh.ncolours; ++col)
@@ -463,7 +468,7 @@ namespace mi_detail
   // storage for the unassembled element tangents, where the smoother can use them (filled by the next full assembly)
   int ensure_element_tangents(mi_ctx *c)
   {
-    const bool want = c->ebe && c->team->size == 1 && c->dim == 3 && c->degree == 2 && c->precond == 1 && c->mg &&
+    const bool want = c->ebe && c->dim == 3 && c->degree == 2 && c->precond == 1 && c->mg &&
                       c->mesh.nnodes > 100000; // below that the smoother runs fused on the assembled matrix
     if (want && !c->d_ke)
       {
@@ -1034,13 +1039,14 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   }
   // element tangents for the smoother (see ebe_spmv): 3D Q2 on an undecomposed mesh with the multigrid preconditioner
   // (a slab would multiply its ghost layer twice, and small problems run the fused smoother on the assembled matrix)
-  if (const char *e = getenv("MI_EBE"))
-    c0->ebe = atoi(e) != 0;
-  {
-    const int rc = ensure_element_tangents(c0);
-    if (rc != MI_OK)
-      return bail(rc, c0->err);
-  }
+  for (mi_ctx *m : T->members)
+    {
+      if (const char *e = getenv("MI_EBE"))
+        m->ebe = atoi(e) != 0;
+      const int rc = ensure_element_tangents(m);
+      if (rc != MI_OK)
+        return bail(rc, m->err);
+    }
   // global interface scratch + coordinates of the global interface nodes (summed over the owners)
   {
     const size_t nifg = std::max<size_t>(1, T->iface_global.size() * size_t(md->dim));
@@ -1630,8 +1636,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->ebe = value;
       else if (k == "element_tangents" && value == 1) // tests: keep them whatever the size / preconditioner
         {
-          if (m->team->size != 1 || m->dim != 3 || m->degree != 2)
-            return fail(c, MI_EINVAL, "element tangents exist for undecomposed 3D Q2 meshes only");
+          if (m->dim != 3 || m->degree != 2)
+            return fail(c, MI_EINVAL, "element tangents exist for 3D Q2 meshes only");
           if (!m->d_ke)
             HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
           m->ke_valid = false;
@@ -1658,6 +1664,12 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->asm_variant = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
         m->mg_lag = value;
+      else if (k == "mg_fuse" && value >= 0 && value <= 2)
+        {
+          const int rc = mg_set_fuse(m, value);
+          if (rc)
+            return fail(c, rc, "mg_fuse needs the multigrid preconditioner");
+        }
       else if (k == "precond_storage" && (value == 64 || value == 32))
         {
           const int rc = set_precond_storage(m, value);

@@ -189,6 +189,7 @@ namespace mi_detail
                 const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother = false,
                 const ChebFusion *cheb = nullptr); // cheb: one entry per member
   int mg_set_storage(mi_ctx *c, int bits); // mi_mg.cpp: forwards to the level contexts
+  int mg_set_fuse(mi_ctx *c, int fuse);
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);
 
 #define HIPCHK(ctx, call)                                                                                   \

@@ -321,6 +321,15 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // 0 never fuse the smoother update into the product, 1 on the latency-bound levels (default), 2 on every level
+  int mg_set_fuse(mi_ctx *c, int fuse)
+  {
+    if (!c->mg)
+      return MI_EINVAL;
+    c->mg->fuse = fuse;
+    return MI_OK;
+  }
+
   void mg_destroy(mi_ctx *c)
   {
     if (!c->mg)

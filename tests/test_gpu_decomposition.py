@@ -247,3 +247,46 @@ def test_global_array_views_roundtrip(dim, p, reps, slabs):
     G.state_restore()
     for k in range(6):
         assert np.array_equal(G.get(k), before[k])
+
+
+def test_element_tangent_product_on_slabs():
+    """the smoother's operator on a decomposed mesh: every slab multiplies with the element tangents of ALL its local
+    cells (own layers + ghost layer) after the halo exchange; the owned rows are complete and equal the assembled
+    product"""
+    P, G = _setup(3, 2, (3, 3, 7), 3, seed=5)
+    G.set_tuning("element_tangents", 1)
+    _randomise(P, G, seed=6)
+    P.update_acceleration()
+    P.assemble()
+    G.update_acceleration()
+    G.assemble()
+    x = np.random.default_rng(7).standard_normal(P.n)
+    y_ref = P.csr() @ x
+    G.set_tuning("spmv_variant", 4)
+    y = G.spmv(x)
+    assert _relmax(y, y_ref) < 1e-13 and np.array_equal(G.spmv(x), y)
+    G.set_tuning("spmv_variant", 3)
+    assert _relmax(G.spmv(x), y_ref) < 1e-13
+
+
+@pytest.mark.parametrize("slabs", [1, 2, 3])
+def test_multigrid_smoother_on_element_tangents_is_slab_invariant(slabs):
+    """multigrid-PCG with the smoother forced onto the element tangents (unfused smoother, as on big meshes) on 1, 2
+    and 3 slabs: same iteration count (+-1) and the same solution as with the assembled smoother operator"""
+    res = {}
+    for op in (0, 1):
+        P, G = _setup(3, 2, (5, 4, 9), slabs, seed=3, perturb_amp=0.0)
+        G.set_tuning("precond", 1)
+        G.set_tuning("mg_fuse", 0)
+        if op:
+            G.set_tuning("element_tangents", 1)
+        G.set_tuning("smoother_operator", op)
+        _randomise(P, G, seed=4)
+        G.update_acceleration()
+        G.assemble()
+        rc, its, r = G.cg_solve(rel_tol=1e-10)
+        assert rc == 0
+        res[op] = (its, G.get(M.V_NEWTON))
+        assert G.get_tuning("smoother_operator_active") == op
+    assert abs(res[0][0] - res[1][0]) <= 1 and 0 < res[1][0] < 60
+    assert _relmax(res[1][1], res[0][1]) < 1e-8
