@@ -152,7 +152,7 @@ struct mi_ctx
 namespace mi_detail
 {
   int  fail(mi_ctx *c, int code, const char *fmt, ...);
-  int  tic(mi_ctx *c, int cls);
+  int  tic(mi_ctx *c, int cls, bool ext = false);
   void toc(mi_ctx *c, int id);
   int  sync(mi_ctx *c);
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,

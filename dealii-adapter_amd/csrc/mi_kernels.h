@@ -133,6 +133,7 @@ namespace mi
                             int face_count, hipStream_t s);
   void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
+  void set_next_sell_launch_events(hipEvent_t start, hipEvent_t stop); // profiling: bracket exactly the next launch
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,

@@ -9,6 +9,7 @@
 //   cg_* / vec_*     : fused CG vector updates with deterministic two-level reductions (:1153-1191)
 //   newmark_*        : Newmark predictor/corrector vector updates (:592-622)
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <type_traits>
@@ -2519,13 +2520,35 @@ namespace mi
   // unroll: 1..4 blocks in flight per lane; 5..7 = 2..4 with non-temporal matrix loads (5 is the default),
   // 8 = 2 with non-temporal values only; -1, -2 timing-only ablations
   // default load pipeline with generated column indices (SellParams::rowbox set)
+  // profiling: events that bracket exactly the NEXT production sliced-ELL launch (kernel start / kernel end from the
+  // dispatch itself, as a profiler sees it); plain events recorded around a launch also pick up the tails of its
+  // neighbours in the stream
+  static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+  void set_next_sell_launch_events(hipEvent_t start, hipEvent_t stop)
+  {
+    g_ev_start = start;
+    g_ev_stop  = stop;
+  }
+
   template <int D, bool DOT, bool F32, bool CHEB>
   static void sell_launch_icol(const SellParams &p, int grid, hipStream_t s)
   {
+    const hipEvent_t a = g_ev_start, b = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
     if constexpr (D == 3)
-      hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
+      {
+        if (a && b)
+          hipExtLaunchKernelGGL((sell_spmv<3, 2, 0, 1, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, a, b, 0, p);
+        else
+          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
+      }
     else
-      hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
+      {
+        if (a && b)
+          hipExtLaunchKernelGGL((sell_spmv<2, 4, 0, 0, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, a, b, 0, p);
+        else
+          hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
+      }
   }
   template <int D>
   static void sell_dispatch_icol(const SellParams &p, int grid, hipStream_t s)
