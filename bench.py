@@ -290,6 +290,8 @@ def main():
                       rho=1000.0, beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
                       world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
         G.set_tuning("smoother_operator", 1 if args.smoother_operator == "element" else 0)
+        if os.environ.get("MI_CG_FUSED_DOT"):
+            G.set_tuning("cg_fused_dot", int(os.environ["MI_CG_FUSED_DOT"]))
         G.set_tuning("precond", 1 if args.precond == "mg" else 0)
         if args.precond_storage == "f32":
             G.set_tuning("precond_storage", 32)

@@ -525,7 +525,7 @@ namespace mi_detail
         cg.flags    = m->d_flags;
         cg.n        = m->own_n;
         cg.npart    = m->grid_vec;
-        cg.npart_pq = m->grid_spmv;
+        cg.npart_pq = m->cg_fused_dot ? m->grid_spmv : m->grid_vec;
         cg.totals   = dist ? m->d_sc + SC_TOT : nullptr;
         cgs.push_back(cg);
       }
@@ -649,10 +649,14 @@ namespace mi_detail
             t = tic(c0, MI_T_SPMV, one_launch);
             if (one_launch && t >= 0)
               mi::set_next_sell_launch_events(c0->stamps[size_t(t)].a, c0->stamps[size_t(t)].b);
-            if ((rc = team_spmv(T, self, p_of, q_of, fusion.data())))
+            if ((rc = team_spmv(T, self, p_of, q_of, c0->cg_fused_dot ? fusion.data() : nullptr)))
               return rc;
             if (!one_launch)
               toc(c0, t);
+            if (!c0->cg_fused_dot) // A/B: p.q by a separate reduction over the owned dofs
+              for (size_t k = 0; k < R; ++k)
+                mi::launch_dot_partials(cgs[k].p, cgs[k].q, T.members[k]->own_n, cgs[k].part_pq, T.members[k]->grid_vec,
+                                        T.members[k]->stream);
             if (dist)
               {
                 for (size_t k = 0; k < R; ++k)
@@ -1673,6 +1677,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->asm_variant = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
         m->mg_lag = value;
+      else if (k == "cg_fused_dot" && (value == 0 || value == 1))
+        m->cg_fused_dot = value;
       else if (k == "mg_fuse" && value >= 0 && value <= 2)
         {
           const int rc = mg_set_fuse(m, value);
