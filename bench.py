@@ -426,14 +426,17 @@ def main():
             G.set_tuning("spmv_variant", 3)
             out["roofline"]["calibration_stream_read"] = {"ms": ms_cal, "GB": 8 * G.nnz / 1e9,
                                                           "GB_per_s": 8 * G.nnz / ms_cal / 1e6}
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_spmv_n59.json")
-        if not os.path.exists(pmc_file):
-            pmc_file = os.path.join(ROOT, "profiles", "r01", "pmc_spmv_icol_n59.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_bench_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
-            out["roofline"]["traffic_from_committed_profile"] = {
-                "GB_per_launch": json.load(open(pmc_file))["traffic_bytes_per_launch"] / 1e9,
-                "source": os.path.relpath(pmc_file, ROOT),
-                "how": "rocprofv3 --pmc, one counter per pass: TCC_EA0_RDREQ x 128 B + WRITE_SIZE x 1 KiB (tools/pmc_spmv.sh)"}
+            # per-launch HBM traffic of this very command under `rocprofv3 --pmc` (tools/pmc_bench.sh), as committed
+            pmc = json.load(open(pmc_file))
+            dot = [v for k, v in pmc.items() if k.startswith("mi::sell_spmv<3, 2, 0, 1, true")]
+            if dot:
+                out["roofline"]["traffic_from_committed_profile"] = {
+                    "GB_per_launch": dot[0]["traffic_GB_per_launch"], "source": os.path.relpath(pmc_file, ROOT),
+                    "ratio_to_algorithmic": dot[0]["traffic_GB_per_launch"] / (bytes_bsr / 1e9),
+                    "how": "rocprofv3 --pmc over `python3 bench.py --steps 1 --warmup 0 --cpu-cells 0`, one counter per pass: "
+                           "TCC_EA0_RDREQ x 128 B - TCC_EA0_RDREQ_32B x 96 B + WRITE_SIZE x 1 KiB (tools/pmc_bench.sh)"}
     del G, R
     # ---- second field for N > 1: weak scaling (one cells^3 block per GPU)
     if world > 1 and not replicas and not args.no_weak and args.scaling == "strong":
