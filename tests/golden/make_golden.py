@@ -46,7 +46,10 @@ def nonlinear_cases():
     return [("fsi3p1", O.scenario_desc("FSI3", 2, degree=1)), ("fsi3p2", O.scenario_desc("FSI3", 2, degree=2)),
             ("fsi3p3", O.scenario_desc("FSI3", 2, degree=3)),
             ("blk3d", O.make_desc(dim=3, degree=2, reps=(2, 2, 2), hi=(0.2, 0.2, 0.2), face_role=[1, 7, 7, 7, 8, 7],
-                                  body_force=(1.0, -9.81, 0.5)))]
+                                  body_force=(1.0, -9.81, 0.5))),
+            ("pf2dp2", O.scenario_desc("PF", 2, degree=2)),
+            ("blk3dq3", O.make_desc(dim=3, degree=3, reps=(1, 1, 2), hi=(0.1, 0.1, 0.2), face_role=[1, 7, 7, 7, 8, 7],
+                                    body_force=(0.0, -9.81, 0.0)))]
 
 
 def linear_cases():
@@ -146,7 +149,8 @@ def main():
         # Newmark trace from rest under per-node tractions
         P = O.Problem(desc)
         S = Mi.Solid(m, desc.mu, desc.nu, desc.rho, tuple(desc.body_force)[:dim], desc.beta, desc.gamma, desc.delta_t)
-        base = np.array([5.0, -40.0, 3.0])[:dim] if name.startswith("fsi3") else np.array([100.0, -2e3, 50.0])
+        base = (np.array([5.0, -40.0, 3.0])[:dim] if name.startswith("fsi3") else
+                np.array([30.0, -4.0])[:dim] if name.startswith("pf") else np.array([100.0, -2e3, 50.0]))
         tr, du, logs = [], [], []
         for k in range(3):
             t = base * min(1.0, (k + 1) / 2.0) + 0.1 * np.abs(base[1]) * rng.standard_normal((len(m.interface_nodes), dim))
