@@ -25,9 +25,10 @@
 
 constexpr int NPC = 27, NBLK = NPC * (NPC + 1) / 2, NT = 384, ESTRIDE = NBLK; // 378 blocks
 
-template <bool NTL>
+template <bool NTL, int MODE = 0>
 __global__ __launch_bounds__(NT) void ebe_product(const double *__restrict__ ke, const int *__restrict__ conn,
-                                                  const double *__restrict__ x, double *y, long cell0)
+                                                  const double *__restrict__ x, double *y, long cell0,
+                                                  const int *__restrict__ lex = nullptr, double *ye = nullptr)
 {
   __shared__ double s_x[NPC * 3];
   __shared__ double s_p[NBLK * 6 + 6];
@@ -78,7 +79,14 @@ __global__ __launch_bounds__(NT) void ebe_product(const double *__restrict__ ke,
         s += s_p[(a * (a + 1) / 2 + b) * 6 + i];
       for (int c = a + 1; c < NPC; ++c)
         s += s_p[(c * (c + 1) / 2 + a) * 6 + 3 + i];
-      y[long(s_conn[a]) * 3 + i] += s;
+      if (MODE == 0)
+        y[long(s_conn[a]) * 3 + i] += s;
+      else if (MODE == 1)
+        ye[long(lex[cell]) * 81 + tid] = s;
+      else if (MODE == 2)
+        ye[cell * 81 + tid] = s;
+      else
+        __builtin_nontemporal_store(s, &ye[long(lex[cell]) * 81 + tid]);
     }
 }
 
@@ -164,6 +172,74 @@ int main(int argc, char **argv)
   hipEvent_t e0, e1;
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
+  // per-cell result variants
+  {
+    std::vector<int> lexv(ncells);
+    long p2 = 0;
+    for (int col = 0; col < 8; ++col)
+      for (long c = 0; c < ncells; ++c)
+        {
+          const int ci[3] = {int(c % n), int((c / n) % n), int(c / (long(n) * n))};
+          if (((ci[0] & 1) | ((ci[1] & 1) << 1) | ((ci[2] & 1) << 2)) == col)
+            lexv[p2++] = int(c);
+        }
+    int *d_lex;
+    double *d_ye;
+    CHK(hipMalloc(&d_lex, ncells * 4));
+    CHK(hipMalloc(&d_ye, ncells * 81 * 8));
+    CHK(hipMemcpy(d_lex, lexv.data(), ncells * 4, hipMemcpyHostToDevice));
+    for (int variant = 0; variant < 6; ++variant)
+      {
+        float sum = 0;
+        for (int r = 0; r < reps + 1; ++r)
+          {
+            CHK(hipEventRecord(e0, 0));
+            const bool one = variant % 2 == 0;
+            const int  mode = variant / 2 + 1;
+            for (int col = 0; col < (one ? 1 : 8); ++col)
+              {
+                const long c0 = one ? 0 : cbegin[col], cn = one ? ncells : cbegin[col + 1] - cbegin[col];
+                if (mode == 1)
+                  hipLaunchKernelGGL((ebe_product<true, 1>), dim3(cn), dim3(NT), 0, 0, d_ke, d_conn, d_x, d_y, c0, d_lex, d_ye);
+                else if (mode == 2)
+                  hipLaunchKernelGGL((ebe_product<true, 2>), dim3(cn), dim3(NT), 0, 0, d_ke, d_conn, d_x, d_y, c0, d_lex, d_ye);
+                else
+                  hipLaunchKernelGGL((ebe_product<true, 3>), dim3(cn), dim3(NT), 0, 0, d_ke, d_conn, d_x, d_y, c0, d_lex, d_ye);
+              }
+            CHK(hipEventRecord(e1, 0));
+            CHK(hipEventSynchronize(e1));
+            float ms;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0)
+              sum += ms;
+          }
+        printf("per-cell results, %s, %s: avg %.3f ms\n", variant / 2 == 0 ? "lexicographic slot" : variant / 2 == 1 ? "own slot" : "lexicographic slot, nt store",
+               variant % 2 == 0 ? "ONE launch" : "8 launches", sum / reps);
+      }
+  }
+  for (int split = 1; split <= 8; split *= 2)
+    {
+      float sum = 0;
+      for (int r = 0; r < reps + 1; ++r)
+        {
+          CHK(hipMemsetAsync(d_y, 0, nnodes * 3 * 8, 0));
+          CHK(hipEventRecord(e0, 0));
+          for (int col = 0; col < 8; ++col)
+            {
+              const long cn = cbegin[col + 1] - cbegin[col], per = (cn + split - 1) / split;
+              for (long c0 = 0; c0 < cn; c0 += per)
+                hipLaunchKernelGGL(ebe_product<true>, dim3(std::min(per, cn - c0)), dim3(NT), 0, 0, d_ke, d_conn, d_x, d_y,
+                                   cbegin[col] + c0);
+            }
+          CHK(hipEventRecord(e1, 0));
+          CHK(hipEventSynchronize(e1));
+          float ms;
+          CHK(hipEventElapsedTime(&ms, e0, e1));
+          if (r > 0)
+            sum += ms;
+        }
+      printf("RMW y, every colour in %d launches (%d per product): avg %.3f ms\n", split, 8 * split, sum / reps);
+    }
   for (int variant = 0; variant < 2; ++variant)
     {
       float best = 1e30f, sum = 0;
