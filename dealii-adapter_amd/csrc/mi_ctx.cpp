@@ -223,53 +223,26 @@ namespace mi_detail
     c->sell_stale = false;
   }
 
-  // whether products of this context run on the unassembled element tangents (smoother: the multigrid's fine-level
-  // products; otherwise: plain products under the test switch "spmv_variant" 4)
-  bool ebe_active(const mi_ctx *c, bool smoother)
-  {
-    return c->d_ke && c->ke_valid && !c->active_sell_vals &&
-           (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4);
-  }
-
   // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
   // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
                     int part, bool smoother, const ChebFusion *cheb)
   {
     // product with the unassembled element tangents: the smoother's fine-level products (and, for tests, any plain
-    // product under "spmv_variant" 4), with the same three epilogues as the fused sliced-ELL product; not for fused
-    // dot products or the linear model's operators
-    if (ebe_active(c, smoother) && !dotv)
+    // product under "spmv_variant" 4); not for fused epilogues, fused dot products or the linear model's operators
+    if (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals &&
+        (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4))
       {
         // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
-        // by layer: the whole product waits for the ghost planes of x (part 2 = after the halo exchange)
+        // by layer: the whole product waits for the ghost planes of x (part 2 = after the halo exchange); the rows of
+        // the ghost planes receive partial sums that nobody reads
         if (part == 1)
           return;
-        mi::EbeParams e{c->d_ke, c->d_conn, c->d_cell_lex, x, c->d_ye};
-        mi::launch_ebe_partial(e, c->mesh.ncells, c->stream);
-        mi::EbeGatherParams g{};
-        g.ye    = c->d_ye;
-        g.nn0   = c->mesh.nn[0];
-        g.nn1   = c->mesh.nn[1];
-        g.nn2   = c->mesh.nn[2];
-        g.r0    = c->mesh.reps[0];
-        g.r1    = c->mesh.reps[1];
-        g.r2    = c->mesh.reps[2];
-        g.node0 = c->slab.own_begin;
-        g.node1 = c->slab.own_end;
-        g.y     = y;
-        g.x     = x;
-        if (cheb)
-          {
-            g.b    = cheb->b;
-            g.dinv = cheb->dinv;
-            g.d    = cheb->d;
-            g.xout = cheb->xout;
-            g.c1   = cheb->c1;
-            g.c2   = cheb->c2;
-            g.blk  = cheb->blk;
-          }
-        mi::launch_ebe_gather(g, c->stream);
+        hipMemsetAsync(y, 0, size_t(c->n) * sizeof(double), c->stream);
+        mi::EbeParams e{c->d_ke, c->d_conn, x, y};
+        for (int col = 0; col < c->mesh.ncolours; ++col)
+          mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]),
+                              c->stream);
         return;
       }
     if (c->spmv_variant == 3 || c->spmv_variant == 4 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
@@ -501,23 +474,11 @@ namespace mi_detail
                       c->mesh.nnodes > 100000; // below that the smoother runs fused on the assembled matrix
     if (want && !c->d_ke)
       {
-        const int rc = alloc_element_tangents(c);
-        if (rc)
-          return rc;
+        HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+        c->ke_valid = false;
         c->mg_stale = c->mg_force = true;
       }
     return MI_OK;
-  }
-
-  int alloc_element_tangents(mi_ctx *c)
-  {
-    if (c->d_ke)
-      return MI_OK;
-    HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&c->d_ye, size_t(c->mesh.ncells) * 81 * sizeof(double)));
-    const int rc = upload(c, &c->d_cell_lex, c->mesh.cell_orig);
-    c->ke_valid  = false;
-    return rc;
   }
 
   // l2 norm over the unconstrained owned dofs of vector `which`, summed over the team (:549-576)
@@ -784,7 +745,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_ye, c->d_cell_lex};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1690,9 +1651,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         {
           if (m->dim != 3 || m->degree != 2)
             return fail(c, MI_EINVAL, "element tangents exist for 3D Q2 meshes only");
-          const int rc = alloc_element_tangents(m);
-          if (rc)
-            return rc;
+          if (!m->d_ke)
+            HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
           m->ke_valid = false;
         }
       else if (k == "xcd_remap" && (value == 0 || value == 1))

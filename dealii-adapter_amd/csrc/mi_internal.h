@@ -94,9 +94,7 @@ struct mi_ctx
   double   *d_sell_vals = nullptr;
   double   *d_dinv_blk = nullptr; // inverse diagonal blocks (block-Jacobi smoother), allocated when it is switched on
   bool      want_dinv_blk = false;
-  double   *d_ke = nullptr;   // unassembled element tangents (3D Q2): the multigrid smoother's operator
-  double   *d_ye = nullptr;   // per-cell results of a product with them [ncells (lexicographic)][81]
-  int32_t  *d_cell_lex = nullptr; // colour-sorted cell position -> lexicographic cell id
+  double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
   bool      ke_valid = false; // d_ke belongs to the current tangent
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
   int       ebe = 1;          // tuning "smoother_operator": 1 element tangents where available, 0 assembled matrix
@@ -174,8 +172,6 @@ namespace mi_detail
   void destroy_team(Team *T);
   int  enqueue_assembly(mi_ctx *c, bool residual_only = false);
   int  ensure_element_tangents(mi_ctx *c);
-  int  alloc_element_tangents(mi_ctx *c);
-  bool ebe_active(const mi_ctx *c, bool smoother);
   // multigrid (mi_mg.cpp)
   int  mg_setup(mi_ctx *c); // build the level hierarchy of a slab (once)
   void mg_destroy(mi_ctx *c);

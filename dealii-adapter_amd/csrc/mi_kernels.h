@@ -27,29 +27,13 @@ namespace mi
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
   };
 
-  // product with the unassembled element tangents (see ebe_partial / ebe_gather in mi_kernels.hip)
+  // product with the unassembled element tangents (see ebe_spmv in mi_kernels.hip)
   struct EbeParams
   {
     const double  *ke;
-    const int32_t *conn;     // [ncells][27] colour-sorted
-    const int32_t *cell_lex; // [ncells] colour-sorted position -> lexicographic cell id
+    const int32_t *conn; // [ncells][27] colour-sorted
     const double  *x;
-    double        *ye;       // [ncells (lexicographic)][81] per-cell results
-  };
-  // second half of the product: every node sums the results of the (up to 8) cells it belongs to, in a fixed order,
-  // and finishes in one of three ways (the same three the fused sliced-ELL epilogue offers):
-  //   y = K x;   y = b - K x (b set, d null);   d = c1 d + c2 D^-1 (b - K x), xout = x + d (b and d set)
-  struct EbeGatherParams
-  {
-    const double *ye;
-    int32_t       nn0, nn1, nn2;    // lattice points per direction
-    int32_t       r0, r1, r2;       // cells per direction
-    int64_t       node0, node1;     // nodes [node0, node1): the owned rows
-    double       *y;
-    const double *x, *b, *dinv;
-    double       *d, *xout;
-    double        c1, c2;
-    int32_t       blk;              // dinv holds 3x3 inverse diagonal blocks per node
+    double        *y;    // += (zeroed by the caller)
   };
 
   struct SpmvParams
@@ -150,8 +134,7 @@ namespace mi
   void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
   void set_next_sell_launch_events(hipEvent_t start, hipEvent_t stop); // profiling: bracket exactly the next launch
-  void launch_ebe_partial(const EbeParams &p, int64_t ncells, hipStream_t s);
-  void launch_ebe_gather(const EbeGatherParams &g, hipStream_t s);
+  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s);

@@ -1439,26 +1439,22 @@ namespace mi
   }
 
   // ------------------------------------------------------------------ product with unassembled element tangents
-  // y = sum over the cells of P_e^T K_e P_e x, with K_e stored as its 378 lower-triangle node-pair blocks (3D Q2),
-  // layout [cell][e][block]: a wave reads 512 contiguous bytes per load, every stored number is read once and used for
-  // both K_ab x_b and K_ab^T x_a.  The symmetric half of the element tangents is 5.59 GB at 5 M dofs against the
-  // 7.62 GB of the assembled matrix, which is why the multigrid smoother (86 % of the fine-level products of a time
-  // step) multiplies with this form; the CG's own product stays on the assembled matrix.
-  // Two launches per product, no colours, no atomics, fixed summation order (bitwise repeatable):
-  //   ebe_partial: one workgroup per cell, thread = block (a >= b); the 6 partial results per block go through LDS, 81
-  //                threads sum the 27 contributions of their local dof and store the cell's 81 results (648 contiguous
-  //                bytes, at the cell's LEXICOGRAPHIC position so that neighbouring cells are neighbours in memory)
-  //   ebe_gather : one thread per owned node sums the results of the up to 8 cells it belongs to (found from the lattice
-  //                indices, z-y-x order) and applies the epilogue: plain, residual or the Chebyshev update of the smoother
+  // y += sum over the cells of one colour of P_e^T K_e P_e x, with K_e stored as its 378 lower-triangle node-pair
+  // blocks (3D Q2), layout [cell][e][block]: a wave reads 512 contiguous bytes per load, every stored number is read
+  // once and used for both K_ab x_b and K_ab^T x_a.  The symmetric half of the element tangents is 5.59 GB at 5 M dofs
+  // against the 7.62 GB of the assembled matrix, which is why the multigrid smoother (86 % of the fine-level products of
+  // a time step) multiplies with this form; the CG's own product stays on the assembled matrix.
+  // One workgroup per cell: thread = block (a >= b); the 6 partial results per block go through LDS and are summed per
+  // local dof in a fixed order (deterministic); cells of one colour share no node, so the update of y is race free.
   // Constrained rows/columns were masked when the blocks were stored (exactly the values that entered the global matrix).
-  __global__ __launch_bounds__(384) void ebe_partial(EbeParams prm)
+  __global__ __launch_bounds__(384) void ebe_spmv(EbeParams prm, int64_t cell0)
   {
     constexpr int NPC = 27, NBLK = EBE_NBLK;
     __shared__ double s_x[NPC * 3];
     __shared__ double s_p[NBLK * 6 + 6];
     __shared__ int    s_conn[NPC];
     const int     tid  = threadIdx.x;
-    const int64_t cell = blockIdx.x;
+    const int64_t cell = cell0 + blockIdx.x;
     const double *__restrict__ kp = prm.ke + cell * (9 * int64_t(NBLK)) + tid;
     const bool act = tid < NBLK;
     double     k[9];
@@ -1502,81 +1498,7 @@ namespace mi
           s += s_p[(a * (a + 1) / 2 + b) * 6 + i];
         for (int c = a + 1; c < NPC; ++c)
           s += s_p[(c * (c + 1) / 2 + a) * 6 + 3 + i];
-        prm.ye[int64_t(prm.cell_lex[cell]) * (NPC * 3) + tid] = s;
-      }
-  }
-
-  __global__ __launch_bounds__(256) void ebe_gather(EbeGatherParams g)
-  {
-    const int64_t node = g.node0 + int64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (node >= g.node1)
-      return;
-    const int i = int(node % g.nn0), j = int((node / g.nn0) % g.nn1), k = int(node / (int64_t(g.nn0) * g.nn1));
-    // cells and local node index along one direction: an odd lattice index is the mid node of one cell, an even one the
-    // last node of the cell before and the first of the cell after
-    int cx[2], lx[2], cy[2], ly[2], cz[2], lz[2], nx = 0, ny = 0, nz = 0;
-    auto split = [](int idx, int ncell, int *c, int *l, int &n) {
-      if (idx & 1)
-        {
-          c[0] = idx >> 1;
-          l[0] = 1;
-          n    = 1;
-          return;
-        }
-      if (idx > 0)
-        {
-          c[n] = (idx >> 1) - 1;
-          l[n] = 2;
-          ++n;
-        }
-      if ((idx >> 1) < ncell)
-        {
-          c[n] = idx >> 1;
-          l[n] = 0;
-          ++n;
-        }
-    };
-    split(i, g.r0, cx, lx, nx);
-    split(j, g.r1, cy, ly, ny);
-    split(k, g.r2, cz, lz, nz);
-    double s[3] = {0.0, 0.0, 0.0};
-    for (int c = 0; c < nz; ++c)
-      for (int bq = 0; bq < ny; ++bq)
-        for (int a = 0; a < nx; ++a)
-          {
-            const int64_t cell = cx[a] + int64_t(g.r0) * (cy[bq] + int64_t(g.r1) * cz[c]);
-            const double *__restrict__ p = g.ye + cell * 81 + (lx[a] + 3 * (ly[bq] + 3 * lz[c])) * 3;
-            s[0] += p[0];
-            s[1] += p[1];
-            s[2] += p[2];
-          }
-    const int64_t o = node * 3;
-    if (!g.b)
-      {
-        g.y[o]     = s[0];
-        g.y[o + 1] = s[1];
-        g.y[o + 2] = s[2];
-        return;
-      }
-    const double res[3] = {g.b[o] - s[0], g.b[o + 1] - s[1], g.b[o + 2] - s[2]};
-    if (!g.d)
-      {
-        g.y[o]     = res[0];
-        g.y[o + 1] = res[1];
-        g.y[o + 2] = res[2];
-        return;
-      }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-      {
-        double t;
-        if (g.blk)
-          t = g.dinv[node * 9 + c * 3] * res[0] + g.dinv[node * 9 + c * 3 + 1] * res[1] + g.dinv[node * 9 + c * 3 + 2] * res[2];
-        else
-          t = g.dinv[o + c] * res[c];
-        const double dn = (g.c1 != 0.0 ? g.c1 * g.d[o + c] : 0.0) + g.c2 * t;
-        g.d[o + c]      = dn;
-        g.xout[o + c]   = g.x[o + c] + dn;
+        prm.y[int64_t(s_conn[a]) * 3 + i] += s;
       }
   }
 
@@ -2693,16 +2615,10 @@ namespace mi
     else
       dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
   }
-  void launch_ebe_partial(const EbeParams &p, int64_t ncells, hipStream_t s)
+  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s)
   {
-    if (ncells > 0)
-      hipLaunchKernelGGL(ebe_partial, dim3(uint32_t(ncells)), dim3(384), 0, s, p);
-  }
-  void launch_ebe_gather(const EbeGatherParams &g, hipStream_t s)
-  {
-    const int64_t n = g.node1 - g.node0;
-    if (n > 0)
-      hipLaunchKernelGGL(ebe_gather, dim3(uint32_t((n + 255) / 256)), dim3(256), 0, s, g);
+    if (cell_count > 0)
+      hipLaunchKernelGGL(ebe_spmv, dim3(cell_count), dim3(384), 0, s, p, cell_begin);
   }
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s)

@@ -515,16 +515,11 @@ namespace mi_detail
     bool fuse_level(Team &T, size_t l)
     {
       const Multigrid &mg0 = *T.members[0]->mg;
-      bool             all_ebe = true;
-      for (mi_ctx *m : T.members)
-        all_ebe = all_ebe && ebe_active(m->mg->levels[l].ctx, true);
-      if (mg0.fuse == 0 && !all_ebe)
+      if (mg0.fuse == 0)
         return false;
       for (mi_ctx *m : T.members)
         {
           const mi_ctx *lc = m->mg->levels[l].ctx;
-          if (ebe_active(lc, true))
-            continue; // the element-tangent product always finishes with the smoother update / residual (ebe_gather)
           if (lc->spmv_variant != 3 || (mg0.fuse == 1 && lc->mesh.nnodes > mg0.fuse_max_nodes))
             return false;
         }
