@@ -401,8 +401,9 @@ def main():
         # one step / the step's wall time
         n_prod = (spmv_n + tm["spmv_precond"][1]) / args.steps
         ebe = G.get_tuning("smoother_operator_active") == 1
-        # element-tangent product: 378 lower-triangle 3x3 blocks + 27 node ids per cell, x gathered, y zeroed and updated
-        ebe_bytes = G.ncells * (378 * 72 + 27 * 4) + 8 * G.n * 3
+        # element-tangent product: 378 lower-triangle 3x3 blocks + 27 node ids + first-touch bits per cell, x gathered,
+        # y written
+        ebe_bytes = G.ncells * (378 * 72 + 27 * 4 + 4) + 8 * G.n * 2
         asm_bytes = 8 * G.nnz + 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n + (G.ncells * 378 * 72 if ebe else 0)
         res_bytes = 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n
         step_bytes = (spmv_n / args.steps * spmv_bytes(G.nnodes, nnzb, 3) +

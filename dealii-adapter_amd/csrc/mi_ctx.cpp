@@ -238,8 +238,7 @@ namespace mi_detail
         // the ghost planes receive partial sums that nobody reads
         if (part == 1)
           return;
-        hipMemsetAsync(y, 0, size_t(c->n) * sizeof(double), c->stream);
-        mi::EbeParams e{c->d_ke, c->d_conn, x, y};
+        mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
         for (int col = 0; col < c->mesh.ncolours; ++col)
           mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]),
                               c->stream);
@@ -475,6 +474,9 @@ namespace mi_detail
     if (want && !c->d_ke)
       {
         HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+        const int rc = upload(c, &c->d_node_first, c->mesh.node_first);
+        if (rc)
+          return rc;
         c->ke_valid = false;
         c->mg_stale = c->mg_force = true;
       }
@@ -745,7 +747,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1652,7 +1654,12 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
           if (m->dim != 3 || m->degree != 2)
             return fail(c, MI_EINVAL, "element tangents exist for 3D Q2 meshes only");
           if (!m->d_ke)
-            HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+            {
+              HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+              const int rc = upload(m, &m->d_node_first, m->mesh.node_first);
+              if (rc)
+                return rc;
+            }
           m->ke_valid = false;
         }
       else if (k == "xcd_remap" && (value == 0 || value == 1))

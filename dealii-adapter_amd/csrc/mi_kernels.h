@@ -31,9 +31,10 @@ namespace mi
   struct EbeParams
   {
     const double  *ke;
-    const int32_t *conn; // [ncells][27] colour-sorted
-    const double  *x;
-    double        *y;    // += (zeroed by the caller)
+    const int32_t  *conn;  // [ncells][27] colour-sorted
+    const uint32_t *first; // [ncells] bit a: first cell (in processing order) that contains its local node a -> store
+    const double   *x;
+    double         *y;     // complete after all colours (no zero fill needed: first touches store)
   };
 
   struct SpmvParams

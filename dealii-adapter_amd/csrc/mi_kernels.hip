@@ -1445,7 +1445,8 @@ namespace mi
   // against the 7.62 GB of the assembled matrix, which is why the multigrid smoother (86 % of the fine-level products of
   // a time step) multiplies with this form; the CG's own product stays on the assembled matrix.
   // One workgroup per cell: thread = block (a >= b); the 6 partial results per block go through LDS and are summed per
-  // local dof in a fixed order (deterministic); cells of one colour share no node, so the update of y is race free.
+  // local dof in a fixed order (deterministic); cells of one colour share no node, so the update of y is race free; the
+  // first cell (in processing order) that contains a node stores, later ones add, so y needs no zero fill.
   // Constrained rows/columns were masked when the blocks were stored (exactly the values that entered the global matrix).
   __global__ __launch_bounds__(384) void ebe_spmv(EbeParams prm, int64_t cell0)
   {
@@ -1498,7 +1499,8 @@ namespace mi
           s += s_p[(a * (a + 1) / 2 + b) * 6 + i];
         for (int c = a + 1; c < NPC; ++c)
           s += s_p[(c * (c + 1) / 2 + a) * 6 + 3 + i];
-        prm.y[int64_t(s_conn[a]) * 3 + i] += s;
+        double *yp = &prm.y[int64_t(s_conn[a]) * 3 + i];
+        *yp        = ((prm.first[cell] >> a) & 1u) ? s : *yp + s; // first touch of the node: store
       }
   }
 

@@ -294,6 +294,8 @@ namespace mi
     std::vector<int32_t>  diagpos;      // [nnodes] block index of (node,node)
     std::vector<uint16_t> off;          // [ncells][npc][npc]: column slot of node b in block row of node a (bits 0-14);
                                         // bit 15: this cell is the FIRST (in processing order) to touch that block
+    std::vector<uint32_t> node_first;   // [ncells] bit a set: this cell is the FIRST (in processing order) that contains
+                                        // its local node a -> a cell-by-cell product may store instead of add (no memset)
     std::vector<uint8_t>  cmask;        // [nnodes] bit c set: dof (node,c) is Dirichlet-constrained
     std::vector<int32_t>  iface_nodes;  // ascending
     std::vector<InterfaceFace> iface_faces;         // sorted by colour
@@ -569,6 +571,23 @@ namespace mi
                 }
           }
       }
+      // the same for nodes (cells with up to 32 nodes: every element of the 3D Q2 product; empty otherwise)
+      node_first.clear();
+      if (npc <= 32)
+        {
+          node_first.assign(size_t(ncells), 0u);
+          std::vector<uint8_t> seen((size_t)nnodes, 0);
+          for (int64_t pos = 0; pos < ncells; ++pos)
+            for (int a = 0; a < npc; ++a)
+              {
+                const size_t nd = size_t(conn[size_t(pos) * npc + a]);
+                if (!seen[nd])
+                  {
+                    seen[nd] = 1;
+                    node_first[size_t(pos)] |= 1u << a;
+                  }
+              }
+        }
       iface_nodes.clear();
       for (int64_t n = 0; n < nnodes; ++n)
         if (on_iface[size_t(n)])
