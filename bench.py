@@ -221,6 +221,10 @@ def main():
                     help="what the multigrid smoother multiplies with on the fine level: the unassembled symmetric element "
                          "tangents (default where available: undecomposed 3D Q2 meshes; 27 %% fewer bytes per product) or the "
                          "assembled sliced-ELL matrix; the CG's own product always uses the assembled matrix")
+    ap.add_argument("--cg-start", choices=["zero", "previous-update"], default="zero",
+                    help="start vector of the 2nd, 3rd ... linear solve of a step: zero (default) or the previous Newton update, "
+                         "as the reference's loop has it (nonlinear_elasticity.cc:419,472: costs 6 more CG iterations per step); "
+                         "the N = 1 line reports the other choice as a second measurement")
     ap.add_argument("--slabs", type=int, default=1, help="diagnostic: cut the mesh into this many slabs on ONE GPU")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N GPUs: strong = the one cells^3 block (BASELINE configuration 4) is cut into N parts (default); "
@@ -283,13 +287,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, cells, steps, warmup, uid_):
+    def measure(scaling, cells, steps, warmup, uid_, cg_start=None):
         """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
         nz = cells * parts if scaling == "weak" else cells
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
                       rho=1000.0, beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
                       world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
         G.set_tuning("smoother_operator", 1 if args.smoother_operator == "element" else 0)
+        G.set_tuning("cg_warm_start", 1 if (cg_start or args.cg_start) == "previous-update" else 0)
         if os.environ.get("MI_CG_FUSED_DOT"):
             G.set_tuning("cg_fused_dot", int(os.environ["MI_CG_FUSED_DOT"]))
         G.set_tuning("precond", 1 if args.precond == "mg" else 0)
@@ -320,7 +325,8 @@ def main():
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        r = {"G": G, "elapsed": elapsed, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
+        lin_its_last = [int(info.lin_its[i]) for i in range(min(info.newton_iterations, 16))]
+        r = {"G": G, "elapsed": elapsed, "lin_its_last": lin_its_last, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
              "tm": G.timings(), "comm": G.comm_info()}
         return r
 
@@ -367,6 +373,10 @@ def main():
                 "newton_iterations_per_step": R["newton"] / args.steps,
                 "cg_iterations_per_step": R["cg_its"] / args.steps,
                 "assemblies_per_step": R["assemblies"] / args.steps,
+                "cg_iterations_last_step": R["lin_its_last"],
+                "cg_start": "zero for every solve (the reference starts the 2nd, 3rd ... solve of a step from the previous Newton "
+                            "update: same stopping rule, more iterations; --cg-start previous-update)"
+                if args.cg_start == "zero" else "previous Newton update, as in the reference (nonlinear_elasticity.cc:419,472)",
                 "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
                 "ms_cg_per_step": tm["cg_total"][0] / args.steps,
                 "ms_sell_copy_per_step": tm["sell_copy"][0] / args.steps,
@@ -452,6 +462,14 @@ def main():
                                    "workload": "%dx%dx%d cells (%d^3 per GPU)" % (n, n, W["nz"], n),
                                    "cg_iterations_per_step": W["cg_its"] / args.steps}
         del W
+    if world == 1 and args.slabs == 1:
+        # the other start vector, measured beside the headline (3 steps)
+        other = "previous-update" if args.cg_start == "zero" else "zero"
+        S = measure(args.scaling, n, 3, 1, None, cg_start=other)
+        out["config"]["with_cg_start_" + other.replace("-", "_")] = {
+            "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"], "cg_iterations_per_step": S["cg_its"] / 3,
+            "cg_iterations_last_step": S["lin_its_last"], "steps": 3, "warmup": 1}
+        del S
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         # the GPU on the CPU sample's own configuration, beside it
         its_a, its_b = (int(x) for x in args.cpu_its.split(","))

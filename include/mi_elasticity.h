@@ -152,7 +152,11 @@ int mi_assemble(mi_ctx *ctx, double *res_norm);     /* :446 -> :1044-1087 incl. 
 int mi_assemble_residual(mi_ctx *ctx, double *res_norm);
 int mi_cg_solve(mi_ctx *ctx, double rel_tol, int64_t max_it, int *its, double *res);
                                                     /* :472 -> :1153-1191 (Jacobi-PCG, warm start) + :1208 */
-int mi_apply_newton_update(mi_ctx *ctx, double *upd_norm); /* get_error_update :564-576; delta += update :487 */
+int mi_apply_newton_update(mi_ctx *ctx, double *upd_norm); /* get_error_update :564-576; delta += update :487; then
+                                                       the consumed update is cleared, so that the next solve of the
+                                                       step starts from zero -- unless mi_set_tuning("cg_warm_start", 1)
+                                                       asks for the reference's start vector, the previous update
+                                                       (:419, :472-473: 28 instead of 22 CG iterations per step) */
 int mi_newmark_finish_step(mi_ctx *ctx);            /* :139-144: u += delta; a, v updates; old := new      */
 /* the whole of solve_nonlinear_timestep + :139-144 with the reference's convergence logic */
 int mi_newmark_step(mi_ctx *ctx, const mi_solver_desc *s, mi_step_info *info);
@@ -240,7 +244,7 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * rows of the SpMV (default), 0 in line on the compute stream; "precond_storage" 64 (default) | 32: the multigrid
  * smoother multiplies with an fp32-rounded copy of the level matrices (arithmetic, the CG's own product and its
  * residuals stay fp64); "sell_icol" 1 (default): the SpMV generates the column indices of a row from its
- * column box (lattice meshes) instead of reading them, 0: reads the index array; "smoother_operator" 1 (default): on 3D Q2 meshes above 100k nodes per slab the multigrid smoother multiplies with the unassembled symmetric element tangents (27 % fewer bytes than the assembled matrix; the CG's own product stays on the assembled matrix), 0: with the assembled matrix; "spmv_variant" 4 + "element_tangents" 1: mi_spmv through the element tangents, "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
+ * column box (lattice meshes) instead of reading them, 0: reads the index array; "smoother_operator" 1 (default): on 3D Q2 meshes above 100k nodes per slab the multigrid smoother multiplies with the unassembled symmetric element tangents (27 % fewer bytes than the assembled matrix; the CG's own product stays on the assembled matrix), 0: with the assembled matrix; "spmv_variant" 4 + "element_tangents" 1: mi_spmv through the element tangents, "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
  * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 /* read back: "smoother_operator_active" (1: the smoother's fine-level products use the element tangents), "precond",
