@@ -387,12 +387,21 @@ def test_newton_table_values_follow_reference_logic():
     P.set_interface_traction(t)
     G.set_interface_traction(t)
     G.set_tuning("precond", 0)
+    G.set_tuning("cg_warm_start", 1)  # the reference's start vector for the later solves of a step (:419, :472-473)
     rc_o, io = P.newmark_step(O.SOLVER_CG_JACOBI, tol_lin=1e-10)
     rc_g, ig = G.newmark_step(tol_lin=1e-10)
     assert rc_o == 0 and rc_g == 0
     assert (ig.newton_iterations, ig.assemblies, ig.converged) == (io.newton_iterations, io.assemblies, 1)
     assert abs(ig.res_abs - io.res_abs) <= 1e-6 * max(io.res_abs, 1e-9) + 1e-9
     assert abs(ig.lin_its_total - io.lin_its_total) <= ig.newton_iterations
+    # the default start vector (zero for every solve): same Newton table, same state, fewer linear iterations
+    P2, G2 = _pair(3, 2, (3, 2, 2))
+    G2.set_interface_traction(t)
+    G2.set_tuning("precond", 0)
+    rc_z, iz = G2.newmark_step(tol_lin=1e-10)
+    assert rc_z == 0 and (iz.newton_iterations, iz.assemblies, iz.converged) == (ig.newton_iterations, ig.assemblies, 1)
+    assert iz.lin_its_total < ig.lin_its_total
+    assert _relmax(G2.get(M.V_U), G.get(M.V_U)) < 1e-8
     # too few Newton iterations -> the reference's "No convergence in nonlinear solver!"
     rc, _ = G.newmark_step(max_it_nr=1, check=False)
     assert rc == M.MI_ENOCONV_NR
