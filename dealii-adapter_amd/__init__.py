@@ -19,9 +19,9 @@ MI_OK, MI_EINVAL, MI_EHIP, MI_ENOCONV_LIN, MI_ENOCONV_NR, MI_ECOMM = 0, -1, -2, 
 FACE_FREE, FACE_CLAMPED, FACE_INTERFACE, FACE_ZCLAMP = 0, 1, 7, 8
 (V_U, V_U_OLD, V_V, V_V_OLD, V_A, V_A_OLD, V_STRESS, V_DELTA, V_NEWTON, V_RHS) = range(10)
 (T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_SELL_COPY, T_ASSEMBLE_RESIDUAL,
- T_SPMV_PRECOND, T_COUNT) = range(11)
+ T_SPMV_PRECOND, T_EBE_LAUNCH, T_COUNT) = range(12)
 TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step", "sell_copy",
-                "assemble_residual", "spmv_precond"]
+                "assemble_residual", "spmv_precond", "ebe_launch"]
 
 
 class MeshDesc(C.Structure):

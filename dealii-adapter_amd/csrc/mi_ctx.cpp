@@ -239,9 +239,17 @@ namespace mi_detail
         if (part == 1)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
+        // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
+        // profiler reports them), class MI_T_EBE_LAUNCH
+        mi_ctx    *c0     = c->team->members[0];
+        const bool sample = c0->profiling && (c->ebe_products++ % 6 == 0);
         for (int col = 0; col < c->mesh.ncolours; ++col)
-          mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]),
-                              c->stream);
+          {
+            const int32_t cnt = int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]);
+            const int     t   = (sample && cnt > 0) ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
+            mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], cnt, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+          }
         return;
       }
     if (c->spmv_variant == 3 || c->spmv_variant == 4 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only

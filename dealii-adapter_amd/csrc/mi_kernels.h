@@ -135,7 +135,9 @@ namespace mi
   void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
   void set_next_sell_launch_events(hipEvent_t start, hipEvent_t stop); // profiling: bracket exactly the next launch
-  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s);
+  // ev_start / ev_stop (optional): bracket exactly this launch (dispatch-level events, profiling)
+  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
+                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s);

@@ -2617,9 +2617,14 @@ namespace mi
     else
       dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
   }
-  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s)
+  void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,
+                       hipEvent_t ev_stop)
   {
-    if (cell_count > 0)
+    if (cell_count <= 0)
+      return;
+    if (ev_start && ev_stop)
+      hipExtLaunchKernelGGL(ebe_spmv, dim3(cell_count), dim3(384), 0, s, ev_start, ev_stop, 0, p, cell_begin);
+    else
       hipLaunchKernelGGL(ebe_spmv, dim3(cell_count), dim3(384), 0, s, p, cell_begin);
   }
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,

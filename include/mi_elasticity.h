@@ -228,7 +228,9 @@ enum
   MI_T_STEP,               /* whole mi_newmark_step                           */
   MI_T_SELL_COPY,          /* block-CSR -> sliced-ELL copy before the first product with a new tangent */
   MI_T_ASSEMBLE_RESIDUAL,  /* all colours of one residual-only pass (mi_assemble_residual)              */
-  MI_T_SPMV_PRECOND,       /* fine-level products of the multigrid preconditioner (same kernel, DOT = false) */
+  MI_T_SPMV_PRECOND,       /* fine-level products of the multigrid preconditioner, per product                */
+  MI_T_EBE_LAUNCH,         /* single launches of ebe_spmv (one colour of one element-tangent product), timed from
+                              the dispatch itself on a sample of the products (every 6th)                      */
   MI_T_COUNT
 };
 typedef struct
