@@ -51,6 +51,12 @@ def scenario(G, M, kw, log):
     G.set_tuning("halo_overlap", kw.get("overlap", 1))
     for precond in (0, 1):
         G.set_tuning("precond", precond)
+        if precond == 1 and kw.get("ebe"):
+            # the smoother on the element tangents (as on big meshes): unfused smoother, every slab multiplies with all its
+            # local cells after the halo exchange
+            G.set_tuning("element_tangents", 1)
+            G.set_tuning("mg_fuse", 0)
+            assert G.get_tuning("smoother_operator_active") == 1
         its = []
         for step in range(2):
             G.set_interface_traction((0.0, -1.5e3 * (step + 1), 0.0)[:G.dim])
@@ -78,6 +84,7 @@ def main():
     dim, p = int(sys.argv[2]), int(sys.argv[3])
     reps = tuple(int(v) for v in sys.argv[4].split(","))
     overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+    ebe = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     M = load()
     hi = tuple(0.1 * r for r in reps)
     roles = [1, 7, 7, 7, 8, 7]
@@ -88,7 +95,7 @@ def main():
     def rank_main(r):
         try:
             G = M.Context(rank=r, world=world, unique_id=uid, **common)
-            results[r] = scenario(G, M, dict(overlap=overlap), None)
+            results[r] = scenario(G, M, dict(overlap=overlap, ebe=ebe), None)
             G.close()
         except BaseException as e:  # noqa: BLE001 -- reported to the parent test
             errors.append("rank %d: %r" % (r, e))
@@ -101,8 +108,8 @@ def main():
     if errors or any(t.is_alive() for t in threads):
         print(json.dumps({"ok": False, "errors": errors, "hung": [t.is_alive() for t in threads]}), flush=True)
         os._exit(1)
-    single = scenario(M.Context(**common), M, {}, None)
-    emu = scenario(M.Context(slabs=world, **common), M, {}, None)
+    single = scenario(M.Context(**common), M, dict(ebe=ebe), None)
+    emu = scenario(M.Context(slabs=world, **common), M, dict(ebe=ebe), None)
 
     def rel(a, b):
         return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))

@@ -24,11 +24,14 @@ def fake_lib():
     return True
 
 
-@pytest.mark.parametrize("world,dim,p,reps,overlap", [(2, 3, 2, "3,2,5", 1), (3, 3, 2, "3,3,7", 1), (4, 3, 1, "4,3,9", 1),
-                                                      (2, 3, 2, "3,2,5", 0), (3, 2, 3, "4,9", 1), (8, 3, 2, "3,3,17", 1)])
-def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, overlap):
-    out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap)],
-                         capture_output=True, text=True, timeout=900)
+@pytest.mark.parametrize("world,dim,p,reps,overlap,ebe", [(2, 3, 2, "3,2,5", 1, 0), (3, 3, 2, "3,3,7", 1, 0),
+                                                          (4, 3, 1, "4,3,9", 1, 0), (2, 3, 2, "3,2,5", 0, 0),
+                                                          (3, 2, 3, "4,9", 1, 0), (8, 3, 2, "3,3,17", 1, 0),
+                                                          (3, 3, 2, "3,3,7", 1, 1)])
+def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, overlap, ebe):
+    """ebe = 1: the multigrid smoother on the unassembled element tangents, as on big meshes"""
+    out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap),
+                          str(ebe)], capture_output=True, text=True, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, (out.stdout[-2000:], out.stderr[-3000:])
     r = json.loads(lines[-1])
