@@ -424,7 +424,7 @@ def main():
         out["config"]["smoother_operator"] = ("unassembled symmetric element tangents (%.2f GB per product)" % (ebe_bytes / 1e9)
                                               if ebe else "assembled sliced-ELL matrix")
         out["config"]["ms_smoother_fine_product"] = tm["spmv_precond"][0] / max(tm["spmv_precond"][1], 1)
-        if ebe and tm["ebe_launch"][1] > 0 and world == 1:
+        if ebe and tm["ebe_launch"][1] > 0 and world == 1 and args.slabs == 1:
             # the DOMINANT kernel of the step (half of the GPU time) is the element-tangent product of the multigrid smoother:
             # the roofline object is quoted on it, the CG's product (the kernel north_star names) moves to `cg_product`
             cg = out["roofline"]
