@@ -68,3 +68,14 @@ def test_host_compiles_against_precice_v3_api():
                    "-D__HIP_PLATFORM_AMD__", src]
             out = subprocess.run(cmd, cwd=host, capture_output=True, text=True)
             assert out.returncode == 0 and "error" not in out.stderr, out.stderr[-3000:]
+
+
+def test_precice_v3_build_links_against_the_test_double(host_built, tmp_path):
+    """-DMI_WITH_PRECICE build linked against tests/fake_precice/libprecice.so (the v3 signatures forwarded to the replay
+    participant); without a device it still gets as far as the reference does before the solver starts"""
+    fake = os.path.join(ROOT, "tests", "fake_precice")
+    subprocess.check_call(["make", "-C", fake])
+    out = subprocess.run(["ldd", os.path.join(fake, "elasticity_precice")], capture_output=True, text=True).stdout
+    assert "libprecice.so" in out
+    r = subprocess.run([os.path.join(fake, "elasticity_precice"), "nope.prm"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 1 and "Exception on processing:" in r.stderr

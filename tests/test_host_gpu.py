@@ -133,6 +133,28 @@ def test_executable_replays_a_per_vertex_force_trace(tmp_path):
     assert np.abs(exp[-1][1][:, 0]).max() > 0  # the trace really has an x component that varies along the flap
 
 
+@pytest.mark.parametrize("name", ["fsi3_neo_2d_explicit", "fsi3_neo_2d_implicit", "fsi3_linear_2d_shipped"])
+def test_precice_v3_code_path_links_and_runs(tmp_path, name):
+    """the host's -DMI_WITH_PRECICE branch (it includes <precice/precice.hpp> and talks to precice::Participant with the
+    v3 signatures) LINKED against a test double of libprecice (tests/fake_precice: string_view / span arguments
+    forwarded to the replay participant) and RUN: explicit and implicit (checkpointed) coupling and the linear model
+    give bit-identical logs with the default build"""
+    fake = os.path.join(ROOT, "tests", "fake_precice")
+    subprocess.check_call(["make", "-C", fake])
+    out = subprocess.run(["ldd", os.path.join(fake, "elasticity_precice")], capture_output=True, text=True).stdout
+    assert "libprecice.so" in out and "libmi_elasticity.so" in out
+    logs = []
+    for exe in (os.path.join(HOST, "elasticity"), os.path.join(fake, "elasticity_precice")):
+        d = tmp_path / os.path.basename(exe)
+        d.mkdir()
+        for f in ("parameters.prm", "precice-config.xml"):
+            (d / f).write_text(open(os.path.join(CASES, name, f)).read())
+        r = subprocess.run([exe], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        logs.append(open(d / "displacement.log").read())
+    assert logs[0] == logs[1] and logs[0].count("\n") >= 3
+
+
 def test_executable_nonlinear_implicit_checkpointing(tmp_path):
     """implicit coupling: 3 coupling iterations per window with save/reload of the 6 state vectors on the device"""
     name = "fsi3_neo_2d_implicit"
