@@ -359,6 +359,8 @@ namespace mi_detail
       mg->nu_coarse = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_FUSE"))
       mg->fuse = std::min(2, std::max(0, atoi(e)));
+    if (const char *e = getenv("MI_MG_FUSE_MAX_NODES"))
+      mg->fuse_max_nodes = std::max(0, atoi(e));
     if (const char *e = getenv("MI_MG_BLOCK"))
       mg->block = atoi(e) != 0;
     if (const char *e = getenv("MI_MG_KIND"))

@@ -167,11 +167,24 @@ def test_headline_size_invariants():
     x, y = rng.standard_normal(G.n), rng.standard_normal(G.n)
     Kx, Ky = G.spmv(x), G.spmv(y)
     assert abs(y @ Kx - x @ Ky) / abs(y @ Kx) < 1e-11
+    # the smoother's operator (unassembled element tangents, active at this size) is the assembled matrix
+    assert G.get_tuning("smoother_operator_active") == 1
+    G.set_tuning("spmv_variant", 4)
+    assert np.abs(G.spmv(x) - Kx).max() / np.abs(Kx).max() < 1e-13
+    G.set_tuning("spmv_variant", 3)
     G.set(M.V_NEWTON, np.zeros(G.n))
     rc, its, res = G.cg_solve(rel_tol=1e-8)
     assert rc == 0
     true_res = np.linalg.norm(r1 - G.spmv(G.get(M.V_NEWTON)))
     assert true_res <= 1.5e-8 * np.linalg.norm(r1) and abs(true_res - res) / res < 1e-3
+    # the reference's start vector for the later solves of the step: same Newton bookkeeping, more linear iterations
+    Gw = M.Context(dim=3, degree=2, reps=(n, n, n))
+    Gw.set_tuning("cg_warm_start", 1)
+    Gw.set_interface_traction((0.0, -2e3, 0.0))
+    rcw, infow = Gw.newmark_step(tol_lin=1e-6, max_it_mult=1.0)
+    assert rcw == 0 and infow.newton_iterations == info.newton_iterations and infow.lin_its_total > info.lin_its_total
+    assert np.abs(Gw.get(M.V_U) - u).max() / np.abs(u).max() < 1e-5  # Residual = 1e-6 regime
+    del Gw
     # two slabs: same residual vector and the same Newton/CG bookkeeping for the same step
     G2 = M.Context(dim=3, degree=2, reps=(n, n, n), slabs=2)
     G2.set_interface_traction((0.0, -2e3, 0.0))
