@@ -511,7 +511,7 @@ namespace mi_detail
 
   // Jacobi-PCG (deal.II SolverCG semantics: start from x, stop when ||r||_2 <= tolerance) on the active matrix of
   // every slab of the team; followed by constraints.distribute (x[constrained] = 0)
-  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res)
+  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero)
   {
     Team      &T    = *c->team;
     mi_ctx    *c0   = T.members[0];
@@ -611,7 +611,12 @@ namespace mi_detail
     // r0 = b - A x0, tolerance = rel_tol * ||b||  (:1171-1172)
     auto self = [](mi_ctx *m) { return m; };
     auto q_of = [](mi_ctx *m) { return m->work(W_Q); };
-    if ((rc = team_spmv(T, self, x_of, q_of, nullptr))) // not under MI_T_SPMV: that class is the fused q = K p only
+    if (x_is_zero) // the start vector is known to be zero: A x0 = 0 without a product
+      {
+        for (mi_ctx *m : T.members)
+          HIPCHK(m, hipMemsetAsync(m->work(W_Q), 0, size_t(m->n) * sizeof(double), m->stream));
+      }
+    else if ((rc = team_spmv(T, self, x_of, q_of, nullptr))) // not under MI_T_SPMV: that class is the fused q = K p only
       return rc;
     for (size_t k = 0; k < R; ++k)
       {
@@ -1265,6 +1270,7 @@ int mi_newton_begin_step(mi_ctx *c)
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
       m->mg_force = true; // new time step: refresh the coarse operators at its first solve
     }
+  c->team->members[0]->newton_update_is_zero = true;
   return MI_OK;
 }
 
@@ -1341,8 +1347,12 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
       m->active_sell_vals = nullptr; // tangent
       m->active_dinv      = nullptr;
     }
-  // SolverCG starts from the passed vector (:1184-1187): whatever MI_V_NEWTON_UPDATE holds (see mi_apply_newton_update)
-  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res);
+  // SolverCG starts from the passed vector (:1184-1187): whatever MI_V_NEWTON_UPDATE holds (see mi_apply_newton_update);
+  // when the library itself has just cleared it, r0 = b needs no product
+  mi_ctx    *c0     = c->team->members[0];
+  const bool x_zero = c0->newton_update_is_zero;
+  c0->newton_update_is_zero = false;
+  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res, x_zero);
   // a breakdown (NaN state, indefinite tangent) is final, as with deal.II's SolverControl: no second attempt from a
   // poisoned iterate
   const bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
@@ -1384,6 +1394,7 @@ int mi_apply_newton_update(mi_ctx *c, double *upd_norm)
       if (!m->cg_warm_start)
         HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
     }
+  T.members[0]->newton_update_is_zero = !T.members[0]->cg_warm_start;
   HIPCHK(c, hipGetLastError());
   if (upd_norm)
     *upd_norm = nrm;
@@ -1553,6 +1564,8 @@ int mi_snapshot_load(mi_ctx *c, const mi_snapshot *s, int which)
 {
   if (!s || which < 0 || which >= MI_V_COUNT)
     return fail(c, MI_EINVAL, "bad snapshot or vector id");
+  if (which == MI_V_NEWTON_UPDATE)
+    c->team->members[0]->newton_update_is_zero = false;
   HIPCHK(c, hipSetDevice(c->device));
   for (size_t k = 0; k < c->team->members.size(); ++k)
     {
@@ -1594,6 +1607,8 @@ int mi_vec_set(mi_ctx *c, int which, const double *host, int64_t n)
     return fail(c, MI_EINVAL, "bad vector id or length");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (which == MI_V_NEWTON_UPDATE)
+    T.members[0]->newton_update_is_zero = false;
   for (mi_ctx *m : T.members) // every slab takes its local range (ghost planes included) from the global array
     HIPCHK(m, hipMemcpy(m->vec(which), host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
                         hipMemcpyHostToDevice));

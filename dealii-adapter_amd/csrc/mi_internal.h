@@ -109,6 +109,7 @@ struct mi_ctx
   double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
   size_t    h_pinned_doubles = 0;
   bool      have_saved = false;
+  bool      newton_update_is_zero = false; // MI_V_NEWTON_UPDATE was cleared by the library and not written since
   bool      cg_breakdown = false; // the last solve stopped on a non-finite residual or p.Ap <= 0
 
   int grid_vec = 0, grid_spmv = 0, grid_spmv_int = 0, grid_spmv_bnd = 0; // grid_spmv = _int + _bnd (partials)
@@ -167,7 +168,8 @@ namespace mi_detail
   int  set_precond_storage(mi_ctx *c, int bits); // 64 | 32, for the context and its multigrid levels
   // Jacobi-PCG on the active matrix (all slabs of the team): x = vector x_id (warm start), b = vector b_id;
   // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
-  int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res);
+  // x_is_zero: the start vector is known to be zero (r0 = b without a product)
+  int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero = false);
   int  team_size(const mi_ctx *c);
   void linear_destroy(mi_ctx *c);
   int  create_member(Team &T, const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int rank,
