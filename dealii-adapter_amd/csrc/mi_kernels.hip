@@ -265,11 +265,15 @@ namespace mi
     __shared__ double s_N1[NQ1 * NP1], s_dN1[NQ1 * NP1], s_qw[NQ1], s_qx[NQ1];
     __shared__ double s_u[NPC * 3], s_a[NPC * 3], s_verts[NV * DIM];
     __shared__ int    s_conn[NPC];
-    __shared__ __attribute__((aligned(16))) double s_qp[NQ * RQ];
     // per quadrature point NPCP records of RN doubles, padded by NDPAD doubles: the two lanes of a tile read the same
     // records of neighbouring points, and an unpadded point stride (a multiple of 32 B) put them on the same banks
     constexpr int NDS = NPCP * RN + NDPAD;
-    __shared__ __attribute__((aligned(16))) double s_nd[QC * NDS];
+    // one buffer for the point records and the (point, node) records: after the main loop it stages the cell's element
+    // tangent for a coalesced store (3D Q2: 3402 of its 4304 doubles)
+    constexpr int NSTAGE = (DIM == 3 && P == 2 && ABL == 0) ? 9 * EBE_NBLK : 0;
+    constexpr int NBIG   = (NQ * RQ + QC * NDS > NSTAGE) ? NQ * RQ + QC * NDS : NSTAGE;
+    __shared__ __attribute__((aligned(16))) double s_big[NBIG];
+    double *const s_qp = s_big, *const s_nd = s_big + NQ * RQ;
 
     const int     tid  = threadIdx.x;
     const int64_t cell = prm.cell_begin + blockIdx.x;
@@ -589,9 +593,9 @@ namespace mi
                   vba[j * DIM + i] = v;
                 }
             if constexpr (DIM == 3 && P == 2)
-              if (prm.ke) // the cell's own (masked) block, before it is summed into the global matrix
+              if (prm.ke) // the cell's own (masked) block, before it is summed into the global matrix: staged in LDS
                 {
-                  double *__restrict__ kq = prm.ke + cell * (int64_t(DD) * EBE_NBLK) + (a * (a + 1) / 2 + b);
+                  double *kq = s_big + (a * (a + 1) / 2 + b);
 #pragma unroll
                   for (int k = 0; k < DD; ++k)
                     kq[k * EBE_NBLK] = vab[k];
@@ -615,6 +619,14 @@ namespace mi
               }
           }
       }
+    if constexpr (DIM == 3 && P == 2 && ABL == 0)
+      if (prm.ke) // the staged element tangent: 3402 contiguous doubles per cell, coalesced
+        {
+          __syncthreads();
+          double *__restrict__ dst = prm.ke + cell * (int64_t(DD) * EBE_NBLK);
+          for (int i = tid; i < DD * EBE_NBLK; i += NT)
+            dst[i] = s_big[i];
+        }
       } // pass
   }
 
