@@ -6,6 +6,9 @@ profiles/r02/cpu_baseline_config3_full.json and supplies the per-step unit count
 bench.py's bounded live sample is scaled with.
 
   python tools/cpu_baseline_full.py [cells] > gpurun_out/cpu_baseline_config3_full.json
+  python tools/cpu_baseline_full.py 59 newton > gpurun_out/cpu_baseline_config4_one_newton_iteration.json
+      (configuration 4: ONE Newton iteration = one assembly + one linear solve, as BASELINE.md section 2 prescribes when
+       whole steps at 5 M DoFs are out of reach on the CPU)
 """
 import os
 import subprocess
@@ -13,4 +16,5 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cells = int(sys.argv[1]) if len(sys.argv) > 1 else 34
-sys.exit(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", "%d,0,0,1" % cells]).returncode)
+mode = 2 if len(sys.argv) > 2 and sys.argv[2] == "newton" else 1
+sys.exit(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-worker", "%d,0,0,%d" % (cells, mode)]).returncode)
