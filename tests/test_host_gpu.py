@@ -334,6 +334,7 @@ def test_linear_model_matrices_and_steps(dim, p, reps):
 
 
 @pytest.mark.parametrize("name,exe,dim", [("fsi3_linear_2d_shipped", "elasticity", 2),
+                                          ("pf_linear_2d", "elasticity", 2),
                                           ("fsi3_linear_3d_shipped", "elasticity3d", 3),
                                           ("block_linear_3d_q1_cg", "elasticity3d", 3)])
 def test_executable_linear(tmp_path, name, exe, dim):
@@ -346,7 +347,8 @@ def test_executable_linear(tmp_path, name, exe, dim):
     oracle_direct = P.n < 4000  # the oracle's banded LU; beyond that its CG + SSOR at the reference's absolute 1e-10
     dt, exp = float(get("Time step size")), []
     for k in range(len(rows)):
-        t = (0.0, -40.0 * min(1.0, (k + 1) / 2.0), 0.0)[:dim] if "shipped" in name else (0.0, -200.0, 0.0)
+        t = ((0.0, -40.0 * min(1.0, (k + 1) / 2.0), 0.0)[:dim] if "shipped" in name else
+             (30.0 * min(1.0, (k + 1) / 2.0), 0.0) if name == "pf_linear_2d" else (0.0, -200.0, 0.0))
         P.vec(O.L_STRESS)[:] = 0
         for c in range(dim):
             P.vec(O.L_STRESS)[ids * dim + c] = t[c]
