@@ -199,6 +199,14 @@ def cpu_baseline(cells, its_a, its_b):
         out["value"] = None
         what += "; no committed full run for this size: per-unit times only"
     out["sample"] = what + "; restatement of the reference algorithm (oracle/), not the deal.II binary"
+    c4 = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config4_one_newton_iteration.json")
+    if os.path.exists(c4):
+        # committed one-off run on the metric's own mesh (one Newton iteration of configuration 4)
+        f = json.load(open(c4))
+        out["config4_one_newton_iteration_committed"] = {
+            "file": os.path.relpath(c4, ROOT), "n_dofs": f["n_dofs"], "cores": f["cores"], "t_assembly_s": f["t_assembly_s"],
+            "A_cg_ssor_s": f["A_cg_ssor"]["t_newton_iteration_s"], "A_cg_iterations": f["A_cg_ssor"]["cg_iterations"],
+            "B_cg_jacobi_s": f["B_cg_jacobi"]["t_newton_iteration_s"], "B_cg_iterations": f["B_cg_jacobi"]["cg_iterations"]}
     return out
 
 
