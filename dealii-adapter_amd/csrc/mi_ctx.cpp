@@ -1067,8 +1067,8 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
           }
       }
   }
-  // element tangents for the smoother (see ebe_spmv): 3D Q2 on an undecomposed mesh with the multigrid preconditioner
-  // (a slab would multiply its ghost layer twice, and small problems run the fused smoother on the assembled matrix)
+  // element tangents for the smoother (see ebe_spmv): 3D Q2 with the multigrid preconditioner, on every slab that is big
+  // enough for the unfused smoother (small problems run the fused smoother on the assembled matrix)
   for (mi_ctx *m : T->members)
     {
       if (const char *e = getenv("MI_EBE"))

@@ -90,6 +90,83 @@ __global__ __launch_bounds__(NT) void ebe_product(const double *__restrict__ ke,
     }
 }
 
+#include <hip/hip_cooperative_groups.h>
+namespace cg = cooperative_groups;
+
+// persistent variant: ONE cooperative launch per product; every workgroup walks its share of the cells of colour 0, then
+// all workgroups meet at a grid-wide barrier, then colour 1, ...
+struct Colours
+{
+  long begin[9];
+};
+__global__ __launch_bounds__(NT) void ebe_persistent(const double *__restrict__ ke, const int *__restrict__ conn,
+                                                     const double *__restrict__ x, double *y, Colours cb)
+{
+  __shared__ double s_x[NPC * 3];
+  __shared__ double s_p[NBLK * 6 + 6];
+  __shared__ int    s_conn[NPC];
+  cg::grid_group grid = cg::this_grid();
+  const int  tid = threadIdx.x;
+  const bool act = tid < NBLK;
+  int a = 0, b = 0;
+  if (act)
+    {
+      a = int((sqrtf(8.0f * float(tid) + 1.0f) - 1.0f) * 0.5f);
+      while ((a + 1) * (a + 2) / 2 <= tid)
+        ++a;
+      while (a * (a + 1) / 2 > tid)
+        --a;
+      b = tid - a * (a + 1) / 2;
+    }
+  for (int col = 0; col < 8; ++col)
+    {
+      for (long cell = cb.begin[col] + blockIdx.x; cell < cb.begin[col + 1]; cell += gridDim.x)
+        {
+          const double *__restrict__ kp = ke + cell * (9L * ESTRIDE) + tid;
+          double k[9];
+          if (act)
+            {
+#pragma unroll
+              for (int e = 0; e < 9; ++e)
+                k[e] = __builtin_nontemporal_load(&kp[e * ESTRIDE]);
+            }
+          if (tid < NPC)
+            s_conn[tid] = conn[cell * NPC + tid];
+          __syncthreads();
+          if (tid < NPC * 3)
+            s_x[tid] = x[long(s_conn[tid / 3]) * 3 + tid % 3];
+          __syncthreads();
+          if (act)
+            {
+              const double xa0 = s_x[a * 3], xa1 = s_x[a * 3 + 1], xa2 = s_x[a * 3 + 2];
+              const double xb0 = s_x[b * 3], xb1 = s_x[b * 3 + 1], xb2 = s_x[b * 3 + 2];
+              double *p = &s_p[tid * 6];
+              p[0] = k[0] * xb0 + k[1] * xb1 + k[2] * xb2;
+              p[1] = k[3] * xb0 + k[4] * xb1 + k[5] * xb2;
+              p[2] = k[6] * xb0 + k[7] * xb1 + k[8] * xb2;
+              const double s = (a == b) ? 0.0 : 1.0;
+              p[3] = s * (k[0] * xa0 + k[3] * xa1 + k[6] * xa2);
+              p[4] = s * (k[1] * xa0 + k[4] * xa1 + k[7] * xa2);
+              p[5] = s * (k[2] * xa0 + k[5] * xa1 + k[8] * xa2);
+            }
+          __syncthreads();
+          if (tid < NPC * 3)
+            {
+              const int na = tid / 3, i = tid - na * 3;
+              double    s = 0.0;
+              for (int bb = 0; bb <= na; ++bb)
+                s += s_p[(na * (na + 1) / 2 + bb) * 6 + i];
+              for (int c = na + 1; c < NPC; ++c)
+                s += s_p[(c * (c + 1) / 2 + na) * 6 + 3 + i];
+              y[long(s_conn[na]) * 3 + i] += s;
+            }
+          __syncthreads();
+        }
+      if (col < 7)
+        grid.sync();
+    }
+}
+
 int main(int argc, char **argv)
 {
   const int n = argc > 1 ? atoi(argv[1]) : 59, reps = argc > 2 ? atoi(argv[2]) : 10;
@@ -217,7 +294,36 @@ int main(int argc, char **argv)
                variant % 2 == 0 ? "ONE launch" : "8 launches", sum / reps);
       }
   }
-  for (int split = 1; split <= 8; split *= 2)
+  {
+    int per_cu = 0, ncu = 0;
+    CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ebe_persistent, NT, 0));
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    ncu = prop.multiProcessorCount;
+    Colours cb;
+    for (int i = 0; i < 9; ++i)
+      cb.begin[i] = cbegin[i];
+    for (int frac = 1; frac <= 2; ++frac)
+      {
+        const int grid = ncu * per_cu / frac;
+        float sum = 0;
+        for (int r = 0; r < reps + 1; ++r)
+          {
+            CHK(hipMemsetAsync(d_y, 0, nnodes * 3 * 8, 0));
+            CHK(hipEventRecord(e0, 0));
+            void *args[] = {(void *)&d_ke, (void *)&d_conn, (void *)&d_x, (void *)&d_y, (void *)&cb};
+            CHK(hipLaunchCooperativeKernel((const void *)ebe_persistent, dim3(grid), dim3(NT), args, 0, 0));
+            CHK(hipEventRecord(e1, 0));
+            CHK(hipEventSynchronize(e1));
+            float ms;
+            CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (r > 0)
+              sum += ms;
+          }
+        printf("persistent cooperative launch, %d workgroups (%d per CU): avg %.3f ms per product\n", grid, per_cu / frac, sum / reps);
+      }
+  }
+  for (int split = 1; split <= 2; split *= 2)
     {
       float sum = 0;
       for (int r = 0; r < reps + 1; ++r)
