@@ -243,6 +243,9 @@ def main():
                     help="what the multigrid smoother multiplies with on the fine level: the unassembled symmetric element "
                          "tangents (default where available: undecomposed 3D Q2 meshes; 27 %% fewer bytes per product) or the "
                          "assembled sliced-ELL matrix; the CG's own product always uses the assembled matrix")
+    ap.add_argument("--cg-operator", choices=["assembled", "element"], default="assembled",
+                    help="A/B: the CG's own product on the assembled sliced-ELL matrix (default; the kernel the north star names) or "
+                         "on the unassembled element tangents like the smoother's (then no sliced-ELL copy is made)")
     ap.add_argument("--cg-start", choices=["zero", "previous-update"], default="zero",
                     help="start vector of the 2nd, 3rd ... linear solve of a step: zero (default) or the previous Newton update, "
                          "as the reference's loop has it (nonlinear_elasticity.cc:419,472: costs 6 more CG iterations per step); "
@@ -317,6 +320,7 @@ def main():
                       world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
         G.set_tuning("smoother_operator", 1 if args.smoother_operator == "element" else 0)
         G.set_tuning("cg_warm_start", 1 if (cg_start or args.cg_start) == "previous-update" else 0)
+        G.set_tuning("cg_operator", 1 if args.cg_operator == "element" else 0)
         if os.environ.get("MI_CG_FUSED_DOT"):
             G.set_tuning("cg_fused_dot", int(os.environ["MI_CG_FUSED_DOT"]))
         G.set_tuning("precond", 1 if args.precond == "mg" else 0)

@@ -230,8 +230,11 @@ namespace mi_detail
   {
     // product with the unassembled element tangents: the smoother's fine-level products (and, for tests, any plain
     // product under "spmv_variant" 4); not for fused epilogues, fused dot products or the linear model's operators
-    if (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals &&
-        (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4))
+    // (opt-in A/B "cg_operator" 1: the CG's own product as well, with p.q by a separate reduction -- then the
+    // sliced-ELL copy of the tangent is never made)
+    const bool ebe_for_cg = dotv && c->cg_operator == 1 && c->d_ke && c->ke_valid && !c->active_sell_vals && !cheb;
+    if (ebe_for_cg || (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals &&
+                       (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4)))
       {
         // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
         // by layer: the whole product waits for the ghost planes of x (part 2 = after the halo exchange); the rows of
@@ -250,6 +253,8 @@ namespace mi_detail
             mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], cnt, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
                                 t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
           }
+        if (ebe_for_cg) // partials of dotv . y over the owned dofs (the early-exit flag is honoured by their consumer)
+          mi::launch_dot_partials(dotv + c->own0, y + c->own0, c->own_n, partials, c->grid_vec, c->stream);
         return;
       }
     if (c->spmv_variant == 3 || c->spmv_variant == 4 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
@@ -517,7 +522,8 @@ namespace mi_detail
     mi_ctx    *c0   = T.members[0];
     const bool dist = T.size > 1;
     for (mi_ctx *m : T.members) // outside the timed SpMV launches
-      refresh_sell(m);
+      if (!(m->cg_operator == 1 && m->d_ke && m->ke_valid && !m->active_sell_vals))
+        refresh_sell(m);
     const int  tt   = tic(c0, MI_T_CG_TOTAL);
     std::vector<mi::CgParams> cgs;
     for (mi_ctx *m : T.members)
@@ -535,7 +541,7 @@ namespace mi_detail
         cg.flags    = m->d_flags;
         cg.n        = m->own_n;
         cg.npart    = m->grid_vec;
-        cg.npart_pq = m->cg_fused_dot ? m->grid_spmv : m->grid_vec;
+        cg.npart_pq = (m->cg_fused_dot && !(m->cg_operator == 1 && m->d_ke && m->ke_valid && !m->active_sell_vals)) ? m->grid_spmv : m->grid_vec;
         cg.totals   = dist ? m->d_sc + SC_TOT : nullptr;
         cgs.push_back(cg);
       }
@@ -660,7 +666,8 @@ namespace mi_detail
             // the product the roofline figure is quoted on: when it is ONE launch of the production kernel its events
             // come from the dispatch itself (kernel start / end, as rocprofv3 reports them)
             const bool one_launch = !dist && c0->profiling && c0->spmv_variant == 3 && c0->sell_icol && c0->sell_unroll == 5 &&
-                                    !c0->active_sell_vals && c0->mesh.sell_nslices_interior == c0->mesh.sell_nslices;
+                                    !c0->active_sell_vals && c0->mesh.sell_nslices_interior == c0->mesh.sell_nslices &&
+                                    !(c0->cg_operator == 1 && c0->d_ke && c0->ke_valid);
             t = tic(c0, MI_T_SPMV, one_launch);
             if (one_launch && t >= 0)
               mi::set_next_sell_launch_events(c0->stamps[size_t(t)].a, c0->stamps[size_t(t)].b);
@@ -1722,6 +1729,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_fused_dot = value;
       else if (k == "cg_warm_start" && (value == 0 || value == 1))
         m->cg_warm_start = value;
+      else if (k == "cg_operator" && (value == 0 || value == 1))
+        m->cg_operator = value;
       else if (k == "mg_fuse" && value >= 0 && value <= 2)
         {
           const int rc = mg_set_fuse(m, value);

@@ -98,6 +98,8 @@ struct mi_ctx
   uint32_t *d_node_first = nullptr; // per cell: bit a = first touch of local node a (see HostMesh::node_first)
   bool      ke_valid = false; // d_ke belongs to the current tangent
   int64_t   ebe_products = 0; // element-tangent products so far (profiling samples every 6th)
+  int       cg_operator = 0;   // A/B: 1 = the CG's own product on the element tangents too (no sliced-ELL copy); default 0:
+                               // the assembled matrix, the kernel north_star names
   int       cg_warm_start = 0; // 1: later solves of a step start from the previous Newton update, as the reference's do
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
   int       ebe = 1;          // tuning "smoother_operator": 1 element tangents where available, 0 assembled matrix

@@ -239,6 +239,26 @@ def test_smoother_operator_choice_only_changes_the_preconditioner():
     assert _relmax(res[1][1], res[0][1]) < 1e-8
 
 
+def test_cg_operator_choice_gives_the_same_solve():
+    """A/B switch "cg_operator": the CG's own product on the element tangents (p.q by a separate reduction, no sliced-ELL
+    copy) instead of the assembled matrix -- same iteration count (+-1), same solution"""
+    G = M.Context(dim=3, degree=2, reps=(24, 24, 24))
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    res = {}
+    for op in (0, 1):
+        G.set_tuning("cg_operator", op)
+        G.set(M.V_NEWTON, np.zeros(G.n))
+        G.newton_begin_step()
+        G.update_acceleration()
+        G.assemble()
+        rc, its, r = G.cg_solve(rel_tol=1e-10)
+        assert rc == 0
+        res[op] = (its, G.get(M.V_NEWTON))
+    assert abs(res[0][0] - res[1][0]) <= 1 and _relmax(res[1][1], res[0][1]) < 1e-8
+    rc, info = G.newmark_step(tol_lin=1e-8)  # and through a whole step
+    assert rc == 0 and info.converged == 1
+
+
 def test_spmv_kernel_variants_agree():
     """sliced-ELL (production) and block-CSR (cross-check) kernels on the same matrix, several grids"""
     P, G = _pair(3, 2, (5, 4, 3), perturb_amp=0.05, seed=11)
