@@ -312,7 +312,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, cells, steps, warmup, uid_, cg_start=None):
+    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None):
         """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
         nz = cells * parts if scaling == "weak" else cells
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
@@ -320,7 +320,7 @@ def main():
                       world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
         G.set_tuning("smoother_operator", 1 if args.smoother_operator == "element" else 0)
         G.set_tuning("cg_warm_start", 1 if (cg_start or args.cg_start) == "previous-update" else 0)
-        G.set_tuning("cg_operator", 1 if args.cg_operator == "element" else 0)
+        G.set_tuning("cg_operator", 1 if (cg_operator or args.cg_operator) == "element" else 0)
         if os.environ.get("MI_CG_FUSED_DOT"):
             G.set_tuning("cg_fused_dot", int(os.environ["MI_CG_FUSED_DOT"]))
         G.set_tuning("precond", 1 if args.precond == "mg" else 0)
@@ -527,6 +527,14 @@ def main():
             "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"], "cg_iterations_per_step": S["cg_its"] / 3,
             "cg_iterations_last_step": S["lin_its_last"], "steps": 3, "warmup": 1}
         del S
+        if args.cg_operator == "assembled" and n >= 24:
+            # opt-in A/B beside the headline: the CG's own product on the element tangents too (no sliced-ELL copy);
+            # not the default because north_star names the product on the assembled matrix
+            S = measure(args.scaling, n, 3, 1, None, cg_operator="element")
+            out["config"]["with_cg_operator_element"] = {
+                "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"],
+                "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1}
+            del S
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         # the GPU on the CPU sample's own configuration, beside it
         its_a, its_b = (int(x) for x in args.cpu_its.split(","))
