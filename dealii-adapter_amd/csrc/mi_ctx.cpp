@@ -145,6 +145,7 @@ namespace mi_detail
       p.body[i] = c->mat.body_force[i];
     p.variant = c->asm_variant;
     p.ke      = c->d_ke;
+    p.qrec    = c->d_qrec;
     return p;
   }
 
@@ -223,6 +224,17 @@ namespace mi_detail
     c->sell_stale = false;
   }
 
+  // which unassembled form of the current tangent the element products use: 2 quadrature-point records (mf_spmv),
+  // 1 element tangents (ebe_spmv), 0 none
+  int element_form(const mi_ctx *c)
+  {
+    if (!c->ke_valid)
+      return 0;
+    if (c->d_qrec && (c->ebe == 2 || !c->d_ke))
+      return 2;
+    return c->d_ke ? 1 : 0;
+  }
+
   // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
   // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
@@ -232,8 +244,9 @@ namespace mi_detail
     // product under "spmv_variant" 4); not for fused epilogues, fused dot products or the linear model's operators
     // (opt-in A/B "cg_operator" 1: the CG's own product as well, with p.q by a separate reduction -- then the
     // sliced-ELL copy of the tangent is never made)
-    const bool ebe_for_cg = dotv && c->cg_operator == 1 && c->d_ke && c->ke_valid && !c->active_sell_vals && !cheb;
-    if (ebe_for_cg || (c->d_ke && c->ke_valid && !cheb && !dotv && !c->active_sell_vals &&
+    const int  kind       = element_form(c);
+    const bool ebe_for_cg = dotv && c->cg_operator == 1 && kind && !c->active_sell_vals && !cheb;
+    if (ebe_for_cg || (kind && !cheb && !dotv && !c->active_sell_vals &&
                        (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4)))
       {
         // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
@@ -242,6 +255,8 @@ namespace mi_detail
         if (part == 1)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
+        mi::MfParams  f{c->d_qrec, c->d_conn, c->d_node_first, c->d_cmask, c->d_vals, c->d_diagpos, c->d_tab, x, y,
+                       c->alpha[1] * c->mat.rho};
         // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
         // profiler reports them), class MI_T_EBE_LAUNCH
         mi_ctx    *c0     = c->team->members[0];
@@ -250,8 +265,12 @@ namespace mi_detail
           {
             const int32_t cnt = int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]);
             const int     t   = (sample && cnt > 0) ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
-            mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], cnt, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
-                                t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+            if (kind == 2)
+              mi::launch_mf_spmv(f, c->mesh.colour_begin[col], cnt, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                 t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+            else
+              mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], cnt, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                  t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
           }
         if (ebe_for_cg) // partials of dotv . y over the owned dofs (the early-exit flag is honoured by their consumer)
           mi::launch_dot_partials(dotv + c->own0, y + c->own0, c->own_n, partials, c->grid_vec, c->stream);
@@ -465,7 +484,8 @@ namespace mi_detail
         HIPCHK(c, hipGetLastError());
         return MI_OK;
       }
-    c->ke_valid = c->d_ke && !(c->dim == 3 && c->degree == 2 && c->asm_variant != 0 && c->asm_variant != 1 && c->asm_variant != 2);
+    c->ke_valid = (c->d_ke || c->d_qrec) &&
+                  !(c->dim == 3 && c->degree == 2 && c->asm_variant != 0 && c->asm_variant != 1 && c->asm_variant != 2);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -484,10 +504,13 @@ namespace mi_detail
   {
     const bool want = c->ebe && c->dim == 3 && c->degree == 2 && c->precond == 1 && c->mg &&
                       c->mesh.nnodes > 100000; // below that the smoother runs fused on the assembled matrix
-    if (want && !c->d_ke)
+    if (want && (c->ebe == 2 ? !c->d_qrec : !c->d_ke))
       {
-        HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
-        const int rc = upload(c, &c->d_node_first, c->mesh.node_first);
+        if (c->ebe == 2)
+          HIPCHK(c, hipMalloc((void **)&c->d_qrec, size_t(c->mesh.ncells) * mi::MF_NREC * 64 * sizeof(double)));
+        else
+          HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+        const int rc = c->d_node_first ? MI_OK : upload(c, &c->d_node_first, c->mesh.node_first);
         if (rc)
           return rc;
         c->ke_valid = false;
@@ -522,7 +545,7 @@ namespace mi_detail
     mi_ctx    *c0   = T.members[0];
     const bool dist = T.size > 1;
     for (mi_ctx *m : T.members) // outside the timed SpMV launches
-      if (!(m->cg_operator == 1 && m->d_ke && m->ke_valid && !m->active_sell_vals))
+      if (!(m->cg_operator == 1 && element_form(m) && !m->active_sell_vals))
         refresh_sell(m);
     const int  tt   = tic(c0, MI_T_CG_TOTAL);
     std::vector<mi::CgParams> cgs;
@@ -541,7 +564,7 @@ namespace mi_detail
         cg.flags    = m->d_flags;
         cg.n        = m->own_n;
         cg.npart    = m->grid_vec;
-        cg.npart_pq = (m->cg_fused_dot && !(m->cg_operator == 1 && m->d_ke && m->ke_valid && !m->active_sell_vals)) ? m->grid_spmv : m->grid_vec;
+        cg.npart_pq = (m->cg_fused_dot && !(m->cg_operator == 1 && element_form(m) && !m->active_sell_vals)) ? m->grid_spmv : m->grid_vec;
         cg.totals   = dist ? m->d_sc + SC_TOT : nullptr;
         cgs.push_back(cg);
       }
@@ -667,7 +690,7 @@ namespace mi_detail
             // come from the dispatch itself (kernel start / end, as rocprofv3 reports them)
             const bool one_launch = !dist && c0->profiling && c0->spmv_variant == 3 && c0->sell_icol && c0->sell_unroll == 5 &&
                                     !c0->active_sell_vals && c0->mesh.sell_nslices_interior == c0->mesh.sell_nslices &&
-                                    !(c0->cg_operator == 1 && c0->d_ke && c0->ke_valid);
+                                    !(c0->cg_operator == 1 && element_form(c0));
             t = tic(c0, MI_T_SPMV, one_launch);
             if (one_launch && t >= 0)
               mi::set_next_sell_launch_events(c0->stamps[size_t(t)].a, c0->stamps[size_t(t)].b);
@@ -767,7 +790,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1079,7 +1102,7 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   for (mi_ctx *m : T->members)
     {
       if (const char *e = getenv("MI_EBE"))
-        m->ebe = atoi(e) != 0;
+        m->ebe = std::max(0, std::min(2, atoi(e)));
       const int rc = ensure_element_tangents(m);
       if (rc != MI_OK)
         return bail(rc, m->err);
@@ -1688,19 +1711,31 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
     {
       if (k == "spmv_variant" && (value == 1 || value == 3 || value == 4 || (value >= 11 && value <= 14)))
         m->spmv_variant = value;
-      else if (k == "smoother_operator" && (value == 0 || value == 1))
-        m->ebe = value;
-      else if (k == "element_tangents" && value == 1) // tests: keep them whatever the size / preconditioner
+      else if (k == "smoother_operator" && value >= 0 && value <= 2)
         {
+          m->ebe = value;
+          if (value && m->precond == 1)
+            {
+              const int rc = ensure_element_tangents(m);
+              if (rc)
+                return rc;
+            }
+        }
+      else if (k == "element_tangents" && (value == 1 || value == 2)) // tests: keep them (1) / the quadrature-point
+        {                                                                // records (2) whatever the size / preconditioner
           if (m->dim != 3 || m->degree != 2)
             return fail(c, MI_EINVAL, "element tangents exist for 3D Q2 meshes only");
-          if (!m->d_ke)
+          if (value == 1 && !m->d_ke)
+            HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
+          if (value == 2 && !m->d_qrec)
+            HIPCHK(m, hipMalloc((void **)&m->d_qrec, size_t(m->mesh.ncells) * mi::MF_NREC * 64 * sizeof(double)));
+          if (!m->d_node_first)
             {
-              HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
               const int rc = upload(m, &m->d_node_first, m->mesh.node_first);
               if (rc)
                 return rc;
             }
+          m->ebe      = value;
           m->ke_valid = false;
         }
       else if (k == "xcd_remap" && (value == 0 || value == 1))
@@ -1772,7 +1807,9 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
   if (!value)
     return fail(c, MI_EINVAL, "null argument");
   if (k == "smoother_operator_active") // 1: the smoother's fine-level products run on the element tangents
-    *value = (m->d_ke && m->ebe && m->precond == 1 && m->precond_storage == 64) ? 1 : 0;
+    *value = (m->ebe && m->precond == 1 && m->precond_storage == 64 && ((m->ebe == 2 && m->d_qrec) || m->d_ke)) ?
+               ((m->d_qrec && (m->ebe == 2 || !m->d_ke)) ? 2 : 1) :
+               0;
   else if (k == "precond")
     *value = m->precond;
   else if (k == "spmv_variant")
@@ -1808,7 +1845,10 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
   HIPCHK(c, hipEventCreate(&b));
   auto once = [&]() {
     for (mi_ctx *m : c->team->members)
-      enqueue_spmv(m, m->work(W_P), m->work(W_Q), m->work(W_P), m->part(2), nullptr);
+      {
+        const bool plain = m->spmv_variant == 4; // the unassembled forms carry no fused dot product
+        enqueue_spmv(m, m->work(W_P), m->work(W_Q), plain ? nullptr : m->work(W_P), plain ? nullptr : m->part(2), nullptr);
+      }
   };
   once(); // warm-up
   HIPCHK(c, hipEventRecord(a, c->stream));

@@ -96,13 +96,15 @@ struct mi_ctx
   bool      want_dinv_blk = false;
   double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
   uint32_t *d_node_first = nullptr; // per cell: bit a = first touch of local node a (see HostMesh::node_first)
-  bool      ke_valid = false; // d_ke belongs to the current tangent
+  double   *d_qrec = nullptr; // quadrature-point records of the last tangent assembly (3D Q2): the matrix-free form of the smoother's operator
+  bool      ke_valid = false; // d_ke / d_qrec belong to the current tangent
   int64_t   ebe_products = 0; // element-tangent products so far (profiling samples every 6th)
   int       cg_operator = 0;   // A/B: 1 = the CG's own product on the element tangents too (no sliced-ELL copy); default 0:
                                // the assembled matrix, the kernel north_star names
   int       cg_warm_start = 0; // 1: later solves of a step start from the previous Newton update, as the reference's do
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
-  int       ebe = 1;          // tuning "smoother_operator": 1 element tangents where available, 0 assembled matrix
+  int       ebe = 2;          // tuning "smoother_operator": 2 matrix-free from the quadrature-point records, 1 element
+                              // tangents (both where available), 0 assembled matrix
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
   int       precond_storage = 64;
   int       small_cg = 1; // matrices up to SMALL_CG_MAX_MATRIX_BYTES on one slab: whole Jacobi-PCG in one launch

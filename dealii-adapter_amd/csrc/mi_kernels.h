@@ -23,6 +23,7 @@ namespace mi
     int32_t         cell_count;
     int32_t         variant; // kernel variant for A/B timing
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
+    double         *qrec;   // optional (3D Q2): the quadrature-point records the tangent is made of, [cell][MF_NREC][64] (see mf_spmv)
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
   };
@@ -35,6 +36,22 @@ namespace mi
     const uint32_t *first; // [ncells] bit a: first cell (in processing order) that contains its local node a -> store
     const double   *x;
     double         *y;     // complete after all colours (no zero fill needed: first touches store)
+  };
+
+  // matrix-free product from the quadrature-point records of the last tangent assembly (see mf_spmv in mi_kernels.hip)
+  constexpr int MF_NREC = 18; // per point: M[9] = Jinv Finv, tau[6] (xx yy zz xy xz yz), JxW, JxW c_II, c_S / 2
+  struct MfParams
+  {
+    const double   *qrec;    // [ncells][MF_NREC][64]
+    const int32_t  *conn;    // [ncells][27] colour-sorted
+    const uint32_t *first;   // as EbeParams
+    const uint8_t  *cmask;   // [nnodes]
+    const double   *vals;    // assembled tangent (block-CSR): diagonal entries of constrained dofs
+    const int32_t  *diagpos; // [nnodes] block index of (node,node)
+    const double   *tab1d;   // N1[4][3], dN1[4][3] (the assembly's tables)
+    const double   *x;
+    double         *y;
+    double          mass;    // alpha_1 rho
   };
 
   struct SpmvParams
@@ -138,6 +155,8 @@ namespace mi
   // ev_start / ev_stop (optional): bracket exactly this launch (dispatch-level events, profiling)
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+  void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
+                      hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s);

@@ -398,6 +398,17 @@ namespace mi
 #pragma unroll
             for (int i = 0; i < 3; ++i)
               r[Q_FACC + i] = prm.rho * w * (acc[i] - prm.body[i]);
+            if constexpr (DIM == 3 && P == 2 && ABL == 0)
+              if (prm.qrec) // what the tangent is made of at this point, for the matrix-free product (mf_spmv)
+                {
+                  double *__restrict__ g = prm.qrec + cell * int64_t(MF_NREC * 64) + q;
+#pragma unroll
+                  for (int k = 0; k < 15; ++k)
+                    g[k * 64] = r[k]; // Q_M (9), Q_TAU (6)
+                  g[15 * 64] = w;
+                  g[16 * 64] = w * cII;
+                  g[17 * 64] = 0.5 * cS;
+                }
           }
       }
     __syncthreads();
@@ -1516,6 +1527,249 @@ namespace mi
       }
   }
 
+  // ------------------------------------------------------------------ matrix-free product from quadrature-point records
+  // y += sum over the cells of one colour of P_e^T K_e P_e x WITHOUT K_e: the assembly leaves, per cell and quadrature
+  // point, the 18 numbers the element tangent is made of (M = Jinv Finv, tau, JxW, JxW c_II, c_S/2: MF_NREC x 64 doubles
+  // = 9.2 kB per 3D Q2 cell against 27.2 kB for the symmetric element tangent and 37.6 kB of assembled rows), and the
+  // product evaluates  y_a = sum_q Q(q) grad_xi N_a(q)  with
+  //   H = sum_b x_b (x) grad_xi N_b,  h = H M,  S = (c_II tr h - 2/3 tau_iso:h) I - 2/3 tr h tau_iso + c_S/2 (h + h^T) + h tau,
+  //   Q = JxW S M^T  (+ the mass term alpha_1 rho JxW N_a N_b),
+  // which is K_e x_e term by term (assemble_cells' node-pair form summed over b; tools/proto/mf_product.py checks the
+  // algebra against the independent mirror).  Gradients and the integration are contracted one lattice direction at a
+  // time (3 nodes <-> 4 points); in every pass a lane owns one line and produces ALL outputs along the contracted
+  // direction, so the 1D tables are scalar operands and every intermediate is written to LDS once.
+  // One wavefront = one cell = its 64 quadrature points.  Update of y as in ebe_spmv (colours, first touch stores).
+  // Constrained dofs: x is masked on the way in; their rows receive diag(K) x from the assembled tangent at the first touch
+  // (|K_e(i,i)| summed over the cells is what the assembly put there), nothing otherwise.
+  __global__ __launch_bounds__(64) void mf_spmv(MfParams prm, int64_t cell0)
+  {
+    constexpr int NPC = 27;
+    __shared__ double s0[768];
+    __shared__ double s1[432];
+    __shared__ int    s_conn[NPC], s_cm[NPC];
+    const int     lane = threadIdx.x;
+    const int64_t cell = cell0 + blockIdx.x;
+    // the cell's records: issued first, consumed after the gradient passes
+    double rec[MF_NREC];
+    {
+      const double *__restrict__ rp = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
+#pragma unroll
+      for (int f = 0; f < MF_NREC; ++f)
+        rec[f] = __builtin_nontemporal_load(&rp[f * 64]);
+    }
+    // 1D tables: S[q][a] = N_a(x_q), D[q][a] = N_a'(x_q) (uniform -> scalar registers)
+    double S[4][3], D[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        {
+          S[q][a] = prm.tab1d[q * 3 + a];
+          D[q][a] = prm.tab1d[12 + q * 3 + a];
+        }
+    const int qz = lane >> 4, q16 = lane & 15;
+    double    Sz[3], Dz[3]; // this lane's rows of the tables for the last gradient pass
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      {
+        Sz[k] = prm.tab1d[qz * 3 + k];
+        Dz[k] = prm.tab1d[12 + qz * 3 + k];
+      }
+    // ---- gather x (constrained entries masked): X[c][a] at c*27 + a, a = (k*3 + j)*3 + i
+    if (lane < NPC)
+      {
+        const int32_t node = prm.conn[cell * NPC + lane];
+        const int     cm   = prm.cmask[node];
+        s_conn[lane]       = node;
+        s_cm[lane]         = cm;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          {
+            const double xv    = prm.x[int64_t(node) * 3 + c];
+            s0[c * NPC + lane] = ((cm >> c) & 1) ? 0.0 : xv;
+          }
+      }
+    __syncthreads();
+    // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at 81 / 189 + qx*27 + lane
+    if (lane < 27)
+      {
+        const double x0 = s0[lane * 3], x1 = s0[lane * 3 + 1], x2 = s0[lane * 3 + 2];
+#pragma unroll
+        for (int qx = 0; qx < 4; ++qx)
+          {
+            s0[81 + qx * 27 + lane]  = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
+            s0[189 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
+          }
+      }
+    __syncthreads();
+    // ---- E2: contract j.  lane = qx*9 + (c*3+k); B_DS / B_SD / B_SS [c*3+k][qy][qx] at 336 + {0,144,288}
+    if (lane < 36)
+      {
+        const int    qx = lane / 9, ck = lane - 9 * qx;
+        const double as0 = s0[81 + 3 * lane], as1 = s0[81 + 3 * lane + 1], as2 = s0[81 + 3 * lane + 2];
+        const double ad0 = s0[189 + 3 * lane], ad1 = s0[189 + 3 * lane + 1], ad2 = s0[189 + 3 * lane + 2];
+#pragma unroll
+        for (int qy = 0; qy < 4; ++qy)
+          {
+            const int o     = 336 + ck * 16 + qy * 4 + qx;
+            s0[o]           = S[qy][0] * ad0 + S[qy][1] * ad1 + S[qy][2] * ad2; // d/dx
+            s0[o + 144]     = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2; // d/dy
+            s0[o + 288]     = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2; // value / d/dz
+          }
+      }
+    __syncthreads();
+    // ---- E3: contract k.  lane = quadrature point; H[c][l] = d x_c / d xi_l, V[c] = x_c
+    double H[3][3], V[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      {
+        H[c][0] = H[c][1] = H[c][2] = V[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          {
+            const int    o   = 336 + (c * 3 + k) * 16 + q16;
+            const double bds = s0[o], bsd = s0[o + 144], bss = s0[o + 288];
+            H[c][0]          = fma(Sz[k], bds, H[c][0]);
+            H[c][1]          = fma(Sz[k], bsd, H[c][1]);
+            H[c][2]          = fma(Dz[k], bss, H[c][2]);
+            V[c]             = fma(Sz[k], bss, V[c]);
+          }
+      }
+    __syncthreads(); // s0 is rewritten below
+    // ---- quadrature point: Q = JxW S M^T
+    {
+      const double *M = rec, *tau = rec + 9;
+      const double  w = rec[15], wcII = rec[16], cs2 = rec[17];
+      double        h[3][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          h[j][k] = H[j][0] * M[k] + H[j][1] * M[3 + k] + H[j][2] * M[6 + k];
+      const double pv  = (tau[0] + tau[1] + tau[2]) * (1.0 / 3.0); // tau_iso = dev tau
+      const double ti0 = tau[0] - pv, ti1 = tau[1] - pv, ti2 = tau[2] - pv;
+      const double trh = h[0][0] + h[1][1] + h[2][2];
+      const double th  = ti0 * h[0][0] + ti1 * h[1][1] + ti2 * h[2][2] + tau[3] * (h[0][1] + h[1][0]) +
+                        tau[4] * (h[0][2] + h[2][0]) + tau[5] * (h[1][2] + h[2][1]);
+      const double aI = wcII * trh - (2.0 / 3.0) * w * th;
+      const double m3 = -(2.0 / 3.0) * trh;
+      const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
+      const double Ti[3][3] = {{ti0, tau[3], tau[4]}, {tau[3], ti1, tau[5]}, {tau[4], tau[5], ti2}};
+      double       Sm[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          {
+            double v = m3 * Ti[i][j] + cs2 * (h[i][j] + h[j][i]) + h[i][0] * T[0][j] + h[i][1] * T[1][j] + h[i][2] * T[2][j];
+            Sm[i][j] = w * v + (i == j ? aI : 0.0);
+          }
+      const double wm = prm.mass * w;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        {
+#pragma unroll
+          for (int l = 0; l < 3; ++l)
+            s0[(i * 4 + l) * 64 + lane] = Sm[i][0] * M[l * 3] + Sm[i][1] * M[l * 3 + 1] + Sm[i][2] * M[l * 3 + 2];
+          s0[(i * 4 + 3) * 64 + lane] = wm * V[i];
+        }
+    }
+    __syncthreads();
+    // ---- I3: contract qz.  lane = c*16 + (qy*4+qx); C_DS / C_SD / C_SS [c*3+k][qy][qx] in s1 at {0,144,288}
+    if (lane < 48)
+      {
+        const int c = lane >> 4;
+        double    v[4][4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int z = 0; z < 4; ++z)
+            v[d][z] = s0[(c * 4 + d) * 64 + z * 16 + q16];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          {
+            double cds = 0.0, csd = 0.0, css = 0.0;
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+              {
+                cds = fma(S[z][k], v[0][z], cds);
+                csd = fma(S[z][k], v[1][z], csd);
+                css = fma(D[z][k], v[2][z], css);
+                css = fma(S[z][k], v[3][z], css);
+              }
+            const int o = (c * 3 + k) * 16 + q16;
+            s1[o]       = cds;
+            s1[o + 144] = csd;
+            s1[o + 288] = css;
+          }
+      }
+    __syncthreads();
+    // ---- I2: contract qy.  lane = qx*9 + (c*3+k); E_D / E_S [qx][c,k,j] in s0 at {0,108} + qx*27 + (c*3+k)*3 + j
+    if (lane < 36)
+      {
+        const int qx = lane / 9, ck = lane - 9 * qx;
+        double    cds[4], csd[4], css[4];
+#pragma unroll
+        for (int qy = 0; qy < 4; ++qy)
+          {
+            const int o = ck * 16 + qy * 4 + qx;
+            cds[qy]     = s1[o];
+            csd[qy]     = s1[o + 144];
+            css[qy]     = s1[o + 288];
+          }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          {
+            double ed = 0.0, es = 0.0;
+#pragma unroll
+            for (int qy = 0; qy < 4; ++qy)
+              {
+                ed = fma(S[qy][j], cds[qy], ed);
+                es = fma(D[qy][j], csd[qy], es);
+                es = fma(S[qy][j], css[qy], es);
+              }
+            s0[3 * lane + j]       = ed;
+            s0[108 + 3 * lane + j] = es;
+          }
+      }
+    __syncthreads();
+    // ---- I1: contract qx and update y.  lane = line (c,k,j)
+    if (lane < 27)
+      {
+        double ed[4], es[4];
+#pragma unroll
+        for (int qx = 0; qx < 4; ++qx)
+          {
+            ed[qx] = s0[qx * 27 + lane];
+            es[qx] = s0[108 + qx * 27 + lane];
+          }
+        const int      c = lane / 9, kj = lane - 9 * c;
+        const uint32_t fb = prm.first[cell];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          {
+            double yv = 0.0;
+#pragma unroll
+            for (int qx = 0; qx < 4; ++qx)
+              {
+                yv = fma(D[qx][i], ed[qx], yv);
+                yv = fma(S[qx][i], es[qx], yv);
+              }
+            const int     a     = kj * 3 + i;
+            const int32_t node  = s_conn[a];
+            const bool    first = (fb >> a) & 1u;
+            const int64_t idx   = int64_t(node) * 3 + c;
+            if ((s_cm[a] >> c) & 1)
+              {
+                if (first)
+                  prm.y[idx] = prm.vals[int64_t(prm.diagpos[node]) * 9 + c * 4] * prm.x[idx];
+              }
+            else
+              prm.y[idx] = first ? yv : prm.y[idx] + yv;
+          }
+      }
+  }
+
   // block-CSR -> sliced-ELL copy of the values (after every assembly); one wavefront per slice
   template <int D>
   __global__ __launch_bounds__(256) void bsr_to_sell(SellParams prm, const int32_t *__restrict__ rowptr,
@@ -2629,6 +2883,17 @@ namespace mi
     else
       dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
   }
+  void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,
+                      hipEvent_t ev_stop)
+  {
+    if (cell_count <= 0)
+      return;
+    if (ev_start || ev_stop)
+      hipExtLaunchKernelGGL(mf_spmv, dim3(cell_count), dim3(64), 0, s, ev_start, ev_stop, 0, p, cell_begin);
+    else
+      hipLaunchKernelGGL(mf_spmv, dim3(cell_count), dim3(64), 0, s, p, cell_begin);
+  }
+
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,
                        hipEvent_t ev_stop)
   {

@@ -249,12 +249,13 @@ def test_global_array_views_roundtrip(dim, p, reps, slabs):
         assert np.array_equal(G.get(k), before[k])
 
 
-def test_element_tangent_product_on_slabs():
+@pytest.mark.parametrize("form", [1, 2])
+def test_element_tangent_product_on_slabs(form):
     """the smoother's operator on a decomposed mesh: every slab multiplies with the element tangents of ALL its local
     cells (own layers + ghost layer) after the halo exchange; the owned rows are complete and equal the assembled
     product"""
     P, G = _setup(3, 2, (3, 3, 7), 3, seed=5)
-    G.set_tuning("element_tangents", 1)
+    G.set_tuning("element_tangents", form)  # 1 element tangents, 2 quadrature-point records (matrix-free product)
     _randomise(P, G, seed=6)
     P.update_acceleration()
     P.assemble()
@@ -274,12 +275,12 @@ def test_multigrid_smoother_on_element_tangents_is_slab_invariant(slabs):
     """multigrid-PCG with the smoother forced onto the element tangents (unfused smoother, as on big meshes) on 1, 2
     and 3 slabs: same iteration count (+-1) and the same solution as with the assembled smoother operator"""
     res = {}
-    for op in (0, 1):
+    for op in (0, 1, 2):
         P, G = _setup(3, 2, (5, 4, 9), slabs, seed=3, perturb_amp=0.0)
         G.set_tuning("precond", 1)
         G.set_tuning("mg_fuse", 0)
         if op:
-            G.set_tuning("element_tangents", 1)
+            G.set_tuning("element_tangents", op)
         G.set_tuning("smoother_operator", op)
         _randomise(P, G, seed=4)
         G.update_acceleration()
@@ -288,5 +289,6 @@ def test_multigrid_smoother_on_element_tangents_is_slab_invariant(slabs):
         assert rc == 0
         res[op] = (its, G.get(M.V_NEWTON))
         assert G.get_tuning("smoother_operator_active") == op
-    assert abs(res[0][0] - res[1][0]) <= 1 and 0 < res[1][0] < 60
-    assert _relmax(res[1][1], res[0][1]) < 1e-8
+    for op in (1, 2):
+        assert abs(res[0][0] - res[op][0]) <= 1 and 0 < res[op][0] < 60
+        assert _relmax(res[op][1], res[0][1]) < 1e-8

@@ -190,13 +190,16 @@ def test_element_kernel_variants_agree():
         assert abs(rn - ref[2]) / ref[2] < 1e-13
 
 
-def test_element_tangent_product_matches_the_assembled_matrix():
-    """the multigrid smoother's operator on big undecomposed 3D Q2 meshes: the masked element tangents stored by the
-    assembly (lower-triangle node-pair blocks) multiplied cell by cell give the same product as the assembled matrix,
-    including constrained rows/columns and their diagonal rule; deterministic; follows every new tangent"""
+@pytest.mark.parametrize("form", [1, 2])
+def test_element_tangent_product_matches_the_assembled_matrix(form):
+    """the multigrid smoother's operator on big undecomposed 3D Q2 meshes, in both unassembled forms: (1) the masked
+    element tangents stored by the assembly (lower-triangle node-pair blocks) multiplied cell by cell, (2) the
+    matrix-free product from the quadrature-point records of the assembly (sum factorisation) -- the same product as
+    the assembled matrix, including constrained rows/columns and their diagonal rule; deterministic; follows every
+    new tangent"""
     roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
     P, G = _pair(3, 2, (4, 3, 5), perturb_amp=0.05, seed=21, roles=roles)
-    G.set_tuning("element_tangents", 1)
+    G.set_tuning("element_tangents", form)
     _randomise_state(P, G, seed=22)
     P.update_acceleration()
     P.assemble()
@@ -224,9 +227,9 @@ def test_smoother_operator_choice_only_changes_the_preconditioner():
     rounding, so the same iteration counts and the same converged solution"""
     G = M.Context(dim=3, degree=2, reps=(24, 24, 24))  # 352,947 dofs, 117,649 nodes: above the 100k-node switch
     G.set_interface_traction((0.0, -2e3, 0.0))
-    assert G.get_tuning("smoother_operator_active") == 1
+    assert G.get_tuning("smoother_operator_active") == 2  # default: matrix-free from the quadrature-point records
     res = {}
-    for op in (1, 0):
+    for op in (2, 1, 0):
         G.set_tuning("smoother_operator", op)
         G.set(M.V_NEWTON, np.zeros(G.n))
         G.newton_begin_step()
@@ -235,15 +238,20 @@ def test_smoother_operator_choice_only_changes_the_preconditioner():
         rc, its, r = G.cg_solve(rel_tol=1e-10)
         assert rc == 0
         res[op] = (its, G.get(M.V_NEWTON))
-    assert abs(res[0][0] - res[1][0]) <= 1 and 0 < res[1][0] < 40
-    assert _relmax(res[1][1], res[0][1]) < 1e-8
+        assert G.get_tuning("smoother_operator_active") == op
+    for op in (1, 2):
+        assert abs(res[0][0] - res[op][0]) <= 1 and 0 < res[op][0] < 40
+        assert _relmax(res[op][1], res[0][1]) < 1e-8
 
 
-def test_cg_operator_choice_gives_the_same_solve():
-    """A/B switch "cg_operator": the CG's own product on the element tangents (p.q by a separate reduction, no sliced-ELL
-    copy) instead of the assembled matrix -- same iteration count (+-1), same solution"""
+@pytest.mark.parametrize("form", [1, 2])
+def test_cg_operator_choice_gives_the_same_solve(form):
+    """A/B switch "cg_operator": the CG's own product on the unassembled form the smoother uses (element tangents or
+    quadrature-point records; p.q by a separate reduction, no sliced-ELL copy) instead of the assembled matrix -- same
+    iteration count (+-1), same solution"""
     G = M.Context(dim=3, degree=2, reps=(24, 24, 24))
     G.set_interface_traction((0.0, -2e3, 0.0))
+    G.set_tuning("smoother_operator", form)
     res = {}
     for op in (0, 1):
         G.set_tuning("cg_operator", op)

@@ -167,8 +167,8 @@ def test_headline_size_invariants():
     x, y = rng.standard_normal(G.n), rng.standard_normal(G.n)
     Kx, Ky = G.spmv(x), G.spmv(y)
     assert abs(y @ Kx - x @ Ky) / abs(y @ Kx) < 1e-11
-    # the smoother's operator (unassembled element tangents, active at this size) is the assembled matrix
-    assert G.get_tuning("smoother_operator_active") == 1
+    # the smoother's operator (matrix-free from the quadrature-point records, active at this size) is the assembled matrix
+    assert G.get_tuning("smoother_operator_active") == 2
     G.set_tuning("spmv_variant", 4)
     assert np.abs(G.spmv(x) - Kx).max() / np.abs(Kx).max() < 1e-13
     G.set_tuning("spmv_variant", 3)
