@@ -239,7 +239,7 @@ def main():
     ap.add_argument("--precond-storage", choices=["f64", "f32"], default="f64",
                     help="f32: the multigrid smoother multiplies with an fp32-rounded copy of the level matrices (the CG's "
                          "own product, residuals, vectors and all arithmetic stay fp64); opt-in, not the headline setting")
-    ap.add_argument("--smoother-operator", choices=["element", "assembled"], default="element",
+    ap.add_argument("--smoother-operator", choices=["matrix-free", "element", "assembled"], default="matrix-free",
                     help="what the multigrid smoother multiplies with on the fine level: the unassembled symmetric element "
                          "tangents (default where available: undecomposed 3D Q2 meshes; 27 %% fewer bytes per product) or the "
                          "assembled sliced-ELL matrix; the CG's own product always uses the assembled matrix")
@@ -318,7 +318,7 @@ def main():
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
                       rho=1000.0, beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
                       world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
-        G.set_tuning("smoother_operator", 1 if args.smoother_operator == "element" else 0)
+        G.set_tuning("smoother_operator", {"matrix-free": 2, "element": 1, "assembled": 0}[args.smoother_operator])
         G.set_tuning("cg_warm_start", 1 if (cg_start or args.cg_start) == "previous-update" else 0)
         G.set_tuning("cg_operator", 1 if (cg_operator or args.cg_operator) == "element" else 0)
         if os.environ.get("MI_CG_FUSED_DOT"):
@@ -436,19 +436,23 @@ def main():
         # tangent assemblies (8 nnz + connectivity + gathers + rhs), residual-only passes and layout copies of
         # one step / the step's wall time
         n_prod = (spmv_n + tm["spmv_precond"][1]) / args.steps
-        ebe = G.get_tuning("smoother_operator_active") == 1
-        # element-tangent product: 378 lower-triangle 3x3 blocks + 27 node ids + first-touch bits per cell, x gathered,
-        # y written
-        ebe_bytes = G.ncells * (378 * 72 + 27 * 4 + 4) + 8 * G.n * 2
-        asm_bytes = 8 * G.nnz + 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n + (G.ncells * 378 * 72 if ebe else 0)
+        form = G.get_tuning("smoother_operator_active")  # 2 matrix-free (records), 1 element tangents, 0 assembled
+        ebe = form in (1, 2)
+        # per cell: element tangents = 378 lower-triangle 3x3 blocks, matrix-free = 18 doubles per quadrature point (64);
+        # both + 27 node ids + first-touch bits per cell, x gathered, y written
+        per_cell = 378 * 72 if form == 1 else 18 * 64 * 8
+        ebe_bytes = G.ncells * (per_cell + 27 * 4 + 4) + 8 * G.n * 2
+        asm_bytes = 8 * G.nnz + 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n + (G.ncells * per_cell if ebe else 0)
         res_bytes = 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n
         step_bytes = (spmv_n / args.steps * spmv_bytes(G.nnodes, nnzb, 3) +
                       tm["spmv_precond"][1] / args.steps * (ebe_bytes if ebe else spmv_bytes(G.nnodes, nnzb, 3)) +
                       tm["assemble_cells"][1] / args.steps * asm_bytes +
                       tm["assemble_residual"][1] / args.steps * res_bytes + tm["sell_copy"][1] / args.steps * 16 * G.nnz +
                       120 * G.n) / share
-        out["config"]["smoother_operator"] = ("unassembled symmetric element tangents (%.2f GB per product)" % (ebe_bytes / 1e9)
-                                              if ebe else "assembled sliced-ELL matrix")
+        out["config"]["smoother_operator"] = (
+            "matrix-free from the quadrature-point records of the assembly (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 2
+            else "unassembled symmetric element tangents (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 1
+            else "assembled sliced-ELL matrix")
         out["config"]["ms_smoother_fine_product"] = tm["spmv_precond"][0] / max(tm["spmv_precond"][1], 1)
         if ebe and tm["ebe_launch"][1] > 0 and world == 1 and args.slabs == 1:
             # the DOMINANT kernel of the step (half of the GPU time) is the element-tangent product of the multigrid smoother:
@@ -457,9 +461,13 @@ def main():
             ebe_ms = tm["ebe_launch"][0] / tm["ebe_launch"][1]
             per_launch = ebe_bytes / 8  # one colour of the eight; the colours differ by +-5 % in cells
             out["roofline"] = {
-                "kernel": "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
-                          "tangents (378 lower-triangle 3x3 blocks per cell); eight launches = one fine-level product of the "
-                          "multigrid smoother; the dominant kernel of the step by GPU time",
+                "kernel": ("mf_spmv: y += sum over the cells of ONE colour of P^T K_e P x evaluated from the 64 x 18 quadrature-"
+                           "point numbers per cell the tangent is made of (sum factorisation, no stored K_e); "
+                           if form == 2 else
+                           "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
+                           "tangents (378 lower-triangle 3x3 blocks per cell); ") +
+                          "eight launches = one fine-level product of the multigrid smoother; the kernel with the largest share "
+                          "of the step's GPU time",
                 "bound": "hbm",
                 "achieved": per_launch / (ebe_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
@@ -499,7 +507,7 @@ def main():
                 cgobj["traffic_from_committed_profile"] = {
                     "GB_per_launch": dot[0]["traffic_GB_per_launch"], "source": os.path.relpath(pmc_file, ROOT),
                     "ratio_to_algorithmic": dot[0]["traffic_GB_per_launch"] / (bytes_bsr / 1e9), "how": how}
-            eb = [v for k, v in pmc.items() if k.startswith("mi::ebe_spmv")]
+            eb = [v for k, v in pmc.items() if k.startswith("mi::mf_spmv" if form == 2 else "mi::ebe_spmv")]
             if eb and "cg_product" in out["roofline"]:
                 tot = sum(v["traffic_GB_per_launch"] * v["launches"] for v in eb) / sum(v["launches"] for v in eb)
                 out["roofline"]["traffic_from_committed_profile"] = {

@@ -255,8 +255,21 @@ namespace mi_detail
         if (part == 1)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
-        mi::MfParams  f{c->d_qrec, c->d_conn, c->d_node_first, c->d_cmask, c->d_vals, c->d_diagpos, c->d_tab, x, y,
-                       c->alpha[1] * c->mat.rho};
+        mi::MfParams  f{};
+        f.qrec    = c->d_qrec;
+        f.conn    = c->d_conn;
+        f.first   = c->d_node_first;
+        f.cmask   = c->d_cmask;
+        f.vals    = c->d_vals;
+        f.diagpos = c->d_diagpos;
+        f.tab1d   = c->d_tab;
+        f.cverts  = c->d_cverts;
+        f.mu      = c->mat.mu;
+        f.kappa   = c->kappa;
+        f.cellbox = c->d_cellbox;
+        f.x       = x;
+        f.y       = y;
+        f.mass    = c->alpha[1] * c->mat.rho;
         // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
         // profiler reports them), class MI_T_EBE_LAUNCH
         mi_ctx    *c0     = c->team->members[0];
@@ -499,6 +512,37 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // quadrature-point records for the matrix-free product (3D Q2) + the geometry class of the local cells
+  int alloc_point_records(mi_ctx *c)
+  {
+    if (c->d_qrec)
+      return MI_OK;
+    HIPCHK(c, hipMalloc((void **)&c->d_qrec, size_t(c->mesh.ncells) * mi::MF_NREC * 64 * sizeof(double)));
+    bool box = c->dim == 3;
+    for (int64_t e = 0; e < c->mesh.ncells && box; ++e)
+      {
+        const double *cv = &c->mesh.cverts[size_t(e) * 24];
+        for (int v = 0; v < 8 && box; ++v)
+          for (int d = 0; d < 3; ++d)
+            box = box && cv[v * 3 + d] == cv[(((v >> d) & 1) ? 7 : 0) * 3 + d];
+      }
+    if (box) // 1/h and the volume per cell, so that the product needs no division for its geometry
+      {
+        std::vector<double> cb(size_t(c->mesh.ncells) * 4);
+        for (int64_t e = 0; e < c->mesh.ncells; ++e)
+          {
+            const double *cv = &c->mesh.cverts[size_t(e) * 24];
+            const double  hx = cv[3] - cv[0], hy = cv[7] - cv[1], hz = cv[14] - cv[2]; // vertex v: bit d = upper end along d
+            cb[size_t(e) * 4 + 0] = 1.0 / hx;
+            cb[size_t(e) * 4 + 1] = 1.0 / hy;
+            cb[size_t(e) * 4 + 2] = 1.0 / hz;
+            cb[size_t(e) * 4 + 3] = hx * hy * hz;
+          }
+        return upload(c, &c->d_cellbox, cb);
+      }
+    return MI_OK;
+  }
+
   // storage for the unassembled element tangents, where the smoother can use them (filled by the next full assembly)
   int ensure_element_tangents(mi_ctx *c)
   {
@@ -507,7 +551,11 @@ namespace mi_detail
     if (want && (c->ebe == 2 ? !c->d_qrec : !c->d_ke))
       {
         if (c->ebe == 2)
-          HIPCHK(c, hipMalloc((void **)&c->d_qrec, size_t(c->mesh.ncells) * mi::MF_NREC * 64 * sizeof(double)));
+          {
+            const int rq = alloc_point_records(c);
+            if (rq)
+              return rq;
+          }
         else
           HIPCHK(c, hipMalloc((void **)&c->d_ke, size_t(c->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
         const int rc = c->d_node_first ? MI_OK : upload(c, &c->d_node_first, c->mesh.node_first);
@@ -790,7 +838,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1727,8 +1775,12 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
             return fail(c, MI_EINVAL, "element tangents exist for 3D Q2 meshes only");
           if (value == 1 && !m->d_ke)
             HIPCHK(m, hipMalloc((void **)&m->d_ke, size_t(m->mesh.ncells) * 9 * mi::EBE_NBLK * sizeof(double)));
-          if (value == 2 && !m->d_qrec)
-            HIPCHK(m, hipMalloc((void **)&m->d_qrec, size_t(m->mesh.ncells) * mi::MF_NREC * 64 * sizeof(double)));
+          if (value == 2)
+            {
+              const int rq = alloc_point_records(m);
+              if (rq)
+                return rq;
+            }
           if (!m->d_node_first)
             {
               const int rc = upload(m, &m->d_node_first, m->mesh.node_first);

@@ -39,7 +39,7 @@ namespace mi
   };
 
   // matrix-free product from the quadrature-point records of the last tangent assembly (see mf_spmv in mi_kernels.hip)
-  constexpr int MF_NREC = 18; // per point: M[9] = Jinv Finv, tau[6] (xx yy zz xy xz yz), JxW, JxW c_II, c_S / 2
+  constexpr int MF_NREC = 11; // per point: F[9], J^(-2/3), 1/J -- the state the tangent is linearised at
   struct MfParams
   {
     const double   *qrec;    // [ncells][MF_NREC][64]
@@ -48,10 +48,14 @@ namespace mi
     const uint8_t  *cmask;   // [nnodes]
     const double   *vals;    // assembled tangent (block-CSR): diagonal entries of constrained dofs
     const int32_t  *diagpos; // [nnodes] block index of (node,node)
-    const double   *tab1d;   // N1[4][3], dN1[4][3] (the assembly's tables)
+    const double   *tab1d;   // N1[4][3], dN1[4][3], qw[4], qx[4] (the assembly's tables)
+    const double   *cverts;  // [ncells][8][3]
+    double          mu, kappa;
+    const double   *cellbox; // [ncells][4] = 1/hx, 1/hy, 1/hz, hx hy hz when every cell is an axis-parallel box, else null
     const double   *x;
     double         *y;
     double          mass;    // alpha_1 rho
+    int32_t         count, xcd_chunk; // set by the launcher: cells of this launch, cells per XCD (0: plain order)
   };
 
   struct SpmvParams

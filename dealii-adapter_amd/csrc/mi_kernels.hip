@@ -98,9 +98,13 @@ namespace mi
   {
     return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
   }
+  __device__ __forceinline__ void inv3x3r(const double *A, double r, double *B); // r = 1 / det A
   __device__ __forceinline__ void inv3x3(const double *A, double det, double *B)
   {
-    const double r = 1.0 / det;
+    inv3x3r(A, 1.0 / det, B);
+  }
+  __device__ __forceinline__ void inv3x3r(const double *A, double r, double *B)
+  {
     B[0]           = (A[4] * A[8] - A[5] * A[7]) * r;
     B[1]           = (A[2] * A[7] - A[1] * A[8]) * r;
     B[2]           = (A[1] * A[5] - A[2] * A[4]) * r;
@@ -190,20 +194,12 @@ namespace mi
   //   tau_iso = dev(tau_bar), tau = tau_iso + kappa/2 (J^2-1) I,
   //   c_II = kappa J^2 - 2/d^2 tr(tau_bar),  c_S = -kappa (J^2-1) + 2/d tr(tau_bar)
   // gu is the 3x3-embedded displacement gradient w.r.t. reference coordinates.
+  // the response from F, J = det F, Jm = J^(-2/d) and rJ = 1/J (what the matrix-free product keeps per point, see mf_spmv)
   template <int DIM>
-  __device__ __forceinline__ void neo_hooke_qp(const double *gu, double mu, double kappa, double *Finv, double &J,
-                                               double *tau, double *tiso, double &cII, double &cS)
+  __device__ __forceinline__ void neo_hooke_from_F(const double *F, double J, double Jm, double rJ, double mu, double kappa,
+                                                   double *Finv, double *tau, double *tiso, double &cII, double &cS)
   {
-    double F[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-      F[k] = gu[k];
-    F[0] += 1.0;
-    F[4] += 1.0;
-    F[8] += 1.0; // DIM==2: gu[8]==0 -> F33 = 1 (embedding keeps det and inverse of the 2x2 part)
-    J = det3x3(F);
-    inv3x3(F, J, Finv);
-    const double Jm = (DIM == 3) ? 1.0 / (cbrt(J) * cbrt(J)) : 1.0 / J; // J^(-2/d)
+    inv3x3r(F, rJ, Finv);
     double       b[6];                                                  // xx yy zz xy xz yz
     b[0]            = F[0] * F[0] + F[1] * F[1] + (DIM == 3 ? F[2] * F[2] : 0.0);
     b[1]            = F[3] * F[3] + F[4] * F[4] + (DIM == 3 ? F[5] * F[5] : 0.0);
@@ -230,6 +226,29 @@ namespace mi
       tau[2] += pv;
     cII = kappa * J * J - (2.0 / (DIM * DIM)) * tr;
     cS  = -kappa * (J * J - 1.0) + (2.0 / DIM) * tr;
+  }
+  template <int DIM>
+  __device__ __forceinline__ void neo_hooke_qp(const double *gu, double mu, double kappa, double *Finv, double &J,
+                                               double *tau, double *tiso, double &cII, double &cS, double *F, double &Jm,
+                                               double &rJ)
+  {
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      F[k] = gu[k];
+    F[0] += 1.0;
+    F[4] += 1.0;
+    F[8] += 1.0; // DIM==2: gu[8]==0 -> F33 = 1 (embedding keeps det and inverse of the 2x2 part)
+    J  = det3x3(F);
+    rJ = 1.0 / J;
+    Jm = (DIM == 3) ? 1.0 / (cbrt(J) * cbrt(J)) : rJ; // J^(-2/d)
+    neo_hooke_from_F<DIM>(F, J, Jm, rJ, mu, kappa, Finv, tau, tiso, cII, cS);
+  }
+  template <int DIM>
+  __device__ __forceinline__ void neo_hooke_qp(const double *gu, double mu, double kappa, double *Finv, double &J,
+                                               double *tau, double *tiso, double &cII, double &cS)
+  {
+    double F[9], Jm, rJ;
+    neo_hooke_qp<DIM>(gu, mu, kappa, Finv, J, tau, tiso, cII, cS, F, Jm, rJ);
   }
 
   __device__ __forceinline__ void sym_mul(const double *S, const double *g, double *out)
@@ -370,8 +389,8 @@ namespace mi
             gu[i * 3 + j] = (i < DIM && j < DIM) ? gxi[i * 3 + 0] * Ji[0 * 3 + j] + gxi[i * 3 + 1] * Ji[1 * 3 + j] +
                                                      (DIM == 3 ? gxi[i * 3 + 2] * Ji[2 * 3 + j] : 0.0) :
                                                    0.0;
-        double Finv[9], J, tau[6], tiso[6], cII, cS;
-        neo_hooke_qp<DIM>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS);
+        double Finv[9], J, tau[6], tiso[6], cII, cS, Fq[9], Jmq, rJq;
+        neo_hooke_qp<DIM>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS, Fq, Jmq, rJq);
         if (part == 0)
           {
             double *r = &s_qp[q * RQ];
@@ -399,15 +418,14 @@ namespace mi
             for (int i = 0; i < 3; ++i)
               r[Q_FACC + i] = prm.rho * w * (acc[i] - prm.body[i]);
             if constexpr (DIM == 3 && P == 2 && ABL == 0)
-              if (prm.qrec) // what the tangent is made of at this point, for the matrix-free product (mf_spmv)
+              if (prm.qrec) // the state the tangent is linearised at, for the matrix-free product (mf_spmv)
                 {
                   double *__restrict__ g = prm.qrec + cell * int64_t(MF_NREC * 64) + q;
 #pragma unroll
-                  for (int k = 0; k < 15; ++k)
-                    g[k * 64] = r[k]; // Q_M (9), Q_TAU (6)
-                  g[15 * 64] = w;
-                  g[16 * 64] = w * cII;
-                  g[17 * 64] = 0.5 * cS;
+                  for (int k = 0; k < 9; ++k)
+                    g[k * 64] = Fq[k];
+                  g[9 * 64]  = Jmq;
+                  g[10 * 64] = rJq;
                 }
           }
       }
@@ -1529,26 +1547,48 @@ namespace mi
 
   // ------------------------------------------------------------------ matrix-free product from quadrature-point records
   // y += sum over the cells of one colour of P_e^T K_e P_e x WITHOUT K_e: the assembly leaves, per cell and quadrature
-  // point, the 18 numbers the element tangent is made of (M = Jinv Finv, tau, JxW, JxW c_II, c_S/2: MF_NREC x 64 doubles
-  // = 9.2 kB per 3D Q2 cell against 27.2 kB for the symmetric element tangent and 37.6 kB of assembled rows), and the
-  // product evaluates  y_a = sum_q Q(q) grad_xi N_a(q)  with
-  //   H = sum_b x_b (x) grad_xi N_b,  h = H M,  S = (c_II tr h - 2/3 tau_iso:h) I - 2/3 tr h tau_iso + c_S/2 (h + h^T) + h tau,
+  // point, the state its tangent is linearised at (F, J^(-2/3), 1/J: MF_NREC x 64 doubles = 5.6 kB per 3D Q2 cell against
+  // 27.2 kB for the symmetric element tangent and 37.6 kB of assembled rows); the product recomputes the material
+  // response from it with the assembly's own function (neo_hooke_from_F) and evaluates  y_a = sum_q Q(q) grad_xi N_a(q):
+  //   M = Jinv Finv,  H = sum_b x_b (x) grad_xi N_b,  h = H M,
+  //   S = (c_II tr h - 2/3 tau_iso:h) I - 2/3 tr h tau_iso + c_S/2 (h + h^T) + h tau,
   //   Q = JxW S M^T  (+ the mass term alpha_1 rho JxW N_a N_b),
   // which is K_e x_e term by term (assemble_cells' node-pair form summed over b; tools/proto/mf_product.py checks the
   // algebra against the independent mirror).  Gradients and the integration are contracted one lattice direction at a
   // time (3 nodes <-> 4 points); in every pass a lane owns one line and produces ALL outputs along the contracted
   // direction, so the 1D tables are scalar operands and every intermediate is written to LDS once.
   // One wavefront = one cell = its 64 quadrature points.  Update of y as in ebe_spmv (colours, first touch stores).
+  // Geometry: BOX (every cell an axis-parallel box, the reference's grids) takes 1/h and the volume from the cell's
+  // corner vertices; otherwise the Jacobian of the trilinear map is evaluated at the point as in the assembly.
   // Constrained dofs: x is masked on the way in; their rows receive diag(K) x from the assembled tangent at the first touch
   // (|K_e(i,i)| summed over the cells is what the assembly put there), nothing otherwise.
-  __global__ __launch_bounds__(64) void mf_spmv(MfParams prm, int64_t cell0)
+  template <bool BOX>
+  __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0)
   {
     constexpr int NPC = 27;
+    // LDS (per cell, 7.9 kB): s0 = x (81 at 0) and the i-contracted lines A (2 x 108 at AO), then the (i,j)-contracted
+    // planes B (3 x 9 x 20 at 0; plane stride 20 and the lane order (c*3+k)*4 + qx keep their stores conflict free), then
+    // the point results Q (12 x 64; the 16-lane groups of component 1 are swapped so that components 0 and 1, one
+    // half-wave in I3, read different banks), then the qz-contracted planes C IN PLACE of the Q entries their lane
+    // consumed; sE = the qy-contracted lines E (2 x 108).
+    constexpr int PS = 20, PW = 9 * PS, AO = 552;
     __shared__ double s0[768];
-    __shared__ double s1[432];
+    __shared__ double sE[216];
     __shared__ int    s_conn[NPC], s_cm[NPC];
+    // reads go through volatile pointers: single ds_read_b64 (2 LDS cycles per wave) instead of merged ds_read2_b64 (8)
+    typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
+    const lds_cvp v0 = (lds_cvp)s0, vE = (lds_cvp)sE;
     const int     lane = threadIdx.x;
-    const int64_t cell = cell0 + blockIdx.x;
+    // workgroups go round robin over the 8 XCDs: give each XCD a contiguous run of cells, so that the x / y lines shared
+    // by neighbouring cells of the colour meet in ONE L2 (MI_MF_XCD=0: plain order, for A/B)
+    int64_t cell = cell0 + blockIdx.x;
+    if (prm.xcd_chunk > 0)
+      {
+        const int64_t local = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
+        if (local >= prm.count)
+          return;
+        cell = cell0 + local;
+      }
     // the cell's records: issued first, consumed after the gradient passes
     double rec[MF_NREC];
     {
@@ -1575,6 +1615,15 @@ namespace mi
         Sz[k] = prm.tab1d[qz * 3 + k];
         Dz[k] = prm.tab1d[12 + qz * 3 + k];
       }
+    // this lane's quadrature weight and (general geometry) unit-cell point: tab1d holds qw[4] at 24 and qx[4] at 28
+    const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
+    double       xiq[3];
+    if constexpr (!BOX)
+      {
+        xiq[0] = prm.tab1d[28 + (lane & 3)];
+        xiq[1] = prm.tab1d[28 + ((lane >> 2) & 3)];
+        xiq[2] = prm.tab1d[28 + qz];
+      }
     // ---- gather x (constrained entries masked): X[c][a] at c*27 + a, a = (k*3 + j)*3 + i
     if (lane < NPC)
       {
@@ -1589,32 +1638,47 @@ namespace mi
             s0[c * NPC + lane] = ((cm >> c) & 1) ? 0.0 : xv;
           }
       }
-    __syncthreads();
-    // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at 81 / 189 + qx*27 + lane
+    // the entries of y this lane will update at the very end (lane = line (c,k,j), its three nodes i): read now, the
+    // colouring keeps every other cell of this launch away from them
+    const int lc = lane / 9, lkj = lane - 9 * lc;
+    int64_t   yidx[3];
+    double    yold[3];
     if (lane < 27)
       {
-        const double x0 = s0[lane * 3], x1 = s0[lane * 3 + 1], x2 = s0[lane * 3 + 2];
 #pragma unroll
-        for (int qx = 0; qx < 4; ++qx)
+        for (int i = 0; i < 3; ++i)
           {
-            s0[81 + qx * 27 + lane]  = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
-            s0[189 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
+            yidx[i] = int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc;
+            yold[i] = prm.y[yidx[i]];
           }
       }
     __syncthreads();
-    // ---- E2: contract j.  lane = qx*9 + (c*3+k); B_DS / B_SD / B_SS [c*3+k][qy][qx] at 336 + {0,144,288}
+    // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at AO + {0,108} + qx*27 + lane
+    if (lane < 27)
+      {
+        const double x0 = v0[lane * 3], x1 = v0[lane * 3 + 1], x2 = v0[lane * 3 + 2];
+#pragma unroll
+        for (int qx = 0; qx < 4; ++qx)
+          {
+            s0[AO + qx * 27 + lane]       = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
+            s0[AO + 108 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
+          }
+      }
+    __syncthreads();
+    // ---- E2: contract j.  lane = (c*3+k)*4 + qx; B_DS / B_SD / B_SS [c*3+k][qy][qx] at {0,PW,2PW} (over x)
+    const int pck = lane >> 2, pqx = lane & 3; // plane index c*3+k and qx of this lane in E2 / I2
     if (lane < 36)
       {
-        const int    qx = lane / 9, ck = lane - 9 * qx;
-        const double as0 = s0[81 + 3 * lane], as1 = s0[81 + 3 * lane + 1], as2 = s0[81 + 3 * lane + 2];
-        const double ad0 = s0[189 + 3 * lane], ad1 = s0[189 + 3 * lane + 1], ad2 = s0[189 + 3 * lane + 2];
+        const int    ia  = AO + pqx * 27 + pck * 3;
+        const double as0 = v0[ia], as1 = v0[ia + 1], as2 = v0[ia + 2];
+        const double ad0 = v0[108 + ia], ad1 = v0[108 + ia + 1], ad2 = v0[108 + ia + 2];
 #pragma unroll
         for (int qy = 0; qy < 4; ++qy)
           {
-            const int o     = 336 + ck * 16 + qy * 4 + qx;
+            const int o     = pck * PS + qy * 4 + pqx;
             s0[o]           = S[qy][0] * ad0 + S[qy][1] * ad1 + S[qy][2] * ad2; // d/dx
-            s0[o + 144]     = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2; // d/dy
-            s0[o + 288]     = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2; // value / d/dz
+            s0[o + PW]      = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2; // d/dy
+            s0[o + 2 * PW]  = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2; // value / d/dz
           }
       }
     __syncthreads();
@@ -1627,19 +1691,55 @@ namespace mi
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           {
-            const int    o   = 336 + (c * 3 + k) * 16 + q16;
-            const double bds = s0[o], bsd = s0[o + 144], bss = s0[o + 288];
+            const int    o   = (c * 3 + k) * PS + q16;
+            const double bds = v0[o], bsd = v0[o + PW], bss = v0[o + 2 * PW];
             H[c][0]          = fma(Sz[k], bds, H[c][0]);
             H[c][1]          = fma(Sz[k], bsd, H[c][1]);
             H[c][2]          = fma(Dz[k], bss, H[c][2]);
             V[c]             = fma(Sz[k], bss, V[c]);
           }
       }
-    __syncthreads(); // s0 is rewritten below
+    __syncthreads(); // B is consumed: the point results go on top of it
     // ---- quadrature point: Q = JxW S M^T
     {
-      const double *M = rec, *tau = rec + 9;
-      const double  w = rec[15], wcII = rec[16], cs2 = rec[17];
+      double M[9], tau[6], w, wcII, cs2;
+      {
+        const double *F = rec;
+        double        Finv[9], tiso[6], cII, cS, Ji[9], detJ;
+        neo_hooke_from_F<3>(F, det3x3(F), rec[9], rec[10], prm.mu, prm.kappa, Finv, tau, tiso, cII, cS);
+        if constexpr (BOX)
+          {
+            const double *__restrict__ cb = prm.cellbox + cell * 4; // 1/hx, 1/hy, 1/hz, hx hy hz (uniform: scalar loads)
+            const double rx = cb[0], ry = cb[1], rz = cb[2];
+            detJ            = cb[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              {
+                M[k]     = rx * Finv[k];
+                M[3 + k] = ry * Finv[3 + k];
+                M[6 + k] = rz * Finv[6 + k];
+              }
+          }
+        else
+          {
+            const double *__restrict__ cv = prm.cverts + cell * 24; // uniform: scalar loads
+            double verts[24], Jm[9];
+#pragma unroll
+            for (int k = 0; k < 24; ++k)
+              verts[k] = cv[k];
+            q1_jacobian<3>(verts, xiq, Jm);
+            detJ = det3x3(Jm);
+            inv3x3(Jm, detJ, Ji);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+                M[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+          }
+        w    = detJ * wq;
+        wcII = w * cII;
+        cs2  = 0.5 * cS;
+      }
       double        h[3][3];
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -1668,14 +1768,16 @@ namespace mi
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         {
+          const int ql = lane ^ ((i & 1) << 4);
 #pragma unroll
           for (int l = 0; l < 3; ++l)
-            s0[(i * 4 + l) * 64 + lane] = Sm[i][0] * M[l * 3] + Sm[i][1] * M[l * 3 + 1] + Sm[i][2] * M[l * 3 + 2];
-          s0[(i * 4 + 3) * 64 + lane] = wm * V[i];
+            s0[(i * 4 + l) * 64 + ql] = Sm[i][0] * M[l * 3] + Sm[i][1] * M[l * 3 + 1] + Sm[i][2] * M[l * 3 + 2];
+          s0[(i * 4 + 3) * 64 + ql] = wm * V[i];
         }
     }
     __syncthreads();
-    // ---- I3: contract qz.  lane = c*16 + (qy*4+qx); C_DS / C_SD / C_SS [c*3+k][qy][qx] in s1 at {0,144,288}
+    // ---- I3: contract qz.  lane = c*16 + (qy*4+qx); C_DS / C_SD / C_SS [c][k][qy][qx] replace Q[c][0 / 1 / 2][z = k][qy][qx],
+    // entries only this lane has read
     if (lane < 48)
       {
         const int c = lane >> 4;
@@ -1684,7 +1786,7 @@ namespace mi
         for (int d = 0; d < 4; ++d)
 #pragma unroll
           for (int z = 0; z < 4; ++z)
-            v[d][z] = s0[(c * 4 + d) * 64 + z * 16 + q16];
+            v[d][z] = v0[(c * 4 + d) * 64 + ((z * 16 + q16) ^ ((c & 1) << 4))];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           {
@@ -1697,25 +1799,25 @@ namespace mi
                 css = fma(D[z][k], v[2][z], css);
                 css = fma(S[z][k], v[3][z], css);
               }
-            const int o = (c * 3 + k) * 16 + q16;
-            s1[o]       = cds;
-            s1[o + 144] = csd;
-            s1[o + 288] = css;
+            const int o = c * 256 + ((k * 16 + q16) ^ ((c & 1) << 4));
+            s0[o]       = cds;
+            s0[o + 64]  = csd;
+            s0[o + 128] = css;
           }
       }
     __syncthreads();
-    // ---- I2: contract qy.  lane = qx*9 + (c*3+k); E_D / E_S [qx][c,k,j] in s0 at {0,108} + qx*27 + (c*3+k)*3 + j
+    // ---- I2: contract qy.  lane = (c*3+k)*4 + qx; E_D / E_S [qx][c,k,j] in sE at {0,108} + qx*27 + (c*3+k)*3 + j
     if (lane < 36)
       {
-        const int qx = lane / 9, ck = lane - 9 * qx;
-        double    cds[4], csd[4], css[4];
+        double cds[4], csd[4], css[4];
 #pragma unroll
         for (int qy = 0; qy < 4; ++qy)
           {
-            const int o = ck * 16 + qy * 4 + qx;
-            cds[qy]     = s1[o];
-            csd[qy]     = s1[o + 144];
-            css[qy]     = s1[o + 288];
+            const int c = pck / 3, kk = pck - 3 * c;
+            const int o = c * 256 + ((kk * 16 + qy * 4 + pqx) ^ ((c & 1) << 4));
+            cds[qy]     = v0[o];
+            csd[qy]     = v0[o + 64];
+            css[qy]     = v0[o + 128];
           }
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -1728,8 +1830,9 @@ namespace mi
                 es = fma(D[qy][j], csd[qy], es);
                 es = fma(S[qy][j], css[qy], es);
               }
-            s0[3 * lane + j]       = ed;
-            s0[108 + 3 * lane + j] = es;
+            const int o  = pqx * 27 + pck * 3 + j;
+            sE[o]       = ed;
+            sE[108 + o] = es;
           }
       }
     __syncthreads();
@@ -1740,10 +1843,9 @@ namespace mi
 #pragma unroll
         for (int qx = 0; qx < 4; ++qx)
           {
-            ed[qx] = s0[qx * 27 + lane];
-            es[qx] = s0[108 + qx * 27 + lane];
+            ed[qx] = vE[qx * 27 + lane];
+            es[qx] = vE[108 + qx * 27 + lane];
           }
-        const int      c = lane / 9, kj = lane - 9 * c;
         const uint32_t fb = prm.first[cell];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -1755,17 +1857,15 @@ namespace mi
                 yv = fma(D[qx][i], ed[qx], yv);
                 yv = fma(S[qx][i], es[qx], yv);
               }
-            const int     a     = kj * 3 + i;
-            const int32_t node  = s_conn[a];
-            const bool    first = (fb >> a) & 1u;
-            const int64_t idx   = int64_t(node) * 3 + c;
-            if ((s_cm[a] >> c) & 1)
+            const int  a     = lkj * 3 + i;
+            const bool first = (fb >> a) & 1u;
+            if ((s_cm[a] >> lc) & 1)
               {
                 if (first)
-                  prm.y[idx] = prm.vals[int64_t(prm.diagpos[node]) * 9 + c * 4] * prm.x[idx];
+                  prm.y[yidx[i]] = prm.vals[int64_t(prm.diagpos[s_conn[a]]) * 9 + lc * 4] * prm.x[yidx[i]];
               }
             else
-              prm.y[idx] = first ? yv : prm.y[idx] + yv;
+              prm.y[yidx[i]] = first ? yv : yold[i] + yv;
           }
       }
   }
@@ -2888,10 +2988,16 @@ namespace mi
   {
     if (cell_count <= 0)
       return;
+    static const bool xcd = !(getenv("MI_MF_XCD") && atoi(getenv("MI_MF_XCD")) == 0);
+    MfParams          q   = p;
+    q.count               = cell_count;
+    q.xcd_chunk           = xcd ? (cell_count + 7) / 8 : 0;
+    const int grid        = xcd ? q.xcd_chunk * 8 : cell_count;
+    auto *kern = q.cellbox ? mf_spmv<true> : mf_spmv<false>;
     if (ev_start || ev_stop)
-      hipExtLaunchKernelGGL(mf_spmv, dim3(cell_count), dim3(64), 0, s, ev_start, ev_stop, 0, p, cell_begin);
+      hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, q, cell_begin);
     else
-      hipLaunchKernelGGL(mf_spmv, dim3(cell_count), dim3(64), 0, s, p, cell_begin);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, q, cell_begin);
   }
 
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,

@@ -1,6 +1,6 @@
 """Time one fine-level product at the headline size in its three forms (assembled sliced-ELL, element tangents,
 matrix-free from quadrature-point records) in ONE process, and check the three against each other.
-  python tools/time_element_products.py [n = 59]"""
+  python tools/time_element_products.py [n = 59] [forms = 2,1]"""
 import os, sys, importlib
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -8,7 +8,8 @@ M = importlib.import_module("dealii-adapter_amd")
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 59
 res = {}
-for form in (2, 1):
+forms = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 1]
+for form in forms:
     G = M.Context(dim=3, degree=2, reps=(n, n, n))
     G.set_tuning("smoother_operator", form)
     G.set_interface_traction((0.0, -2e3, 0.0))
