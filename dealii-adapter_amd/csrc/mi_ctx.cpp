@@ -498,7 +498,7 @@ namespace mi_detail
         return MI_OK;
       }
     c->ke_valid = (c->d_ke || c->d_qrec) &&
-                  !(c->dim == 3 && c->degree == 2 && c->asm_variant != 0 && c->asm_variant != 1 && c->asm_variant != 2);
+                  !(c->dim == 3 && c->degree == 2 && c->asm_variant != 0 && c->asm_variant != 1 && c->asm_variant != 2 && c->asm_variant != 9);
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -1808,7 +1808,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->small_cg = value;
       else if (k == "halo_overlap" && (value == 0 || value == 1))
         c->team->overlap = value;
-      else if (k == "asm_variant" && value >= 0 && value <= 8)
+      else if (k == "asm_variant" && value >= 0 && value <= 9)
         m->asm_variant = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
         m->mg_lag = value;

@@ -660,6 +660,514 @@ namespace mi
   }
 
 
+  // ------------------------------------------------------------------ 3D Q2 cell assembly, sum factorised (default)
+  // Same element tangent, residual and scatter as assemble_cells, a third of its arithmetic.  With g_a = M^T grad_xi N_a,
+  // M = Jinv Finv, every term of the tangent is a bilinear form in the UNIT-CELL gradients:
+  //   K_ab^{ij} = sum_q sum_{kl} d_k N_a(q) C^{ij}_{kl}(q) d_l N_b(q)  +  delta_ij sum_q mu(q) N_a(q) N_b(q),
+  //   C^{ij}_{kl} = A_ki M_lj + B_ki Tm_lj + E_kj M_li + delta_ij S_kl,   Tm = -(2/3) M tau_iso,
+  //   A = w (c_II M + Tm),  B = w M,  E = w (c_S/2) M,  S = w (c_S/2 M M^T + M tau M^T),  mu = alpha_1 rho w,
+  // and N_a(q) = N_a1(qx) N_a2(qy) N_a3(qz), so the sum over the 64 points is contracted one direction at a time
+  // (tools/proto/sf_assembly.py checks algebra and decomposition against the independent mirror).
+  // One workgroup of 4 waves per cell:
+  //   wave 0, lane = quadrature point: u and the acceleration interpolated to the points by sum factorisation,
+  //     kinematics + material (neo_hooke_qp), the 81 coefficient fields + mu -> LDS, the point records for mf_spmv,
+  //     then the residual  r_a = -sum_q (w tau M^T grad_xi N_a + N_a rho w (acc - b))  integrated by sum factorisation;
+  //   waves 1-3, lane = (ij, (a1 >= b1), a2) [162 items]: for every qz: x-contraction of C along a line of 4 points
+  //     (per-lane products N_a1 N_b1), y-contraction into 12 accumulators (a2 per lane, b2 unrolled; the (k==z, l==z)
+  //     type of (kl) selects the accumulator, so the sum over kl happens here), then the z-contraction into the lane's
+  //     27 tangent entries K^{ij}[(a1 a2 a3),(b1 b2 b3)], b2 a3 b3 unrolled.  1D tables are scalar operands.
+  // Only node pairs with (a1,a2,a3) >= (b1,b2,b3) (x most significant) are formed; they are filed under the lower
+  // triangle of the usual node order, transposed where the two orders disagree, in an LDS image of the element tangent
+  // [e = i*3+j][block], from which the scatter of assemble_cells runs (constraint masking, first-touch store / RMW).
+  // RES_ONLY (64 threads): wave 0 alone = the residual-only pass of the Newton convergence check.
+  #define MI_WAVE_SYNC()                                                                                              \
+    do                                                                                                                \
+      {                                                                                                               \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                        \
+        __builtin_amdgcn_wave_barrier();                                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                        \
+      }                                                                                                               \
+    while (0)
+  template <bool RES_ONLY>
+  __global__ __launch_bounds__(RES_ONLY ? 64 : 256, RES_ONLY ? 4 : 3) void assemble_q2sf(AsmParams prm)
+  {
+    constexpr int NPC = 27, FS = 66, NF = 82; // field stride (padded: fields of different ij on different banks), fields
+    constexpr int PS = 20, PW = 9 * PS, AO = 552;
+    __shared__ __attribute__((aligned(16))) double s_C[RES_ONLY ? 2 : NF * FS]; // later the element tangent [9][378]
+    __shared__ __attribute__((aligned(16))) double s_w[768 + 216];              // wave 0's scratch (as in mf_spmv)
+    __shared__ int s_conn[NPC];
+    typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
+    const int     tid  = threadIdx.x;
+    const int64_t cell = prm.cell_begin + blockIdx.x;
+    // 1D tables (uniform)
+    double S[4][3], D[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        {
+          S[q][a] = prm.tab1d[q * 3 + a];
+          D[q][a] = prm.tab1d[12 + q * 3 + a];
+        }
+
+    if (tid < 64)
+      {
+        // ================================================================= wave 0: quadrature points
+        const int     lane = tid;
+        double *const s0 = s_w, *const sE = s_w + 768;
+        const lds_cvp v0 = (lds_cvp)s0, vE = (lds_cvp)sE;
+        const int     qz = lane >> 4, q16 = lane & 15;
+        double        Sz[3], Dz[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          {
+            Sz[k] = prm.tab1d[qz * 3 + k];
+            Dz[k] = prm.tab1d[12 + qz * 3 + k];
+          }
+        const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
+        double       xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
+        const int    pck = lane >> 2, pqx = lane & 3;
+        int32_t      node = 0;
+        double       accn[3] = {0.0, 0.0, 0.0};
+        if (lane < NPC)
+          {
+            node         = prm.conn[cell * NPC + lane];
+            s_conn[lane] = node;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              {
+                const int64_t g    = int64_t(node) * 3 + c;
+                s0[c * NPC + lane] = prm.u[g] + prm.du[g]; // get_total_solution, :580-588
+                accn[c]            = prm.acc[g];
+              }
+          }
+        // ---- two interpolations to the points: pass 0 = u (gradients), pass 1 = acceleration (values)
+        double gxi[3][3], accq[3];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass)
+          {
+            MI_WAVE_SYNC();
+            if (lane < 27) // contract i
+              {
+                const double x0 = v0[lane * 3], x1 = v0[lane * 3 + 1], x2 = v0[lane * 3 + 2];
+#pragma unroll
+                for (int qx = 0; qx < 4; ++qx)
+                  {
+                    s0[AO + qx * 27 + lane] = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
+                    if (pass == 0)
+                      s0[AO + 108 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
+                  }
+              }
+            MI_WAVE_SYNC();
+            if (lane < 36) // contract j
+              {
+                const int    ia  = AO + pqx * 27 + pck * 3;
+                const double as0 = v0[ia], as1 = v0[ia + 1], as2 = v0[ia + 2];
+                double       ad0 = 0.0, ad1 = 0.0, ad2 = 0.0;
+                if (pass == 0)
+                  {
+                    ad0 = v0[108 + ia];
+                    ad1 = v0[108 + ia + 1];
+                    ad2 = v0[108 + ia + 2];
+                  }
+#pragma unroll
+                for (int qy = 0; qy < 4; ++qy)
+                  {
+                    const int o = pck * PS + qy * 4 + pqx;
+                    if (pass == 0)
+                      {
+                        s0[o]      = S[qy][0] * ad0 + S[qy][1] * ad1 + S[qy][2] * ad2;
+                        s0[o + PW] = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2;
+                      }
+                    s0[o + 2 * PW] = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2;
+                  }
+              }
+            MI_WAVE_SYNC();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) // contract k
+              {
+                double h0 = 0.0, h1 = 0.0, h2 = 0.0, vv = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  {
+                    const int    o   = (c * 3 + k) * PS + q16;
+                    const double bss = v0[o + 2 * PW];
+                    if (pass == 0)
+                      {
+                        h0 = fma(Sz[k], v0[o], h0);
+                        h1 = fma(Sz[k], v0[o + PW], h1);
+                        h2 = fma(Dz[k], bss, h2);
+                      }
+                    else
+                      vv = fma(Sz[k], bss, vv);
+                  }
+                if (pass == 0)
+                  {
+                    gxi[c][0] = h0;
+                    gxi[c][1] = h1;
+                    gxi[c][2] = h2;
+                  }
+                else
+                  accq[c] = vv;
+              }
+            if (pass == 0)
+              {
+                MI_WAVE_SYNC();
+                if (lane < NPC)
+#pragma unroll
+                  for (int c = 0; c < 3; ++c)
+                    s0[c * NPC + lane] = accn[c];
+              }
+          }
+        // ---- geometry, kinematics, material at this point (nonlinear_elasticity.cc:927-934)
+        double M[9], tau[6], tiso[6], w, cII, cS;
+        {
+          const double *__restrict__ cv = prm.cverts + cell * 24;
+          double verts[24], Jm[9], Ji[9], gu[9], Finv[9], J, Fq[9], Jmq, rJq;
+#pragma unroll
+          for (int k = 0; k < 24; ++k)
+            verts[k] = cv[k];
+          q1_jacobian<3>(verts, xiq, Jm);
+          const double detJ = det3x3(Jm);
+          inv3x3(Jm, detJ, Ji);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              gu[i * 3 + j] = gxi[i][0] * Ji[0 * 3 + j] + gxi[i][1] * Ji[1 * 3 + j] + gxi[i][2] * Ji[2 * 3 + j];
+          neo_hooke_qp<3>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS, Fq, Jmq, rJq);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              M[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+          w = detJ * wq; // JxW of the reference configuration
+          if constexpr (!RES_ONLY)
+            if (prm.qrec) // the state the tangent is linearised at, for the matrix-free product (mf_spmv)
+              {
+                double *__restrict__ g = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                  g[k * 64] = Fq[k];
+                g[9 * 64]  = Jmq;
+                g[10 * 64] = rJq;
+              }
+        }
+        const double T[3][3]  = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
+        // ---- coefficient fields for the tangent waves
+        if constexpr (!RES_ONLY)
+          {
+            const double Ti[3][3] = {{tiso[0], tiso[3], tiso[4]}, {tiso[3], tiso[1], tiso[5]}, {tiso[4], tiso[5], tiso[2]}};
+            const double cs2      = 0.5 * cS;
+            double       Tm[3][3], A[3][3], B[3][3], E[3][3], Sk[3][3], MT[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                {
+                  Tm[k][i] = (-2.0 / 3.0) * (M[k * 3] * Ti[0][i] + M[k * 3 + 1] * Ti[1][i] + M[k * 3 + 2] * Ti[2][i]);
+                  MT[k][i] = M[k * 3] * T[0][i] + M[k * 3 + 1] * T[1][i] + M[k * 3 + 2] * T[2][i]; // (M tau)_ki
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+                {
+                  A[k][i] = w * (cII * M[k * 3 + i] + Tm[k][i]);
+                  B[k][i] = w * M[k * 3 + i];
+                  E[k][i] = (w * cs2) * M[k * 3 + i];
+                }
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int l = 0; l < 3; ++l)
+                Sk[k][l] = E[k][0] * M[l * 3] + E[k][1] * M[l * 3 + 1] + E[k][2] * M[l * 3 + 2] +
+                           w * (MT[k][0] * M[l * 3] + MT[k][1] * M[l * 3 + 1] + MT[k][2] * M[l * 3 + 2]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                  for (int l = 0; l < 3; ++l)
+                    {
+                      double c = A[k][i] * M[l * 3 + j] + B[k][i] * Tm[l][j] + E[k][j] * M[l * 3 + i];
+                      if (i == j)
+                        c += Sk[k][l];
+                      s_C[((i * 3 + j) * 9 + k * 3 + l) * FS + lane] = c;
+                    }
+            s_C[81 * FS + lane] = prm.alpha1 * prm.rho * w;
+            __syncthreads(); // (1) fields complete
+          }
+        // ---- residual: Q[i][k] = w sum_j tau_ij M_kj, V[i] = rho w (acc - b)_i, integrated against grad N_a / N_a
+        MI_WAVE_SYNC();
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          {
+            const int ql = lane ^ ((i & 1) << 4);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              // explicit fma chain: the same arithmetic in the full and in the residual-only instantiation, whatever
+              // else shares these products
+              s0[(i * 4 + k) * 64 + ql] = w * fma(T[i][2], M[k * 3 + 2], fma(T[i][1], M[k * 3 + 1], T[i][0] * M[k * 3]));
+            s0[(i * 4 + 3) * 64 + ql] = prm.rho * w * (accq[i] - prm.body[i]);
+          }
+        MI_WAVE_SYNC();
+        if (lane < 48) // contract qz
+          {
+            const int c = lane >> 4;
+            double    v[4][4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+              for (int z = 0; z < 4; ++z)
+                v[d][z] = v0[(c * 4 + d) * 64 + ((z * 16 + q16) ^ ((c & 1) << 4))];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              {
+                double cds = 0.0, csd = 0.0, css = 0.0;
+#pragma unroll
+                for (int z = 0; z < 4; ++z)
+                  {
+                    cds = fma(S[z][k], v[0][z], cds);
+                    csd = fma(S[z][k], v[1][z], csd);
+                    css = fma(D[z][k], v[2][z], css);
+                    css = fma(S[z][k], v[3][z], css);
+                  }
+                const int o = c * 256 + ((k * 16 + q16) ^ ((c & 1) << 4));
+                s0[o]       = cds;
+                s0[o + 64]  = csd;
+                s0[o + 128] = css;
+              }
+          }
+        MI_WAVE_SYNC();
+        if (lane < 36) // contract qy
+          {
+            double cds[4], csd[4], css[4];
+#pragma unroll
+            for (int qy = 0; qy < 4; ++qy)
+              {
+                const int c = pck / 3, kk = pck - 3 * c;
+                const int o = c * 256 + ((kk * 16 + qy * 4 + pqx) ^ ((c & 1) << 4));
+                cds[qy]     = v0[o];
+                csd[qy]     = v0[o + 64];
+                css[qy]     = v0[o + 128];
+              }
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              {
+                double ed = 0.0, es = 0.0;
+#pragma unroll
+                for (int qy = 0; qy < 4; ++qy)
+                  {
+                    ed = fma(S[qy][j], cds[qy], ed);
+                    es = fma(D[qy][j], csd[qy], es);
+                    es = fma(S[qy][j], css[qy], es);
+                  }
+                const int o = pqx * 27 + pck * 3 + j;
+                sE[o]       = ed;
+                sE[108 + o] = es;
+              }
+          }
+        MI_WAVE_SYNC();
+        if (lane < 27) // contract qx; residual scatter (:769-773; constrained rows get no rhs)
+          {
+            double ed[4], es[4];
+#pragma unroll
+            for (int qx = 0; qx < 4; ++qx)
+              {
+                ed[qx] = vE[qx * 27 + lane];
+                es[qx] = vE[108 + qx * 27 + lane];
+              }
+            const int lc = lane / 9, lkj = lane - 9 * lc;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+              {
+                double rv = 0.0;
+#pragma unroll
+                for (int qx = 0; qx < 4; ++qx)
+                  {
+                    rv = fma(D[qx][i], ed[qx], rv);
+                    rv = fma(S[qx][i], es[qx], rv);
+                  }
+                const int32_t A = s_conn[lkj * 3 + i];
+                if (!((prm.cmask[A] >> lc) & 1))
+                  prm.rhs[int64_t(A) * 3 + lc] -= rv;
+              }
+          }
+        if constexpr (RES_ONLY)
+          return;
+      }
+    if constexpr (!RES_ONLY)
+      {
+        // ================================================================= waves 1-3: the element tangent
+        const int  it     = tid - 64;
+        const bool active = tid >= 64 && it < 162;
+        const int  ij = active ? it / 18 : 0, r18 = active ? it - 18 * ij : 0, pr = r18 / 3, a2 = r18 - 3 * pr;
+        const int  a1 = pr >= 3 ? 2 : (pr >= 1 ? 1 : 0), b1 = pr - a1 * (a1 + 1) / 2; // pairs (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+        const int  ci = ij / 3, cj = ij - 3 * ci;
+        double     Kacc[3][3][3]; // [a3][b3][b2]
+#pragma unroll
+        for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+          for (int b3 = 0; b3 < 3; ++b3)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; ++b2)
+              Kacc[a3][b3][b2] = 0.0;
+        if (tid >= 64)
+          {
+            // per-lane tables: P1[kx*2+lx][qx] = phi^kx_a1(qx) phi^lx_b1(qx), phi2[ky][qy] = phi^ky_a2(qy); phi^1 = N', phi^0 = N
+            double P1[4][4], phi2[2][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              {
+                const double sa = prm.tab1d[q * 3 + a1], da = prm.tab1d[12 + q * 3 + a1];
+                const double sb = prm.tab1d[q * 3 + b1], db = prm.tab1d[12 + q * 3 + b1];
+                P1[0][q]        = sa * sb;
+                P1[1][q]        = sa * db;
+                P1[2][q]        = da * sb;
+                P1[3][q]        = da * db;
+                phi2[0][q]      = prm.tab1d[q * 3 + a2];
+                phi2[1][q]      = prm.tab1d[12 + q * 3 + a2];
+              }
+            const double mflag = (ci == cj) ? 1.0 : 0.0;
+            __syncthreads(); // (1) fields complete
+            const double *__restrict__ cb = s_C + ij * 9 * FS;
+#pragma unroll
+            for (int qz = 0; qz < 4; ++qz)
+              {
+                double acc[2][2][3]; // [k==z][l==z][b2]
+#pragma unroll
+                for (int x = 0; x < 12; ++x)
+                  (&acc[0][0][0])[x] = 0.0;
+#pragma unroll
+                for (int kl = 0; kl < 10; ++kl)
+                  {
+                    const int  k = kl / 3, l = kl - 3 * k;
+                    const bool mass = kl == 9;
+                    const int  kx = (!mass && k == 0), lx = (!mass && l == 0), ky = (!mass && k == 1),
+                              ly = (!mass && l == 1), kz = (!mass && k == 2), lz = (!mass && l == 2);
+                    const double *__restrict__ f = mass ? s_C + 81 * FS : cb + kl * FS;
+#pragma unroll
+                    for (int qy = 0; qy < 4; ++qy)
+                      {
+                        const double2 c01 = *reinterpret_cast<const double2 *>(f + qz * 16 + qy * 4);
+                        const double2 c23 = *reinterpret_cast<const double2 *>(f + qz * 16 + qy * 4 + 2);
+                        double t = P1[kx * 2 + lx][0] * c01.x;
+                        t        = fma(P1[kx * 2 + lx][1], c01.y, t);
+                        t        = fma(P1[kx * 2 + lx][2], c23.x, t);
+                        t        = fma(P1[kx * 2 + lx][3], c23.y, t);
+                        if (mass)
+                          t *= mflag;
+                        const double ta = t * phi2[ky][qy];
+#pragma unroll
+                        for (int b2 = 0; b2 < 3; ++b2)
+                          acc[kz][lz][b2] = fma(ta, ly ? D[qy][b2] : S[qy][b2], acc[kz][lz][b2]);
+                      }
+                  }
+#pragma unroll
+                for (int kz = 0; kz < 2; ++kz)
+#pragma unroll
+                  for (int lz = 0; lz < 2; ++lz)
+#pragma unroll
+                    for (int b2 = 0; b2 < 3; ++b2)
+                      {
+                        const double v = acc[kz][lz][b2];
+#pragma unroll
+                        for (int a3 = 0; a3 < 3; ++a3)
+                          {
+                            const double va = v * (kz ? D[qz][a3] : S[qz][a3]);
+#pragma unroll
+                            for (int b3 = 0; b3 < 3; ++b3)
+                              Kacc[a3][b3][b2] = fma(va, lz ? D[qz][b3] : S[qz][b3], Kacc[a3][b3][b2]);
+                          }
+                      }
+              }
+          }
+        __syncthreads(); // (2) fields consumed: the element tangent image goes on top of them
+        if (active)
+          {
+#pragma unroll
+            for (int a3 = 0; a3 < 3; ++a3)
+#pragma unroll
+              for (int b3 = 0; b3 < 3; ++b3)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; ++b2)
+                  {
+                    // wanted: (a1,a2,a3) >= (b1,b2,b3), x most significant (a1 >= b1 by construction)
+                    const bool want = a1 > b1 || a2 > b2 || (a2 == b2 && a3 >= b3);
+                    const int  a = a1 + 3 * a2 + 9 * a3, b = b1 + 3 * b2 + 9 * b3;
+                    if (want)
+                      {
+                        const bool low = a >= b; // lower triangle of the node order; otherwise the transposed block of (b,a)
+                        const int  hi = low ? a : b, lo = low ? b : a, e = low ? ci * 3 + cj : cj * 3 + ci;
+                        s_C[e * EBE_NBLK + hi * (hi + 1) / 2 + lo] = Kacc[a3][b3][b2];
+                      }
+                  }
+          }
+        __syncthreads(); // (3) image complete
+        // ---- tangent scatter, one thread per node-pair block.  [DEAL.II distribute_local_to_global] constrained
+        // rows/cols are dropped, the diagonal of a constrained dof receives |K_e(i,i)|.
+        const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
+        for (int blk = tid; blk < EBE_NBLK; blk += 256)
+          {
+            int a = int((sqrtf(8.0f * float(blk) + 1.0f) - 1.0f) * 0.5f);
+            while ((a + 1) * (a + 2) / 2 <= blk)
+              ++a;
+            while (a * (a + 1) / 2 > blk)
+              --a;
+            const int     b = blk - a * (a + 1) / 2;
+            const int32_t A = s_conn[a], B = s_conn[b];
+            const int     ma = prm.cmask[A], mb = prm.cmask[B];
+            const uint16_t oab = offc[a * NPC + b], oba = offc[b * NPC + a];
+            double *__restrict__ pab = prm.vals + (int64_t(prm.rowptr[A]) + (oab & 0x7fff)) * 9;
+            double *__restrict__ pba = prm.vals + (int64_t(prm.rowptr[B]) + (oba & 0x7fff)) * 9;
+            const bool first_ab = oab >> 15, first_ba = oba >> 15; // first touch in processing order: plain store
+            double     vab[9], vba[9];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+                {
+                  double v = s_C[(i * 3 + j) * EBE_NBLK + blk];
+                  if (((ma >> i) | (mb >> j)) & 1)
+                    v = (a == b && i == j) ? fabs(v) : 0.0;
+                  vab[i * 3 + j] = v;
+                  vba[j * 3 + i] = v;
+                }
+            if (prm.ke) // the cell's own masked block, before it is summed into the global matrix
+#pragma unroll
+              for (int k = 0; k < 9; ++k)
+                s_C[k * EBE_NBLK + blk] = vab[k];
+            if (!first_ab)
+#pragma unroll
+              for (int k = 0; k < 9; ++k)
+                vab[k] += pab[k];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+              pab[k] = vab[k];
+            if (a != b)
+              {
+                if (!first_ba)
+#pragma unroll
+                  for (int k = 0; k < 9; ++k)
+                    vba[k] += pba[k];
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                  pba[k] = vba[k];
+              }
+          }
+        if (prm.ke)
+          {
+            __syncthreads();
+            double *__restrict__ dst = prm.ke + cell * (int64_t(9) * EBE_NBLK);
+            for (int i = tid; i < 9 * EBE_NBLK; i += 256)
+              dst[i] = s_C[i];
+          }
+      }
+  }
+
   // ------------------------------------------------------------------ cell assembly by sum factorisation (3D Q2)
   // Same element tangent and residual as assemble_cells, different arithmetic.  With g_a = M^T grad_xi N_a every term
   // of K_ab is a bilinear form in the UNIT-CELL gradients:
@@ -2773,8 +3281,17 @@ namespace mi
     if (dim == 3 && degree == 2)
       {
         // 105 tiles x 2 lanes, 64 quadrature points in chunks of QC; variants for A/B timing (mi_set_tuning "asm_variant")
-        switch (p.residual_only ? 0 : p.variant)
+        switch ((p.variant == 9 || !p.residual_only) ? p.variant : 0)
           {
+            case 0: // sum factorised (default): 4 waves per cell, 51 kB LDS
+              if (p.residual_only)
+                hipLaunchKernelGGL(assemble_q2sf<true>, dim3(p.cell_count), dim3(64), 0, s, p);
+              else
+                hipLaunchKernelGGL(assemble_q2sf<false>, dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 9: // node-pair form (the default until round 2): 16.4 ms per assembly at 5 M DoFs
+              launch_asm_sel<3, 2, 2, 256, 8>(p, s);
+              break;
             case 1:
               launch_asm<3, 2, 2, 256, 16>(p, s); // 54 kB LDS, 2 workgroups per CU: 23.6 ms per assembly at 5M DoFs
               break;
