@@ -2071,7 +2071,7 @@ namespace mi
   // Constrained dofs: x is masked on the way in; their rows receive diag(K) x from the assembled tangent at the first touch
   // (|K_e(i,i)| summed over the cells is what the assembly put there), nothing otherwise.
   template <bool BOX>
-  __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0)
+  __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0) // 5 waves per SIMD spill and lose 7 %
   {
     constexpr int NPC = 27;
     // LDS (per cell, 7.9 kB): s0 = x (81 at 0) and the i-contracted lines A (2 x 108 at AO), then the (i,j)-contracted
@@ -2149,16 +2149,12 @@ namespace mi
     // the entries of y this lane will update at the very end (lane = line (c,k,j), its three nodes i): read now, the
     // colouring keeps every other cell of this launch away from them
     const int lc = lane / 9, lkj = lane - 9 * lc;
-    int64_t   yidx[3];
     double    yold[3];
     if (lane < 27)
       {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          {
-            yidx[i] = int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc;
-            yold[i] = prm.y[yidx[i]];
-          }
+          yold[i] = prm.y[int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc];
       }
     __syncthreads();
     // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at AO + {0,108} + qx*27 + lane
@@ -2208,6 +2204,13 @@ namespace mi
           }
       }
     __syncthreads(); // B is consumed: the point results go on top of it
+    if constexpr (BOX) // the mass term first: it needs only the cell's volume, and V dies before the tensor algebra
+      {
+        const double wm = prm.mass * prm.cellbox[cell * 4 + 3] * wq;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          s0[(i * 4 + 3) * 64 + (lane ^ ((i & 1) << 4))] = wm * V[i];
+      }
     // ---- quadrature point: Q = JxW S M^T
     {
       double M[9], tau[6], w, wcII, cs2;
@@ -2280,7 +2283,8 @@ namespace mi
 #pragma unroll
           for (int l = 0; l < 3; ++l)
             s0[(i * 4 + l) * 64 + ql] = Sm[i][0] * M[l * 3] + Sm[i][1] * M[l * 3 + 1] + Sm[i][2] * M[l * 3 + 2];
-          s0[(i * 4 + 3) * 64 + ql] = wm * V[i];
+          if constexpr (!BOX)
+            s0[(i * 4 + 3) * 64 + ql] = wm * V[i];
         }
     }
     __syncthreads();
@@ -2365,15 +2369,16 @@ namespace mi
                 yv = fma(D[qx][i], ed[qx], yv);
                 yv = fma(S[qx][i], es[qx], yv);
               }
-            const int  a     = lkj * 3 + i;
-            const bool first = (fb >> a) & 1u;
+            const int     a     = lkj * 3 + i;
+            const bool    first = (fb >> a) & 1u;
+            const int64_t yi    = int64_t(s_conn[a]) * 3 + lc;
             if ((s_cm[a] >> lc) & 1)
               {
                 if (first)
-                  prm.y[yidx[i]] = prm.vals[int64_t(prm.diagpos[s_conn[a]]) * 9 + lc * 4] * prm.x[yidx[i]];
+                  prm.y[yi] = prm.vals[int64_t(prm.diagpos[s_conn[a]]) * 9 + lc * 4] * prm.x[yi];
               }
             else
-              prm.y[yidx[i]] = first ? yv : yold[i] + yv;
+              prm.y[yi] = first ? yv : yold[i] + yv;
           }
       }
   }
