@@ -3071,6 +3071,35 @@ namespace mi
       }
   }
 
+  // the same step for 3 components with one thread per DOF (192 threads = 64 nodes): every load and store is a
+  // contiguous stream (the node-per-thread form reads 24-byte records at a stride), the residual of a node's three
+  // components is shared through LDS
+  __global__ __launch_bounds__(192) void cheb_step_blk3(double *x, double *d, const double *__restrict__ b,
+                                                        const double *__restrict__ q, const double *__restrict__ dinv,
+                                                        double c1, double c2, int64_t node0, int64_t nnodes)
+  {
+    __shared__ double s_res[192];
+    const int     ld  = threadIdx.x;
+    const int64_t g   = (node0 + int64_t(blockIdx.x) * 64) * 3 + ld;
+    const bool    in  = int64_t(blockIdx.x) * 64 + ld / 3 < nnodes;
+    double        res = 0.0;
+    if (in)
+      res = b[g] - (q ? q[g] : 0.0);
+    s_res[ld] = res;
+    __syncthreads();
+    if (!in)
+      return;
+    const int    r0 = (ld / 3) * 3;
+    const double a0 = dinv[g * 3], a1 = dinv[g * 3 + 1], a2 = dinv[g * 3 + 2];
+    double       s  = 0.0;
+    s += a0 * s_res[r0];
+    s += a1 * s_res[r0 + 1];
+    s += a2 * s_res[r0 + 2];
+    const double dn = (c1 != 0.0 ? c1 * d[g] : 0.0) + c2 * s; // first step: old d not read
+    d[g]            = dn;
+    x[g]            = (q ? x[g] : 0.0) + dn;
+  }
+
   // masked l2 norm partials: sum over dofs whose constraint bit is clear (:549-576)
   template <int D>
   __global__ __launch_bounds__(256) void masked_norm_partials(const double *__restrict__ v,
@@ -3588,7 +3617,8 @@ namespace mi
   {
     const int grid = int((nnodes + 255) / 256);
     if (dim == 3)
-      hipLaunchKernelGGL((cheb_step_blk<3>), dim3(grid), dim3(256), 0, s, x, d, b, q, dinv, c1, c2, node0, nnodes);
+      hipLaunchKernelGGL(cheb_step_blk3, dim3(int((nnodes + 63) / 64)), dim3(192), 0, s, x, d, b, q, dinv, c1, c2, node0,
+                         nnodes);
     else
       hipLaunchKernelGGL((cheb_step_blk<2>), dim3(grid), dim3(256), 0, s, x, d, b, q, dinv, c1, c2, node0, nnodes);
   }
