@@ -1,0 +1,34 @@
+#!/bin/bash
+# The committed profile set of a round from ONE box, in one gpurun call: bash tools/profile_round.sh [outdir]
+# (rocprofv3 kernel trace of the bench command, the bench line of that process, PMC passes over the same command, the
+# plain default run with the CPU baseline, the A/B runs).  Copy what is wanted from <outdir> to profiles/<round>/.
+set -u
+OUT=${1:-gpurun_out/round}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf "$OUT"; mkdir -p "$OUT"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py --steps 3 --warmup 1 --cpu-cells 0 \
+  > "$OUT/bench_under_rocprof_n59.json" 2> "$OUT/trace.err"
+T=$(ls "$OUT"/trace/*/*kernel_trace.csv | head -1)
+python3 tools/trace_buckets.py "$T" > "$OUT/kernel_trace_by_grid_n59.txt"
+cp "$(dirname "$T")"/*kernel_stats.csv "$OUT/kernel_stats_bench_n59.csv"
+cp "$(dirname "$T")"/*domain_stats.csv "$OUT/domain_stats_bench_n59.csv"
+rm -rf "$OUT/trace"
+bash tools/pmc_bench.sh "$OUT/pmc" > /dev/null 2>&1
+cp "$OUT/pmc/pmc_bench.json" "$OUT/pmc_bench_n59.json"; rm -rf "$OUT/pmc"
+python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_n59.json"
+python bench.py --steps 5 --warmup 2 --cpu-cells 0 --cg-start previous-update 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_reference_cg_start.json"
+python bench.py --steps 5 --warmup 2 --cpu-cells 0 --smoother-operator element 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_element_tangent_smoother.json"
+python bench.py --steps 5 --warmup 2 --cpu-cells 0 --smoother-operator assembled 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_assembled_smoother.json"
+python bench.py --steps 5 --warmup 2 --cpu-cells 0 --cg-operator element 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_cg_operator_matrix_free.json"
+python bench.py --steps 5 --warmup 2 --cpu-cells 0 --precond-storage f32 --smoother-operator assembled 2>/dev/null | tail -1 > "$OUT/bench_precond_storage_f32_option.json"
+python bench.py --steps 5 --warmup 2 --cpu-cells 0 --cells 34 2>/dev/null | tail -1 > "$OUT/bench_n34_config3.json"
+mkdir -p "$OUT/emulated_slabs"
+for N in 1 2 4 8; do
+  python bench.py --steps 3 --warmup 1 --cpu-cells 0 --slabs $N 2>/dev/null | tail -1 > "$OUT/emulated_slabs/slabs$N.json"
+done
+for N in 2 4 8; do
+  python bench.py --steps 3 --warmup 1 --cpu-cells 0 --slabs $N --scaling weak 2>/dev/null | tail -1 > "$OUT/emulated_slabs/weak_slabs$N.json"
+done
+python tools/tune_assemble.py --cells 59 --rounds 2 --reps 3 --variants 0,9 > "$OUT/assembly_kernels_n59.txt" 2>&1
+python tools/time_element_products.py 59 2,1 > "$OUT/fine_level_product_forms_n59.txt" 2>&1
+ls -la "$OUT"
