@@ -246,10 +246,17 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * rows of the SpMV (default), 0 in line on the compute stream; "precond_storage" 64 (default) | 32: the multigrid
  * smoother multiplies with an fp32-rounded copy of the level matrices (arithmetic, the CG's own product and its
  * residuals stay fp64); "sell_icol" 1 (default): the SpMV generates the column indices of a row from its
- * column box (lattice meshes) instead of reading them, 0: reads the index array; "smoother_operator" 1 (default): on 3D Q2 meshes above 100k nodes per slab the multigrid smoother multiplies with the unassembled symmetric element tangents (27 % fewer bytes than the assembled matrix; the CG's own product stays on the assembled matrix), 0: with the assembled matrix; "spmv_variant" 4 + "element_tangents" 1: mi_spmv through the element tangents, "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
+ * column box (lattice meshes) instead of reading them, 0: reads the index array; "smoother_operator" 2 (default): on 3D Q2
+ * meshes above 100k nodes per slab the multigrid smoother applies the tangent matrix-free from the quadrature-point
+ * state of the last assembly (6x fewer bytes than the assembled matrix; the CG's own product stays on the assembled
+ * matrix), 1: with stored symmetric element tangents, 0: with the assembled matrix; "spmv_variant" 4 +
+ * "element_tangents" 2 | 1: mi_spmv through that form whatever the mesh size (tests); "cg_operator" 0 (default) | 1: the
+ * CG's own product on the assembled matrix | in the smoother's unassembled form (A/B); "asm_variant" 0 (default): 3D Q2
+ * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
  * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
-/* read back: "smoother_operator_active" (1: the smoother's fine-level products use the element tangents), "precond",
+/* read back: "smoother_operator_active" (2 / 1: the smoother's fine-level products are matrix-free / use the stored
+ * element tangents, 0: the assembled matrix), "precond",
  * "spmv_variant" */
 int mi_get_tuning(mi_ctx *ctx, const char *key, int *value);
 int mi_reset_timings(mi_ctx *ctx);
