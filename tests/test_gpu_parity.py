@@ -165,8 +165,9 @@ def test_spmv_matches_reference_matrix(dim, p, reps):
 
 
 def test_element_kernel_variants_agree():
-    """the A/B instantiations of the 3D Q2 element kernel (quadrature chunk sizes, and the sum-factorised kernel that
-    contracts one lattice direction at a time) assemble the same tangent and residual"""
+    """the 3D Q2 element kernels -- 0: the sum-factorised default (assemble_q2sf), 9: the node-pair kernel every other
+    element uses, 1 / 2: its quadrature chunk sizes, 5: round 1's sum factorisation -- assemble the same tangent and
+    residual; so does the residual-only pass of each family"""
     reps = (3, 3, 2)
     nverts = int(np.prod([r + 1 for r in reps]))
     perturb = 0.02 * np.random.default_rng(3).standard_normal((nverts, 3))
@@ -178,10 +179,12 @@ def test_element_kernel_variants_agree():
     G.update_acceleration()
     x = rng.standard_normal(G.n)
     ref = None
-    for v in (0, 1, 2, 5):
+    for v in (0, 9, 1, 2, 5):
         G.set_tuning("asm_variant", v)
         rn = G.assemble()
         y, r = G.spmv(x), G.get(M.V_RHS)
+        if v in (0, 9):  # the residual-only pass of the family: bit-identical with its full kernel
+            assert G.assemble_residual() == rn and np.array_equal(G.get(M.V_RHS), r)
         if ref is None:
             ref = (y, r, rn)
             continue
