@@ -438,6 +438,7 @@ def main():
         n_prod = (spmv_n + tm["spmv_precond"][1]) / args.steps
         form = G.get_tuning("smoother_operator_active")  # 2 matrix-free (records), 1 element tangents, 0 assembled
         ebe = form in (1, 2)
+        single = False
         # per cell: element tangents = 378 lower-triangle 3x3 blocks, matrix-free = 11 doubles per quadrature point (64:
         # F, J^-2/3, 1/J; MF_NREC in mi_kernels.h); both + 27 node ids + first-touch bits per cell, x gathered, y written
         per_cell = 378 * 72 if form == 1 else 11 * 64 * 8
@@ -469,15 +470,22 @@ def main():
             cg = out["roofline"]
             ebe_ms = tm["ebe_launch"][0] / tm["ebe_launch"][1]
             per_launch = ebe_bytes / 8  # one colour of the eight; the colours differ by +-5 % in cells
+            single = form == 2 and G.get_tuning("mf_single_launch") == 1
+            if single:
+                # ONE launch over all cells: records + node ids + slot ids per cell, x once, 81 contributions per cell
+                # written to the cell's slots (the sum over the slots of a node is a second, streaming launch: mf_gather)
+                per_launch = G.ncells * (11 * 64 * 8 + 27 * 4 + 27 * 4 + 81 * 8) + 8 * G.n
             out["roofline"] = {
-                "kernel": ("mf_spmv: y += sum over the cells of ONE colour of P^T K_e P x evaluated from the 64 x 11 quadrature-"
+                "kernel": ("mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
                            "point numbers per cell the tangent is linearised at (sum factorisation, no stored K_e; 4.8x fewer bytes "
                            "than the element tangents it replaced, which takes the product off the HBM roofline: VALU 46 %, LDS 31 % "
                            "busy, profiles/r02/pmc_counters_mf_spmv_n59.json); "
                            if form == 2 else
                            "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
                            "tangents (378 lower-triangle 3x3 blocks per cell); ") +
-                          "eight launches = one fine-level product of the multigrid smoother; the kernel with the largest share "
+                          ("one launch over all cells (every cell stores into its own slots) + mf_gather (sum over the slots of a "
+                           "node, in the order of the colour-by-colour update) " if single else "eight launches ") +
+                          "= one fine-level product of the multigrid smoother; the kernel with the largest share "
                           "of the step's GPU time",
                 "bound": "hbm",
                 "achieved": per_launch / (ebe_ms * 1e-3) / 1e9,
@@ -489,7 +497,7 @@ def main():
                 "bytes_per_launch": per_launch,
                 "launches_timed": tm["ebe_launch"][1],
                 "avg_launch_ms": ebe_ms,
-                "timing": "start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on every 6th product's eight launches",
+                "timing": "start/stop events of the dispatch itself (hipExtLaunchKernelGGL) on every 6th product's launch(es)",
                 "share_of_step": tm["spmv_precond"][0] / args.steps / ms_step,
                 "cg_product": cg,
             }
@@ -518,7 +526,8 @@ def main():
                 cgobj["traffic_from_committed_profile"] = {
                     "GB_per_launch": dot[0]["traffic_GB_per_launch"], "source": os.path.relpath(pmc_file, ROOT),
                     "ratio_to_algorithmic": dot[0]["traffic_GB_per_launch"] / (bytes_bsr / 1e9), "how": how}
-            eb = [v for k, v in pmc.items() if k.startswith("mi::mf_spmv" if form == 2 else "mi::ebe_spmv")]
+            eb = [v for k, v in pmc.items() if k.startswith("mi::mf_spmv" if form == 2 else "mi::ebe_spmv")
+                  and (not single or v["traffic_GB_per_launch"] > 1.0)]
             if eb and "cg_product" in out["roofline"]:
                 tot = sum(v["traffic_GB_per_launch"] * v["launches"] for v in eb) / sum(v["launches"] for v in eb)
                 out["roofline"]["traffic_from_committed_profile"] = {

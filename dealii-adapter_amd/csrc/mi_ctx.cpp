@@ -270,10 +270,25 @@ namespace mi_detail
         f.x       = x;
         f.y       = y;
         f.mass    = c->alpha[1] * c->mat.rho;
+        const bool one_launch = kind == 2 && c->mf_slots && c->d_mf_yc;
+        if (one_launch)
+          {
+            f.yc        = c->d_mf_yc;
+            f.dst       = c->d_mf_dst;
+            f.slot_base = c->d_mf_slot_base;
+          }
         // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
         // profiler reports them), class MI_T_EBE_LAUNCH
         mi_ctx    *c0     = c->team->members[0];
         const bool sample = c0->profiling && (c->ebe_products++ % 6 == 0);
+        if (one_launch) // all cells at once (no two cells share a slot), then the sum over the slots of every node
+          {
+            const int t = sample ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
+            mi::launch_mf_spmv(f, 0, int32_t(c->mesh.ncells), c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                               t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+            mi::launch_mf_gather(f, int64_t(c->mesh.nnodes) * 3, c->stream);
+          }
+        else
         for (int col = 0; col < c->mesh.ncolours; ++col)
           {
             const int32_t cnt = int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]);
@@ -526,6 +541,29 @@ namespace mi_detail
           for (int d = 0; d < 3; ++d)
             box = box && cv[v * 3 + d] == cv[(((v >> d) & 1) ? 7 : 0) * 3 + d];
       }
+    {
+      // slots for the single-launch product: rank of every (cell, local node) among the cells of the node, in
+      // processing order (colour-sorted cell order: the order in which the colour-by-colour update adds them)
+      const int64_t        nc = c->mesh.ncells, nn = c->mesh.nnodes;
+      std::vector<int32_t> base(size_t(nn) + 1, 0), dst(size_t(nc) * 27), fill(size_t(nn), 0);
+      for (int64_t e = 0; e < nc; ++e)
+        for (int a = 0; a < 27; ++a)
+          ++base[size_t(c->mesh.conn[size_t(e) * 27 + a]) + 1];
+      for (int64_t n = 0; n < nn; ++n)
+        base[size_t(n) + 1] += base[size_t(n)];
+      for (int64_t e = 0; e < nc; ++e)
+        for (int a = 0; a < 27; ++a)
+          {
+            const int32_t n = c->mesh.conn[size_t(e) * 27 + a];
+            dst[size_t(e) * 27 + a] = base[size_t(n)] + fill[size_t(n)]++;
+          }
+      int rc = upload(c, &c->d_mf_dst, dst);
+      if (rc == MI_OK)
+        rc = upload(c, &c->d_mf_slot_base, base);
+      if (rc)
+        return rc;
+      HIPCHK(c, hipMalloc((void **)&c->d_mf_yc, size_t(nc) * 27 * 3 * sizeof(double)));
+    }
     if (box) // 1/h and the volume per cell, so that the product needs no division for its geometry
       {
         std::vector<double> cb(size_t(c->mesh.ncells) * 4);
@@ -838,7 +876,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1151,6 +1189,8 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     {
       if (const char *e = getenv("MI_EBE"))
         m->ebe = std::max(0, std::min(2, atoi(e)));
+      if (const char *e = getenv("MI_MF_SINGLE_LAUNCH"))
+        m->mf_slots = atoi(e) != 0;
       const int rc = ensure_element_tangents(m);
       if (rc != MI_OK)
         return bail(rc, m->err);
@@ -1790,6 +1830,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
           m->ebe      = value;
           m->ke_valid = false;
         }
+      else if (k == "mf_single_launch" && (value == 0 || value == 1))
+        m->mf_slots = value;
       else if (k == "xcd_remap" && (value == 0 || value == 1))
         m->xcd_remap = value;
       else if (k == "sell_unroll" && value >= -2 && value <= 8 && value != 0)
@@ -1862,6 +1904,8 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = (m->ebe && m->precond == 1 && m->precond_storage == 64 && ((m->ebe == 2 && m->d_qrec) || m->d_ke)) ?
                ((m->d_qrec && (m->ebe == 2 || !m->d_ke)) ? 2 : 1) :
                0;
+  else if (k == "mf_single_launch")
+    *value = (m->mf_slots && m->d_mf_yc) ? 1 : 0;
   else if (k == "precond")
     *value = m->precond;
   else if (k == "spmv_variant")

@@ -97,6 +97,10 @@ struct mi_ctx
   double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
   uint32_t *d_node_first = nullptr; // per cell: bit a = first touch of local node a (see HostMesh::node_first)
   double   *d_qrec = nullptr; // quadrature-point records of the last tangent assembly (3D Q2): the matrix-free form of the smoother's operator
+  double   *d_mf_yc = nullptr;        // matrix-free product in one launch: per-(cell, node) contributions ...
+  int32_t  *d_mf_dst = nullptr;       // ... their slots [ncells][27] ...
+  int32_t  *d_mf_slot_base = nullptr; // ... and the first slot of every node [nnodes+1]
+  int       mf_slots = 1;             // tuning "mf_single_launch": 1 one launch + gather (default), 0 eight colour launches
   double   *d_cellbox = nullptr; // with d_qrec when every local cell is an axis-parallel box: [ncells][4] = 1/h, volume
   bool      ke_valid = false; // d_ke / d_qrec belong to the current tangent
   int64_t   ebe_products = 0; // element-tangent products so far (profiling samples every 6th)

@@ -56,6 +56,10 @@ namespace mi
     double         *y;
     double          mass;    // alpha_1 rho
     int32_t         count, xcd_chunk; // set by the launcher: cells of this launch, cells per XCD (0: plain order)
+    // single-launch form (null: colour-by-colour update of y): every cell stores its results in its own slots
+    double         *yc;        // [nslots][3] contributions
+    const int32_t  *dst;       // [ncells][27] slot of (cell, local node)
+    const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
   };
 
   struct SpmvParams
@@ -161,6 +165,7 @@ namespace mi
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+  void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s);

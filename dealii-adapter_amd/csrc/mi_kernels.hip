@@ -2070,7 +2070,11 @@ namespace mi
   // corner vertices; otherwise the Jacobian of the trilinear map is evaluated at the point as in the assembly.
   // Constrained dofs: x is masked on the way in; their rows receive diag(K) x from the assembled tangent at the first touch
   // (|K_e(i,i)| summed over the cells is what the assembly put there), nothing otherwise.
-  template <bool BOX>
+  // SLOTS: instead of updating y colour by colour, every cell stores its 81 results in its own slots of a
+  // contribution array (slot = position of the cell among the cells of the node, in processing order) and ONE launch
+  // covers all cells; mf_gather then sums the slots of every node in that order -- the same additions in the same
+  // order as the colour-by-colour update, i.e. the same bits, in 2 launches instead of 8.
+  template <bool BOX, bool SLOTS>
   __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0) // 5 waves per SIMD spill and lose 7 %
   {
     constexpr int NPC = 27;
@@ -2150,11 +2154,15 @@ namespace mi
     // colouring keeps every other cell of this launch away from them
     const int lc = lane / 9, lkj = lane - 9 * lc;
     double    yold[3];
+    int32_t   ydst[3];
     if (lane < 27)
       {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          yold[i] = prm.y[int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc];
+          if constexpr (SLOTS)
+            ydst[i] = prm.dst[cell * NPC + lkj * 3 + i];
+          else
+            yold[i] = prm.y[int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc];
       }
     __syncthreads();
     // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at AO + {0,108} + qx*27 + lane
@@ -2358,7 +2366,7 @@ namespace mi
             ed[qx] = vE[qx * 27 + lane];
             es[qx] = vE[108 + qx * 27 + lane];
           }
-        const uint32_t fb = prm.first[cell];
+        const uint32_t fb = SLOTS ? 0u : prm.first[cell];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           {
@@ -2368,6 +2376,11 @@ namespace mi
               {
                 yv = fma(D[qx][i], ed[qx], yv);
                 yv = fma(S[qx][i], es[qx], yv);
+              }
+            if constexpr (SLOTS)
+              {
+                prm.yc[int64_t(ydst[i]) * 3 + lc] = yv;
+                continue;
               }
             const int     a     = lkj * 3 + i;
             const bool    first = (fb >> a) & 1u;
@@ -2381,6 +2394,27 @@ namespace mi
               prm.y[yi] = first ? yv : yold[i] + yv;
           }
       }
+  }
+
+  // y = sum of the cells' contributions, node by node in slot order (= processing order of the cells: the order of the
+  // colour-by-colour update); constrained rows: diag(K) x from the assembled tangent.  One thread per DOF.
+  __global__ __launch_bounds__(256) void mf_gather(MfParams prm, int64_t ndofs)
+  {
+    const int64_t g = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (g >= ndofs)
+      return;
+    const int64_t n = g / 3;
+    const int     c = int(g - n * 3);
+    if ((prm.cmask[n] >> c) & 1)
+      {
+        prm.y[g] = prm.vals[int64_t(prm.diagpos[n]) * 9 + c * 4] * prm.x[g];
+        return;
+      }
+    const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
+    double        s  = prm.yc[int64_t(b0) * 3 + c];
+    for (int32_t k = b0 + 1; k < b1; ++k)
+      s = s + prm.yc[int64_t(k) * 3 + c];
+    prm.y[g] = s;
   }
 
   // block-CSR -> sliced-ELL copy of the values (after every assembly); one wavefront per slice
@@ -3544,11 +3578,17 @@ namespace mi
     q.count               = cell_count;
     q.xcd_chunk           = xcd ? (cell_count + 7) / 8 : 0;
     const int grid        = xcd ? q.xcd_chunk * 8 : cell_count;
-    auto *kern = q.cellbox ? mf_spmv<true> : mf_spmv<false>;
+    auto *kern = q.yc ? (q.cellbox ? mf_spmv<true, true> : mf_spmv<false, true>) :
+                        (q.cellbox ? mf_spmv<true, false> : mf_spmv<false, false>);
     if (ev_start || ev_stop)
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, q, cell_begin);
     else
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, q, cell_begin);
+  }
+
+  void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s)
+  {
+    hipLaunchKernelGGL(mf_gather, dim3(int((ndofs + 255) / 256)), dim3(256), 0, s, p, ndofs);
   }
 
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,
