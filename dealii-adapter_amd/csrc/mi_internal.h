@@ -169,6 +169,7 @@ namespace mi_detail
   int  tic(mi_ctx *c, int cls, bool ext = false);
   void toc(mi_ctx *c, int id);
   int  sync(mi_ctx *c);
+  void           refresh_sell(mi_ctx *c); // sliced-ELL copy of the current tangent, if stale
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
                              const int32_t *done);
   // smoother: the product belongs to the multigrid preconditioner and may use the fp32-rounded copy of the values

@@ -166,6 +166,9 @@ namespace mi
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);
+  // coarsest multigrid level: dense inverse of the level's sliced-ELL matrix (n <= 96, -1 otherwise) and its application
+  int  launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s);
+  void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
                           double *sell_vals, float *sell_vals32, hipStream_t s);

@@ -3012,6 +3012,79 @@ namespace mi
       }
   }
 
+  // ------------------------------------------------------------------ exact solve on the coarsest multigrid level
+  // The coarsest level (2^dim cells: 81 dofs in 3D) is small enough to invert: one workgroup scatters the level's
+  // sliced-ELL matrix into a dense n x n array in LDS, inverts it in place (Gauss-Jordan without pivoting: the matrix
+  // is symmetric positive definite, constrained dofs are decoupled diagonal entries) and writes the inverse out; a
+  // V-cycle then applies it in ONE launch instead of a degree-12 polynomial (12 launches).
+  constexpr int DENSE_MAX = 96;
+  template <int D>
+  __global__ __launch_bounds__(256) void dense_inverse_from_sell(SellParams prm, int n, double *out)
+  {
+    constexpr int DD = D * D;
+    __shared__ double A[DENSE_MAX * DENSE_MAX];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n * n; i += 256)
+      A[i] = 0.0;
+    __syncthreads();
+    for (int r = tid; r < prm.nslices * 64; r += 256)
+      {
+        const int sl = r >> 6, lane = r & 63;
+        const int node = prm.perm[r];
+        if (node < 0)
+          continue;
+        const int     len = prm.len[sl];
+        const int64_t off = prm.off[sl];
+        for (int k = 0; k < len; ++k)
+          {
+            const int32_t c = prm.col[(off + k) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                A[(node * D + i) * n + c * D + j] += prm.vals[((off + k) * DD + i * D + j) * 64 + lane];
+          }
+      }
+    __syncthreads();
+    for (int p = 0; p < n; ++p)
+      {
+        const double r = 1.0 / A[p * n + p];
+        __syncthreads();
+        for (int j = tid; j < n; j += 256)
+          if (j != p)
+            A[p * n + j] *= r;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 256)
+          {
+            const int i = e / n, j = e - i * n;
+            if (i != p && j != p)
+              A[e] -= A[i * n + p] * A[p * n + j];
+          }
+        __syncthreads();
+        for (int i = tid; i < n; i += 256)
+          A[i * n + p] = (i == p) ? r : -A[i * n + p] * r;
+        __syncthreads();
+      }
+    for (int i = tid; i < n * n; i += 256)
+      out[i] = A[i];
+  }
+  // x = Ainv b (n <= DENSE_MAX); the inverse of a symmetric matrix is read by columns
+  __global__ __launch_bounds__(128) void dense_apply(const double *__restrict__ inv, const double *__restrict__ b, double *x,
+                                                     int n)
+  {
+    __shared__ double s_b[DENSE_MAX];
+    const int         i = threadIdx.x;
+    if (i < n)
+      s_b[i] = b[i];
+    __syncthreads();
+    if (i >= n)
+      return;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j)
+      s += inv[j * n + i] * s_b[j];
+    x[i] = s;
+  }
+
   // ------------------------------------------------------------------ small vector kernels
   // dinv = 1 / diag(K); constraints.distribute afterwards keeps constrained entries of x at 0
   template <int D>
@@ -3584,6 +3657,21 @@ namespace mi
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, q, cell_begin);
     else
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, q, cell_begin);
+  }
+
+  int launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s)
+  {
+    if (n > DENSE_MAX)
+      return -1;
+    if (dim == 3)
+      hipLaunchKernelGGL((dense_inverse_from_sell<3>), dim3(1), dim3(256), 0, s, p, n, out);
+    else
+      hipLaunchKernelGGL((dense_inverse_from_sell<2>), dim3(1), dim3(256), 0, s, p, n, out);
+    return 0;
+  }
+  void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(dense_apply, dim3(1), dim3(128), 0, s, inv, b, x, n);
   }
 
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s)

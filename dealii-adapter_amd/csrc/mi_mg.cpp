@@ -39,6 +39,7 @@ namespace mi_detail
     bool    x_swapped = false; // the fused smoother step writes x' = x + d into the other of the two x buffers
     bool    ev_ready = false;
     double  lmax = 0.0;     // estimate of the largest eigenvalue of D^-1 A
+    double *dense_inv = nullptr; // coarsest level, n <= 96: the inverse of the level matrix (exact coarse solve in one launch)
     MgTransfer to_coarse;   // to level l+1
     double *b() const { return ws; }
     double *x() const { return ws + (x_swapped ? 6 : 1) * ctx->n; }
@@ -62,7 +63,10 @@ namespace mi_detail
     int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
-    int    coarsest_reps = 1;    // stop coarsening once no direction has more cells than this
+    int    coarsest_reps = 2;    // stop coarsening once no direction has more cells than this (2^dim cells: 81 dofs in
+                                 // 3D, solved exactly by a dense inverse; MI_MG_COARSEST=1 + MI_MG_DENSE=0: round 1's
+                                 // one-cell level with a degree-12 polynomial)
+    int    dense         = 1;    // exact solve on the coarsest level when it has <= 96 dofs
     int    coarsen_factor = 2;   // cells per direction shrink by this factor from level to level
     double coarse_ratio  = 60.0;
     int    power_its     = 15;   // first estimate
@@ -341,6 +345,8 @@ namespace mi_detail
           hipFree(p);
         if (L.ws)
           hipFree(L.ws);
+        if (L.dense_inv)
+          hipFree(L.dense_inv);
         if (l > 0 && L.team)
           destroy_team(L.team); // destroys the level context; the stream is shared and stays
       }
@@ -369,6 +375,8 @@ namespace mi_detail
       mg->smooth_ratio = std::max(2.0, atof(e));
     if (const char *e = getenv("MI_MG_COARSEST"))
       mg->coarsest_reps = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_DENSE"))
+      mg->dense = atoi(e) != 0;
     if (const char *e = getenv("MI_MG_SAFETY"))
       mg->lmax_safety = std::max(1.0, atof(e));
     if (const char *e = getenv("MI_MG_POWER_ITS"))
@@ -448,6 +456,11 @@ namespace mi_detail
               return rc;
           }
       }
+    if (mg->dense && mg->levels.size() > 1 && mg->levels.back().ctx->n <= 96 && mg->levels.back().ctx->spmv_variant == 3)
+      {
+        MgLevel &L = mg->levels.back();
+        HIPCHK(c, hipMalloc((void **)&L.dense_inv, size_t(L.ctx->n) * size_t(L.ctx->n) * sizeof(double)));
+      }
     if (mg->block)
       for (MgLevel &L : mg->levels)
         L.ctx->want_dinv_blk = true; // filled by the next assembly of the level
@@ -504,8 +517,22 @@ namespace mi_detail
       }
     HIPCHK(c0, hipGetLastError());
     for (size_t l = 0; l < nl; ++l)
-      if ((rc = estimate_lmax(T, l)))
-        return rc;
+      {
+        if (l + 1 == nl && c0->mg->levels[l].dense_inv) // exact coarse solve: invert the level matrix instead
+          {
+            for (mi_ctx *m : T.members)
+              {
+                MgLevel &L = m->mg->levels[l];
+                refresh_sell(L.ctx);
+                mi::SellParams sp = sell_params(L.ctx, nullptr, nullptr, nullptr, nullptr, nullptr);
+                if (mi::launch_dense_inverse_from_sell(L.ctx->dim, sp, int(L.ctx->n), L.dense_inv, L.ctx->stream))
+                  return fail(c0, MI_EINVAL, "multigrid: coarsest level too large for the dense solve");
+              }
+            continue;
+          }
+        if ((rc = estimate_lmax(T, l)))
+          return rc;
+      }
     for (mi_ctx *m : T.members)
       m->mg_stale = false;
     return MI_OK;
@@ -653,7 +680,16 @@ namespace mi_detail
       const size_t nl  = mg0.levels.size();
       int          rc;
       if (l + 1 == nl)
-        return chebyshev(T, l, mg0.coarse_degree, mg0.coarse_ratio, true);
+        {
+          if (!mg0.levels[l].dense_inv)
+            return chebyshev(T, l, mg0.coarse_degree, mg0.coarse_ratio, true);
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel &L = m->mg->levels[l];
+              mi::launch_dense_apply(L.dense_inv, L.b(), L.x(), int(L.ctx->n), L.ctx->stream);
+            }
+          return MI_OK;
+        }
       const bool dist_l = is_dist(T, l), dist_c = is_dist(T, l + 1);
       const int  nu     = (l == 0) ? mg0.nu : mg0.nu_coarse;
       if ((rc = smooth(T, l, nu, true)))
