@@ -225,6 +225,50 @@ def test_element_tangent_product_matches_the_assembled_matrix(form):
         G.assemble()
 
 
+def test_matrix_free_product_in_one_launch_is_bitwise_the_coloured_update():
+    """mf_spmv in ONE launch (every cell stores into its own slots, mf_gather sums the slots of a node in processing
+    order) performs the additions of the colour-by-colour update of y in the same order: identical bits"""
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+    for amp in (0.05, 0.0):  # distorted cells (Jacobian per point) and axis-parallel boxes (precomputed geometry)
+        P, G = _pair(3, 2, (5, 4, 3), perturb_amp=amp, seed=31, roles=roles)
+        G.set_tuning("element_tangents", 2)
+        _randomise_state(P, G, seed=32)
+        G.update_acceleration()
+        G.assemble()
+        x = np.random.default_rng(33).standard_normal(G.n)
+        G.set_tuning("spmv_variant", 4)
+        assert G.get_tuning("mf_single_launch") == 1
+        y1 = G.spmv(x)
+        G.set_tuning("mf_single_launch", 0)
+        assert G.get_tuning("mf_single_launch") == 0
+        y0 = G.spmv(x)
+        assert np.array_equal(y0, y1)
+        G.set_tuning("spmv_variant", 3)
+        assert _relmax(y1, G.spmv(x)) < 1e-13
+
+
+def test_exact_coarsest_level_solve_against_the_polynomial(monkeypatch):
+    """the dense inverse on the coarsest multigrid level (2^3 cells) against round 1's degree-12 polynomial on a one-cell
+    level: a preconditioner at least as good (iterations) and the same converged solution"""
+    res = {}
+    for dense in (1, 0):
+        if not dense:
+            monkeypatch.setenv("MI_MG_DENSE", "0")
+            monkeypatch.setenv("MI_MG_COARSEST", "1")
+        G = M.Context(dim=3, degree=2, reps=(12, 10, 8))
+        G.set_tuning("precond", 1)
+        G.set_interface_traction((0.0, -2e3, 0.0))
+        G.newton_begin_step()
+        G.update_acceleration()
+        G.assemble()
+        rc, its, r = G.cg_solve(rel_tol=1e-10)
+        assert rc == 0
+        res[dense] = (its, G.get(M.V_NEWTON))
+        G.close()
+    assert res[1][0] <= res[0][0] + 1 and 0 < res[1][0] < 40
+    assert _relmax(res[1][1], res[0][1]) < 1e-8
+
+
 def test_smoother_operator_choice_only_changes_the_preconditioner():
     """multigrid-PCG with the smoother on the element tangents vs on the assembled matrix: the same operator up to
     rounding, so the same iteration counts and the same converged solution"""
