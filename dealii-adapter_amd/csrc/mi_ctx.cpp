@@ -235,6 +235,12 @@ namespace mi_detail
     return c->d_ke ? 1 : 0;
   }
 
+  bool mf_gather_fusable(const mi_ctx *c)
+  {
+    return element_form(c) == 2 && c->ebe == 2 && c->mf_slots && c->d_mf_yc && c->precond_storage == 64 &&
+           !c->active_sell_vals && c->d_dinv_blk;
+  }
+
   // y = K x on the owned rows (+ optional fused dot partials); x and y are whole local vectors.
   // part: 0 all rows, 1 interior rows only (no ghost columns: may run while the halo is in flight), 2 boundary rows
   void enqueue_spmv(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials, const int32_t *done,
@@ -246,7 +252,8 @@ namespace mi_detail
     // sliced-ELL copy of the tangent is never made)
     const int  kind       = element_form(c);
     const bool ebe_for_cg = dotv && c->cg_operator == 1 && kind && !c->active_sell_vals && !cheb;
-    if (ebe_for_cg || (kind && !cheb && !dotv && !c->active_sell_vals &&
+    const bool cheb_ok    = !cheb || (cheb->inplace && smoother && mf_gather_fusable(c));
+    if (ebe_for_cg || (kind && cheb_ok && !dotv && !c->active_sell_vals &&
                        (smoother ? (c->ebe != 0 && c->precond_storage == 64) : c->spmv_variant == 4)))
       {
         // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
@@ -286,7 +293,11 @@ namespace mi_detail
             const int t = sample ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
             mi::launch_mf_spmv(f, 0, int32_t(c->mesh.ncells), c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
                                t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
-            mi::launch_mf_gather(f, int64_t(c->mesh.nnodes) * 3, c->stream);
+            if (cheb) // the smoother's update / residual on the owned nodes, straight from the slots
+              mi::launch_mf_gather_cheb(f, cheb->b, cheb->dinv, cheb->d, const_cast<double *>(x), y, cheb->c1, cheb->c2,
+                                        c->own0 / 3, c->own_n / 3, c->stream);
+            else
+              mi::launch_mf_gather(f, int64_t(c->mesh.nnodes) * 3, c->stream);
           }
         else
         for (int col = 0; col < c->mesh.ncolours; ++col)

@@ -41,6 +41,8 @@ namespace mi_detail
     double       *d, *xout;
     double        c1, c2;
     int           blk = 0; // dinv = DxD blocks per node
+    int           inplace = 0; // matrix-free single-launch product only: the gather applies the step itself, x += d in
+                               // place (the product is complete by then); d == null: y = b - K x
   };
   struct LinearModel; // mi_linear.cpp
   struct Multigrid;   // mi_mg.cpp
@@ -170,6 +172,8 @@ namespace mi_detail
   void toc(mi_ctx *c, int id);
   int  sync(mi_ctx *c);
   void           refresh_sell(mi_ctx *c); // sliced-ELL copy of the current tangent, if stale
+  int            element_form(const mi_ctx *c); // 2 quadrature-point records, 1 element tangents, 0 none (current tangent)
+  bool           mf_gather_fusable(const mi_ctx *c); // the smoother's product is the single-launch matrix-free form
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,
                              const int32_t *done);
   // smoother: the product belongs to the multigrid preconditioner and may use the fp32-rounded copy of the values

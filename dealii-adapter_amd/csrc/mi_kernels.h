@@ -166,6 +166,9 @@ namespace mi
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);
+  // gather fused with the smoother's Chebyshev step (d != null: x += d in place) or residual (d == null: yres = b - K x)
+  void launch_mf_gather_cheb(const MfParams &p, const double *b, const double *dinv, double *d, double *xio, double *yres,
+                             double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);
   // coarsest multigrid level: dense inverse of the level's sliced-ELL matrix (n <= 96, -1 otherwise) and its application
   int  launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s);
   void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s);

@@ -2417,6 +2417,56 @@ namespace mi
     prm.y[g] = s;
   }
 
+  // the same sum fused with its consumer in the multigrid smoother: q = (K x) from the slots, then the Chebyshev step
+  // with the 3x3 block-Jacobi diagonal, d = c1 d + c2 D^-1 (b - q), x += d (in place: the product is complete), or,
+  // with d == null, the residual y = b - q.  One thread per DOF of the nodes [node0, node0 + nnodes), 64 nodes per block.
+  __global__ __launch_bounds__(192) void mf_gather_cheb(MfParams prm, const double *__restrict__ b,
+                                                        const double *__restrict__ dinv, double *d, double *xio, double *yres,
+                                                        double c1, double c2, int64_t node0, int64_t nnodes)
+  {
+    __shared__ double s_res[192];
+    const int     ld = threadIdx.x;
+    const int64_t nl = int64_t(blockIdx.x) * 64 + ld / 3;
+    const bool    in = nl < nnodes;
+    const int64_t n  = node0 + nl;
+    const int     c  = ld % 3;
+    const int64_t g  = n * 3 + c;
+    double        res = 0.0;
+    if (in)
+      {
+        double q;
+        if ((prm.cmask[n] >> c) & 1)
+          q = prm.vals[int64_t(prm.diagpos[n]) * 9 + c * 4] * prm.x[g];
+        else
+          {
+            const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
+            q                = prm.yc[int64_t(b0) * 3 + c];
+            for (int32_t k = b0 + 1; k < b1; ++k)
+              q = q + prm.yc[int64_t(k) * 3 + c];
+          }
+        res = b[g] - q;
+      }
+    if (!d)
+      {
+        if (in)
+          yres[g] = res;
+        return;
+      }
+    s_res[ld] = res;
+    __syncthreads();
+    if (!in)
+      return;
+    const int    r0 = (ld / 3) * 3;
+    const double a0 = dinv[g * 3], a1 = dinv[g * 3 + 1], a2 = dinv[g * 3 + 2];
+    double       s  = 0.0;
+    s += a0 * s_res[r0];
+    s += a1 * s_res[r0 + 1];
+    s += a2 * s_res[r0 + 2];
+    const double dn = (c1 != 0.0 ? c1 * d[g] : 0.0) + c2 * s;
+    d[g]            = dn;
+    xio[g]          = xio[g] + dn;
+  }
+
   // block-CSR -> sliced-ELL copy of the values (after every assembly); one wavefront per slice
   template <int D>
   __global__ __launch_bounds__(256) void bsr_to_sell(SellParams prm, const int32_t *__restrict__ rowptr,
@@ -3674,6 +3724,14 @@ namespace mi
     hipLaunchKernelGGL(dense_apply, dim3(1), dim3(128), 0, s, inv, b, x, n);
   }
 
+  void launch_mf_gather_cheb(const MfParams &p, const double *b, const double *dinv, double *d, double *xio, double *yres,
+                             double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s)
+  {
+    if (nnodes <= 0)
+      return;
+    hipLaunchKernelGGL(mf_gather_cheb, dim3(int((nnodes + 63) / 64)), dim3(192), 0, s, p, b, dinv, d, xio, yres, c1, c2,
+                       node0, nnodes);
+  }
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s)
   {
     hipLaunchKernelGGL(mf_gather, dim3(int((ndofs + 255) / 256)), dim3(256), 0, s, p, ndofs);

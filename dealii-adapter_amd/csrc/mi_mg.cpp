@@ -580,6 +580,22 @@ namespace mi_detail
               c2               = 2.0 * rho / delta;
               rho_old          = rho;
             }
+          // level 0 with the single-launch matrix-free product: the gather of the product applies this step itself
+          bool mf_fused = !skip_spmv && l == 0 && T.members[0]->mg->block;
+          for (mi_ctx *m : T.members)
+            mf_fused = mf_fused && mf_gather_fusable(m);
+          if (mf_fused)
+            {
+              std::vector<ChebFusion> cf;
+              for (mi_ctx *m : T.members)
+                {
+                  MgLevel &L = m->mg->levels[l];
+                  cf.push_back(ChebFusion{L.b(), L.ctx->d_dinv_blk, L.d(), nullptr, c1, c2, 1, 1});
+                }
+              if ((rc = level_spmv(T, l, x_of, cf.data())))
+                return rc;
+              continue;
+            }
           bool fused = !skip_spmv && fuse_level(T, l);
           if (fused)
             {
@@ -699,7 +715,18 @@ namespace mi_detail
       auto ctx_l  = [l](mi_ctx *m) { return m->mg->levels[l].ctx; };
       auto ctx_c  = [l](mi_ctx *m) { return m->mg->levels[l + 1].ctx; };
       auto xc_of  = [l](mi_ctx *m) { return m->mg->levels[l + 1].x(); };
-      if (fuse_level(T, l))
+      bool mf_fused = l == 0;
+      for (mi_ctx *m : T.members)
+        mf_fused = mf_fused && mf_gather_fusable(m);
+      if (mf_fused)
+        {
+          std::vector<ChebFusion> cf; // the gather of the matrix-free product writes q = b - A x on the owned rows
+          for (mi_ctx *m : T.members)
+            cf.push_back(ChebFusion{m->mg->levels[l].b(), nullptr, nullptr, nullptr, 0.0, 0.0, 0, 1});
+          if ((rc = level_spmv(T, l, x_of, cf.data())))
+            return rc;
+        }
+      else if (fuse_level(T, l))
         {
           std::vector<ChebFusion> cf; // residual mode of the fused epilogue: q = b - A x on the owned rows
           for (mi_ctx *m : T.members)
