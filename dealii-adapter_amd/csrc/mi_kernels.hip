@@ -1107,57 +1107,75 @@ namespace mi
                   }
           }
         __syncthreads(); // (3) image complete
-        // ---- tangent scatter, one thread per node-pair block.  [DEAL.II distribute_local_to_global] constrained
-        // rows/cols are dropped, the diagonal of a constrained dof receives |K_e(i,i)|.
+        // ---- tangent scatter, one thread per node-pair block (two blocks for the first 122 threads).  [DEAL.II
+        // distribute_local_to_global] constrained rows/cols are dropped, the diagonal of a constrained dof receives
+        // |K_e(i,i)|.  The old values of BOTH blocks are requested before anything is stored: one round trip, not two.
         const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
-        for (int blk = tid; blk < EBE_NBLK; blk += 256)
+        constexpr int NB = 2;
+        int           sa[NB], sb[NB], sma[NB], smb[NB];
+        bool          act[NB], fab[NB], fba[NB];
+        double       *pab[NB], *pba[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u)
           {
-            int a = int((sqrtf(8.0f * float(blk) + 1.0f) - 1.0f) * 0.5f);
+            const int blk = tid + u * 256;
+            act[u]        = blk < EBE_NBLK;
+            int a         = int((sqrtf(8.0f * float(blk) + 1.0f) - 1.0f) * 0.5f);
             while ((a + 1) * (a + 2) / 2 <= blk)
               ++a;
             while (a * (a + 1) / 2 > blk)
               --a;
-            const int     b = blk - a * (a + 1) / 2;
-            const int32_t A = s_conn[a], B = s_conn[b];
-            const int     ma = prm.cmask[A], mb = prm.cmask[B];
+            a                  = act[u] ? a : 0;
+            const int     b    = act[u] ? blk - a * (a + 1) / 2 : 0;
+            const int32_t A    = s_conn[a], B = s_conn[b];
             const uint16_t oab = offc[a * NPC + b], oba = offc[b * NPC + a];
-            double *__restrict__ pab = prm.vals + (int64_t(prm.rowptr[A]) + (oab & 0x7fff)) * 9;
-            double *__restrict__ pba = prm.vals + (int64_t(prm.rowptr[B]) + (oba & 0x7fff)) * 9;
-            const bool first_ab = oab >> 15, first_ba = oba >> 15; // first touch in processing order: plain store
-            double     vab[9], vba[9];
+            sa[u]              = a;
+            sb[u]              = b;
+            sma[u]             = prm.cmask[A];
+            smb[u]             = prm.cmask[B];
+            pab[u]             = prm.vals + (int64_t(prm.rowptr[A]) + (oab & 0x7fff)) * 9;
+            pba[u]             = prm.vals + (int64_t(prm.rowptr[B]) + (oba & 0x7fff)) * 9;
+            fab[u]             = oab >> 15; // first touch in processing order: plain store
+            fba[u]             = oba >> 15;
+          }
+        double oab_[NB][9], oba_[NB][9];
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+        for (int u = 0; u < NB; ++u)
 #pragma unroll
-              for (int j = 0; j < 3; ++j)
-                {
-                  double v = s_C[(i * 3 + j) * EBE_NBLK + blk];
-                  if (((ma >> i) | (mb >> j)) & 1)
-                    v = (a == b && i == j) ? fabs(v) : 0.0;
-                  vab[i * 3 + j] = v;
-                  vba[j * 3 + i] = v;
-                }
-            if (prm.ke) // the cell's own masked block, before it is summed into the global matrix
+          for (int k = 0; k < 9; ++k)
+            {
+              oab_[u][k] = (act[u] && !fab[u]) ? pab[u][k] : 0.0;
+              oba_[u][k] = (act[u] && !fba[u] && sa[u] != sb[u]) ? pba[u][k] : 0.0;
+            }
 #pragma unroll
-              for (int k = 0; k < 9; ++k)
-                s_C[k * EBE_NBLK + blk] = vab[k];
-            if (!first_ab)
+        for (int u = 0; u < NB; ++u)
+          if (act[u])
+            {
+              const int blk = tid + u * 256, a = sa[u], b = sb[u], ma = sma[u], mb = smb[u];
+              double    vab[9], vba[9];
 #pragma unroll
-              for (int k = 0; k < 9; ++k)
-                vab[k] += pab[k];
+              for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int k = 0; k < 9; ++k)
-              pab[k] = vab[k];
-            if (a != b)
-              {
-                if (!first_ba)
-#pragma unroll
-                  for (int k = 0; k < 9; ++k)
-                    vba[k] += pba[k];
+                for (int j = 0; j < 3; ++j)
+                  {
+                    double v = s_C[(i * 3 + j) * EBE_NBLK + blk];
+                    if (((ma >> i) | (mb >> j)) & 1)
+                      v = (a == b && i == j) ? fabs(v) : 0.0;
+                    vab[i * 3 + j] = v;
+                    vba[j * 3 + i] = v;
+                  }
+              if (prm.ke) // the cell's own masked block, before it is summed into the global matrix
 #pragma unroll
                 for (int k = 0; k < 9; ++k)
-                  pba[k] = vba[k];
-              }
-          }
+                  s_C[k * EBE_NBLK + blk] = vab[k];
+#pragma unroll
+              for (int k = 0; k < 9; ++k)
+                pab[u][k] = vab[k] + oab_[u][k];
+              if (a != b)
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+                  pba[u][k] = vba[k] + oba_[u][k];
+            }
         if (prm.ke)
           {
             __syncthreads();
