@@ -4,6 +4,7 @@
 #include <sys/stat.h>
 
 #include <cerrno>
+#include <cstdlib>
 #include <iostream>
 #include <string>
 #include <thread>
@@ -27,6 +28,9 @@ int main(int argc, char **argv)
   try
     {
       const unsigned int n_threads = 1; // host side is single threaded; the parallelism is on the device
+      // decomposed run (mi/device_vector.h): every rank executes the same program on global views; rank 0 speaks
+      if (mi::host_rank() > 0)
+        std::cout.setstate(std::ios_base::badbit);
 
       const std::string adapter_info =
         GIT_SHORTREV == std::string("") ? "unknown" : (GIT_SHORTREV + std::string(" on branch ") + GIT_BRANCH);
@@ -39,6 +43,10 @@ int main(int argc, char **argv)
                 << "--     . running with " << n_threads << " thread" << (n_threads == 1 ? "" : "s") << std::endl;
       std::cout << "--     . adapter revision " << adapter_info << std::endl;
       std::cout << "--     . device " << device_info << " (DIM=" << DIM << ")" << std::endl;
+      if (mi::host_world_size() > 1)
+        std::cout << "--     . " << mi::host_world_size() << " processes, one z-slab and one GPU each (RCCL)" << std::endl;
+      else if (std::getenv("MI_SLABS") && std::atoi(std::getenv("MI_SLABS")) > 1)
+        std::cout << "--     . " << std::atoi(std::getenv("MI_SLABS")) << " z-slabs emulated on one GPU" << std::endl;
       std::cout << "-----------------------------------------------------------------------------" << std::endl
                 << std::endl;
 

@@ -27,6 +27,7 @@
 #else
 
 #include <cmath>
+#include <cstdlib>
 #include <cstddef>
 #include <fstream>
 #include <iomanip>
@@ -61,6 +62,13 @@ namespace precice
     T          *p_;
     std::size_t n_;
   };
+
+  // rank of this process in a decomposed run of the executables (mi/device_vector.h): ranks > 0 write no files
+  inline int quiet_rank()
+  {
+    const char *w = std::getenv("MI_WORLD_SIZE"), *r = std::getenv("MI_RANK");
+    return (w && std::atoi(w) > 1 && r) ? std::atoi(r) : 0;
+  }
 
   class Participant
   {
@@ -175,7 +183,7 @@ namespace precice
       positions_.assign(positions.data(), positions.data() + positions.size());
       for (std::size_t i = 0; i < ids.size(); ++i)
         ids[i] = int(i);
-      if (!vertices_file_.empty())
+      if (!vertices_file_.empty() && quiet_rank() == 0)
         {
           std::ofstream vf(vertices_file_);
           vf << "# vertex x y" << (dims_ == 3 ? " z" : "") << "\n" << std::setprecision(17);
@@ -207,7 +215,8 @@ namespace precice
       need_write_cp_ = implicit_;
       if (!log_file_.empty())
         {
-          log_.open(log_file_);
+          if (quiet_rank() == 0) // decomposed runs: every rank replays the same partner, rank 0 keeps the log
+            log_.open(log_file_);
           log_ << "# replay participant for " << name_ << ": t, then " << n_vertices_ * dims_
                << " written values per completed window\n";
         }

@@ -4,15 +4,37 @@
 // device-resident global vector.  Copy-assignment copies device-to-device, so the Adapter's checkpoint code
 // (`old_state_data[i] = *state_variables[i]`, adapter.h:457-460) keeps its shape while the data never leaves HBM.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "mi_elasticity.h"
 
 namespace mi
 {
+  // Decomposition of the executables, taken from the environment (the reference is single-rank, adapter.h:152-154):
+  //   MI_SLABS=N                                   N z-slabs inside this process on one GPU (emulation; tests)
+  //   MI_WORLD_SIZE=N MI_RANK=r MI_UID_FILE=path   one process per GPU over RCCL (tools/launch_elasticity.py sets them
+  //   [MI_LOCAL_RANK=d]                            and starts the N processes); rank 0 creates the RCCL id and leaves
+  //                                                it in the file, the others wait for it; device = local rank
+  // Every rank holds the whole interface and global views of the vectors (the library gathers them), so the Adapter
+  // and the solvers above run unchanged on every rank; ranks > 0 keep quiet and write no files.
+  inline int host_world_size()
+  {
+    const char *e = std::getenv("MI_WORLD_SIZE");
+    return e ? std::max(1, std::atoi(e)) : 1;
+  }
+  inline int host_rank()
+  {
+    const char *e = std::getenv("MI_RANK");
+    return (e && host_world_size() > 1) ? std::atoi(e) : 0;
+  }
   struct Error : std::runtime_error
   {
     int code;
@@ -27,7 +49,37 @@ namespace mi
   public:
     Device(const mi_mesh_desc &mesh, const mi_material_desc &mat, const mi_newmark_desc &nm, int device_id = 0)
     {
-      const int rc = mi_ctx_create(&mesh, &mat, &nm, device_id, nullptr, &ctx_);
+      mi_comm_desc  comm;
+      mi_comm_desc *use = nullptr;
+      std::memset(&comm, 0, sizeof(comm));
+      const int world = host_world_size();
+      if (world > 1)
+        {
+          comm.rank = host_rank();
+          comm.size = world;
+          if (comm.rank < 0 || comm.rank >= world)
+            throw Error(MI_EINVAL, "MI_RANK outside [0, MI_WORLD_SIZE)");
+          const char *file = std::getenv("MI_UID_FILE");
+          if (!file)
+            throw Error(MI_EINVAL, "MI_WORLD_SIZE > 1 needs MI_UID_FILE (see tools/launch_elasticity.py)");
+          exchange_unique_id(file, comm.rank, uid_);
+          comm.nccl_unique_id = uid_;
+          if (const char *e = std::getenv("MI_LOCAL_RANK"))
+            device_id = std::atoi(e);
+          else
+            device_id = comm.rank;
+          use = &comm;
+        }
+      else if (const char *e = std::getenv("MI_SLABS"))
+        {
+          if (std::atoi(e) > 1)
+            {
+              comm.rank = -1; // all slabs in this process
+              comm.size = std::atoi(e);
+              use       = &comm;
+            }
+        }
+      const int rc = mi_ctx_create(&mesh, &mat, &nm, device_id, use, &ctx_);
       if (rc != MI_OK)
         throw Error(rc, std::string("mi_ctx_create: ") + mi_last_error(nullptr));
     }
@@ -43,7 +95,39 @@ namespace mi
     }
 
   private:
-    mi_ctx *ctx_ = nullptr;
+    // rank 0 writes the 128-byte RCCL id (to a temporary name, then renamed: never seen half written), the others
+    // poll for it for up to two minutes
+    static void exchange_unique_id(const std::string &file, int rank, unsigned char *uid)
+    {
+      const size_t nb = 128;
+      if (rank == 0)
+        {
+          if (mi_comm_unique_id(uid) != MI_OK)
+            throw Error(MI_EINVAL, std::string("mi_comm_unique_id: ") + mi_last_error(nullptr));
+          const std::string tmp = file + ".tmp";
+          std::FILE        *f   = std::fopen(tmp.c_str(), "wb");
+          if (!f || std::fwrite(uid, 1, nb, f) != nb)
+            throw Error(MI_EINVAL, "cannot write " + tmp);
+          std::fclose(f);
+          if (std::rename(tmp.c_str(), file.c_str()))
+            throw Error(MI_EINVAL, "cannot rename " + tmp);
+          return;
+        }
+      for (int tries = 0; tries < 2400; ++tries)
+        {
+          if (std::FILE *f = std::fopen(file.c_str(), "rb"))
+            {
+              const size_t got = std::fread(uid, 1, nb, f);
+              std::fclose(f);
+              if (got == nb)
+                return;
+            }
+          std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+      throw Error(MI_EINVAL, "no RCCL id in " + file + " after two minutes (is rank 0 running?)");
+    }
+    mi_ctx       *ctx_ = nullptr;
+    unsigned char uid_[128] = {0};
   };
 
   class Vector

@@ -119,7 +119,8 @@ namespace Linear_Elasticity
     const unsigned int interval = parameters.output_interval > 0 ? parameters.output_interval : 1;
     std::ostringstream name;
     name << "solution-" << std::setw(3) << std::setfill('0') << time.get_timestep() / interval << ".vtk";
-    mi::write_vtk(*device, dim, int(parameters.poly_degree), mesh_desc.reps, parameters.output_folder + "/" + name.str());
+    if (mi::host_rank() == 0)
+      mi::write_vtk(*device, dim, int(parameters.poly_degree), mesh_desc.reps, parameters.output_folder + "/" + name.str());
     timer.leave_subsection("Output results");
   }
 

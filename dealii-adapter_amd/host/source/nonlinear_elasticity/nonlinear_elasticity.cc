@@ -333,6 +333,8 @@ namespace Nonlinear_Elasticity
   template <int dim>
   void Solid<dim>::log_step_json() const
   {
+    if (mi::host_rank() > 0)
+      return;
     std::ofstream out(parameters.output_folder + "/steps.jsonl", std::ios::app);
     if (!out)
       return;
@@ -350,7 +352,8 @@ namespace Nonlinear_Elasticity
     const unsigned int interval = parameters.output_interval > 0 ? parameters.output_interval : 1;
     std::ostringstream name;
     name << "solution-" << std::setw(3) << std::setfill('0') << time.get_timestep() / interval << ".vtk";
-    mi::write_vtk(*device, dim, int(degree), mesh_desc.reps, parameters.output_folder + "/" + name.str());
+    if (mi::host_rank() == 0)
+      mi::write_vtk(*device, dim, int(degree), mesh_desc.reps, parameters.output_folder + "/" + name.str());
     std::cout << "\t Output written to " << name.str() << " \n" << std::endl;
     timer.leave_subsection("Output results");
   }

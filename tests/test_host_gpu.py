@@ -24,10 +24,11 @@ CASES = os.path.join(ROOT, "tests", "cases")
 TOL = 1e-8
 
 
-def _run_case(name, exe, tmp_path):
+def _run_case(name, exe, tmp_path, env=None):
     for f in ("parameters.prm", "precice-config.xml"):
         (tmp_path / f).write_text(open(os.path.join(CASES, name, f)).read())
-    out = subprocess.run([os.path.join(HOST, exe)], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([os.path.join(HOST, exe)], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, **env) if env else None)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     rows = [np.array(l.split(), dtype=float) for l in open(tmp_path / "displacement.log") if not l.startswith("#")]
     return out.stdout, rows
@@ -197,6 +198,33 @@ def test_executable_nonlinear_3d(tmp_path, name, windows, traction):
     if name == "block_neo_3d_q2":
         _check_vtk(tmp_path / "out" / "solution-000.vtk", P, zero=True)
         _check_vtk(tmp_path / "out" / "solution-001.vtk", P, zero=False)  # timestep 2 / Output interval 2
+
+
+def test_executable_on_emulated_slabs(tmp_path):
+    """the decomposition reaches the executables through the environment (mi/device_vector.h): MI_SLABS=2 cuts the block
+    into two z-slabs inside one process; same banner plus the decomposition line, same displacement log and VTK output as
+    the undecomposed run to the linear tolerance.  (One process per GPU over RCCL -- tools/launch_elasticity.py, MI_RANK /
+    MI_WORLD_SIZE / MI_UID_FILE -- takes the same path in mi::Device and cannot run on a single-GPU box.)"""
+    (tmp_path / "one").mkdir()
+    (tmp_path / "two").mkdir()
+    out1, rows1 = _run_case("block_neo_3d_q2", "elasticity3d", tmp_path / "one")
+    out2, rows2 = _run_case("block_neo_3d_q2", "elasticity3d", tmp_path / "two", env={"MI_SLABS": "2"})
+    assert "2 z-slabs emulated on one GPU" in out2 and "z-slabs" not in out1
+    assert len(rows1) == len(rows2) > 0
+    for a, b in zip(rows1, rows2):
+        assert a[0] == b[0] and np.abs(a[1:] - b[1:]).max() <= 1e-9 * np.abs(a[1:]).max()
+    v1 = open(tmp_path / "one" / "out" / "solution-001.vtk").read().split()
+    v2 = open(tmp_path / "two" / "out" / "solution-001.vtk").read().split()
+    assert len(v1) == len(v2)
+
+
+def test_launcher_rank_environment_is_validated(tmp_path):
+    """MI_WORLD_SIZE without the id file: the executable refuses loudly instead of running undecomposed"""
+    for f in ("parameters.prm", "precice-config.xml"):
+        (tmp_path / f).write_text(open(os.path.join(CASES, "block_neo_3d_q2", f)).read())
+    out = subprocess.run([os.path.join(HOST, "elasticity3d")], cwd=tmp_path, capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, MI_WORLD_SIZE="2", MI_RANK="0"))
+    assert out.returncode == 1 and "MI_UID_FILE" in out.stderr
 
 
 def _check_vtk(path, P, zero):
