@@ -262,12 +262,23 @@ namespace mi_detail
               HIPCHK(c, hipMemcpyAsync(L.ev(), h.data(), size_t(n) * sizeof(double), hipMemcpyHostToDevice, c->stream));
               HIPCHK(c, hipStreamSynchronize(c->stream)); // h goes out of scope
               L.ev_ready = true;
-              its        = mg0.power_its + 1; // the first pass only normalises
+              its        = -1; // first estimate: iterate until the estimate has settled (below)
             }
         }
       double lam = 0.0;
       int    rc;
       auto   ev_of = [l](mi_ctx *m) { return m->mg->levels[l].ev(); };
+      // The estimate |D^-1 A v| of a normalised v grows monotonically towards lambda_max.  A FIRST estimate runs until
+      // three consecutive iterations each add less than 0.1 % (at least power_its, at most 300): a fixed count of 15 was
+      // enough up to 28 M dofs but stopped 20 % short at 42 M (the top of the spectrum is a cluster that the iteration
+      // enters late), and a Chebyshev smoother built on an interval that ends below lambda_max amplifies the modes
+      // above it -- the preconditioned CG then crawls (found in round 2 on the 120^3 mesh).  Refreshes continue from
+      // the previous eigenvector with power_its_update iterations.
+      const bool first = its < 0;
+      if (first)
+        its = 300;
+      double prev = 0.0;
+      int    calm = 0;
       for (int it = 0; it < its; ++it)
         {
           if ((rc = level_spmv(T, l, ev_of)))
@@ -299,6 +310,15 @@ namespace mi_detail
           if (!(nw > 0.0) || !std::isfinite(nw))
             return fail(c0, MI_EINVAL, "multigrid: power iteration broke down on level %d", int(l));
           lam = nw;
+          if (getenv("MI_MG_VERBOSE"))
+            fprintf(stderr, "mg level %d power iteration %d: |D^-1 A v| = %.6f\n", int(l), it, nw);
+          if (first && it >= 1) // iteration 0 only normalises the start vector
+            {
+              calm = (nw <= prev * 1.001) ? calm + 1 : 0;
+              if (calm >= 3 && it >= mg0.power_its)
+                its = it + 1; // settled: this was the last iteration (v is still normalised below)
+            }
+          prev = nw;
           for (mi_ctx *m : T.members)
             {
               MgLevel &L = m->mg->levels[l];
