@@ -1,12 +1,13 @@
 """Convergence of the preconditioned CG on a big mesh, with capped iterations:
-python tools/big_mesh_phases.py <cells> [key=value ...]   (environment switches of the library apply)"""
+python tools/big_mesh_phases.py <cells | nx,ny,nz> [key=value ...]   (environment switches of the library apply; SLABS=N)"""
 import sys, time, os
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from bench import _pkg
 M = _pkg()
-n = int(sys.argv[1])
-G = M.Context(dim=3, degree=2, reps=(n, n, n))
+reps = tuple(int(v) for v in sys.argv[1].split(",")) if "," in sys.argv[1] else (int(sys.argv[1]),) * 3
+slabs = int(os.environ.get("SLABS", "1"))
+G = M.Context(dim=3, degree=2, reps=reps, hi=tuple(r / max(reps) for r in reps), slabs=slabs)
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     G.set_tuning(k, int(v))
