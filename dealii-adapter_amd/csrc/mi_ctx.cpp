@@ -1481,14 +1481,32 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   mi_ctx    *c0     = c->team->members[0];
   const bool x_zero = c0->newton_update_is_zero;
   c0->newton_update_is_zero = false;
-  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, max_it, its, res, x_zero);
+  // A multigrid-preconditioned solve needs 7-15 iterations; one that has not converged after 300 has stalled, and
+  // iterating on to max_it (dofs x multiplier, i.e. millions) would be a hang in all but name.
+  const bool    mg     = mg_active(c);
+  const int64_t mg_cap = mg ? std::min<int64_t>(max_it, 300) : max_it;
+  int           my_its = 0;
+  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, mg_cap, &my_its, res, x_zero);
   // a breakdown (NaN state, indefinite tangent) is final, as with deal.II's SolverControl: no second attempt from a
   // poisoned iterate
-  const bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
-  if (rc == MI_ENOCONV_LIN && mg_active(c) && !broke)
+  bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
+  if (rc == MI_ENOCONV_LIN && mg && !broke && my_its < max_it)
     {
-      // safety net: should the V-cycle ever stall (e.g. an eigenvalue bound gone stale under a violent state
-      // change), continue from the current iterate with the Jacobi preconditioner instead of giving up
+      // first suspect: a smoother interval that ends below lambda_max (its modes are amplified).  Estimate the
+      // eigenvalues of every level from scratch and continue from the current iterate.
+      mg_reset_estimates(*c->team);
+      int more = 0;
+      rc       = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, std::min<int64_t>(max_it - my_its, mg_cap), &more, res);
+      my_its += more;
+      broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
+    }
+  if (its)
+    *its = my_its;
+  if (rc == MI_ENOCONV_LIN && mg && !broke && my_its < max_it)
+    {
+      // safety net: should the V-cycle still stall, continue from the current iterate with the Jacobi preconditioner
+      // instead of giving up
+      max_it -= my_its;
       const int done_its = its ? *its : 0;
       for (mi_ctx *m : c->team->members)
         m->precond = 0;
@@ -1840,6 +1858,11 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
             }
           m->ebe      = value;
           m->ke_valid = false;
+        }
+      else if (k == "mg_scale_lmax_percent" && value >= 10 && value <= 400) // tests: spoil the eigenvalue estimates once
+        {
+          if (m == c->team->members[0])
+            mg_scale_estimates(*c->team, 0.01 * value);
         }
       else if (k == "mf_single_launch" && (value == 0 || value == 1))
         m->mf_slots = value;

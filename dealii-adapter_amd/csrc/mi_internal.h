@@ -192,7 +192,9 @@ namespace mi_detail
   int  enqueue_assembly(mi_ctx *c, bool residual_only = false);
   int  ensure_element_tangents(mi_ctx *c);
   // multigrid (mi_mg.cpp)
-  int  mg_setup(mi_ctx *c); // build the level hierarchy of a slab (once)
+  int  mg_setup(mi_ctx *c);
+  void mg_reset_estimates(Team &T); // eigenvalue estimates of all levels from scratch at the next operator update
+  void mg_scale_estimates(Team &T, double f); // tests: spoil the current estimates // build the level hierarchy of a slab (once)
   void mg_destroy(mi_ctx *c);
   int  mg_update(Team &T);  // re-assemble the coarse operators for the current state (team-wide)
   int  mg_apply(Team &T);   // W_Z = V-cycle(W_R) on every slab of the team (team-wide, collective)

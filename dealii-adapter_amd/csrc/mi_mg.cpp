@@ -332,6 +332,27 @@ namespace mi_detail
     }
   } // namespace
 
+  // forget the eigenvalue estimates of every level: the next operator update estimates them from scratch
+  void mg_reset_estimates(Team &T)
+  {
+    for (mi_ctx *m : T.members)
+      if (m->mg)
+        {
+          for (MgLevel &L : m->mg->levels)
+            L.ev_ready = false;
+          m->mg_stale = m->mg_force = true;
+        }
+  }
+
+  // tests: scale the current estimates (a factor < 1 reproduces a smoother interval that ends below lambda_max)
+  void mg_scale_estimates(Team &T, double f)
+  {
+    for (mi_ctx *m : T.members)
+      if (m->mg)
+        for (MgLevel &L : m->mg->levels)
+          L.lmax *= f;
+  }
+
   int mg_set_storage(mi_ctx *c, int bits)
   {
     if (!c->mg)

@@ -269,6 +269,30 @@ def test_exact_coarsest_level_solve_against_the_polynomial(monkeypatch):
     assert _relmax(res[1][1], res[0][1]) < 1e-8
 
 
+def test_stalled_multigrid_solve_heals_itself():
+    """a smoother interval that ends below lambda_max amplifies the top modes and the preconditioned CG crawls (what
+    happened on the 120^3 mesh with a 15-iteration eigenvalue estimate).  mi_cg_solve gives a multigrid solve 300
+    iterations, then estimates the eigenvalues of every level from scratch and continues: the solve ends converged
+    instead of iterating on to dofs x multiplier"""
+    G = M.Context(dim=3, degree=2, reps=(12, 12, 12))
+    G.set_tuning("precond", 1)
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    G.newton_begin_step()
+    G.update_acceleration()
+    G.assemble()
+    rc, its_ok, _ = G.cg_solve(rel_tol=1e-10)
+    assert rc == 0 and its_ok < 40
+    x_ok = G.get(M.V_NEWTON)
+    G.set(M.V_NEWTON, np.zeros(G.n))
+    G.set_tuning("mg_scale_lmax_percent", 45)  # spoil the estimates: Chebyshev on [.., 0.45 lambda_max]
+    rc, its, _ = G.cg_solve(rel_tol=1e-10)
+    assert rc == 0 and 300 < its < 300 + 3 * its_ok + 10, its
+    assert _relmax(G.get(M.V_NEWTON), x_ok) < 1e-7
+    G.set(M.V_NEWTON, np.zeros(G.n))
+    rc, its, _ = G.cg_solve(rel_tol=1e-10)  # healed for good
+    assert rc == 0 and abs(its - its_ok) <= 2
+
+
 def test_smoother_operator_choice_only_changes_the_preconditioner():
     """multigrid-PCG with the smoother on the element tangents vs on the assembled matrix: the same operator up to
     rounding, so the same iteration counts and the same converged solution"""
