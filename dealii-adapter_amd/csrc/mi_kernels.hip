@@ -1186,377 +1186,6 @@ namespace mi
       }
   }
 
-  // ------------------------------------------------------------------ cell assembly by sum factorisation (3D Q2)
-  // Same element tangent and residual as assemble_cells, different arithmetic.  With g_a = M^T grad_xi N_a every term
-  // of K_ab is a bilinear form in the UNIT-CELL gradients:
-  //   K_ab^{ij} = sum_q sum_{kl} d_k N_a(q) C^{ij}_{kl}(q) d_l N_b(q)  +  delta_ij sum_q N_a N_b mu(q),
-  //   C^{ij}_{kl} = w[(c_II M_ki + Tm_ki) M_lj + M_ki Tm_lj + (c_S/2) M_kj M_li] + delta_ij S_kl,
-  //   Tm = -(2/d) M tau_iso,  S = w (c_S/2 M M^T + M tau M^T),  mu = alpha_1 rho w,
-  // and N_a(q) = N_a1(q1) N_a2(q2) N_a3(q3), so the sum over the 64 points is contracted one lattice direction at a
-  // time: T1[a1 b1; q2 q3] -> T2[a1 b1 a2 b2; q3] -> K[a b].  Per (i,j) and (k,l) that is 576 + 1296 + 2916 FMAs
-  // instead of 729 x 64 x 3: 0.39 M FMAs per cell instead of 1.1 M.
-  // One workgroup per cell; the 9 (i,j) pairs are phases; thread (a1 b1 a2 b2, a3) accumulates the three blocks
-  // (a, b3 = 0..2) in registers and scatters them exactly like assemble_cells (first touch store / later RMW,
-  // constrained rows and columns dropped, |K_e(i,i)| on constrained diagonals).
-  // STATUS (mi_set_tuning "asm_variant" 5, not the default): agrees with assemble_cells to 1e-15, but takes 20.2 ms
-  // per assembly at 5 M dofs against 16.2 ms.  It needs a third of the FMAs and twice the LDS traffic (about 2,300
-  // doubles per lane and cell against 1,216: ~1.2 FMAs per LDS double where the CU balances at 4), i.e. it is LDS
-  // bound.  The next step is register blocking of the three stages (all nine (a3,b3) per T2 value, several (i,j)
-  // phases in flight) -- see DESIGN.md section 8.
-  constexpr int RQ2 = 25; // extra per-point record: Tm[9], S[6] (xx yy zz xy xz yz), R[9] = w M tau; odd stride
-  constexpr int RQS = 33; // stride of the per-point records in this kernel: odd, so that lane-per-point reads are conflict free
-  __global__ __launch_bounds__(256) void assemble_cells_sf(AsmParams prm)
-  {
-    constexpr int DIM = 3, P = 2, NT = 256;
-    using E = Elem<DIM, P>;
-    constexpr int NPC = E::NPC, NQ = E::NQ, NQ1 = E::NQ1, NP1 = E::NP1, DD = E::DD, NV = E::NV;
-    constexpr int NC = 10; // (k,l) combinations + the mass term
-
-    __shared__ double s_N1[NQ1 * NP1], s_dN1[NQ1 * NP1], s_qw[NQ1], s_qx[NQ1];
-    __shared__ double s_u[NPC * 3], s_a[NPC * 3], s_verts[NV * DIM];
-    __shared__ int    s_conn[NPC];
-    __shared__ double s_qp[NQ * RQS];
-
-    const int     tid  = threadIdx.x;
-    const int64_t cell = prm.cell_begin + blockIdx.x;
-
-    // ---- stage tables, connectivity, vertices, gathered u_total and acceleration
-    for (int i = tid; i < NQ1 * NP1; i += NT)
-      {
-        s_N1[i]  = prm.tab1d[i];
-        s_dN1[i] = prm.tab1d[NQ1 * NP1 + i];
-      }
-    if (tid < NQ1)
-      {
-        s_qw[tid] = prm.tab1d[2 * NQ1 * NP1 + tid];
-        s_qx[tid] = prm.tab1d[2 * NQ1 * NP1 + NQ1 + tid];
-      }
-    if (tid < NPC)
-      s_conn[tid] = prm.conn[cell * NPC + tid];
-    if (tid < NV * DIM)
-      s_verts[tid] = prm.cverts[cell * (NV * DIM) + tid];
-    __syncthreads();
-    for (int i = tid; i < NPC * 3; i += NT)
-      {
-        const int a = i / 3, c = i - a * 3;
-        double    uv = 0.0, av = 0.0;
-        if (c < DIM)
-          {
-            const int64_t g = int64_t(s_conn[a]) * DIM + c;
-            uv              = prm.u[g] + prm.du[g]; // get_total_solution, :580-588
-            av              = prm.acc[g];
-          }
-        s_u[i] = uv;
-        s_a[i] = av;
-      }
-    __syncthreads();
-
-    // ---- phase A: quadrature-point records, 4 lanes per point
-    for (int task = tid; task < NQ * 4; task += NT)
-      {
-        const int q = task >> 2, part = task & 3;
-        double    gxi[9], acc[3];
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          gxi[k] = 0.0;
-        acc[0] = acc[1] = acc[2] = 0.0;
-        for (int a = part; a < NPC; a += 4)
-          {
-            double N, dN[3];
-            shape_at_qp<DIM, P>(s_N1, s_dN1, q, a, N, dN);
-#pragma unroll
-            for (int i = 0; i < DIM; ++i)
-              {
-                const double ui = s_u[a * 3 + i];
-#pragma unroll
-                for (int j = 0; j < DIM; ++j)
-                  gxi[i * 3 + j] += ui * dN[j];
-                acc[i] += s_a[a * 3 + i] * N;
-              }
-          }
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          {
-            gxi[k] += __shfl_xor(gxi[k], 1, 64);
-            gxi[k] += __shfl_xor(gxi[k], 2, 64);
-          }
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          {
-            acc[k] += __shfl_xor(acc[k], 1, 64);
-            acc[k] += __shfl_xor(acc[k], 2, 64);
-          }
-        // geometry of the d-linear map at this point
-        double xi[3], wq = 1.0;
-        {
-          int qi[3] = {q % NQ1, (q / NQ1) % NQ1, (DIM == 3) ? q / (NQ1 * NQ1) : 0};
-#pragma unroll
-          for (int d = 0; d < DIM; ++d)
-            {
-              xi[d] = s_qx[qi[d]];
-              wq *= s_qw[qi[d]];
-            }
-        }
-        double Jm[9], Ji[9];
-        q1_jacobian<DIM>(s_verts, xi, Jm);
-        const double detJ = det3x3(Jm);
-        inv3x3(Jm, detJ, Ji);
-        // Grad_X u = grad_xi u * Jinv
-        double gu[9];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            gu[i * 3 + j] = (i < DIM && j < DIM) ? gxi[i * 3 + 0] * Ji[0 * 3 + j] + gxi[i * 3 + 1] * Ji[1 * 3 + j] +
-                                                     (DIM == 3 ? gxi[i * 3 + 2] * Ji[2 * 3 + j] : 0.0) :
-                                                   0.0;
-        double Finv[9], J, tau[6], tiso[6], cII, cS;
-        neo_hooke_qp<DIM>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS);
-        if (part == 0)
-          {
-            double *r = &s_qp[q * RQS];
-            // M = Jinv * Finv
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-              for (int j = 0; j < 3; ++j)
-                r[Q_M + i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] +
-                                     Ji[i * 3 + 2] * Finv[2 * 3 + j];
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
-              {
-                r[Q_TAU + k]  = tau[k];
-                r[Q_TISO + k] = tiso[k];
-              }
-            const double w   = detJ * wq; // JxW of the reference configuration
-            const double sqn = sqrt(prm.alpha1 * prm.rho * w);
-            r[Q_W]           = w;
-            r[Q_WCII]        = w * cII;
-            r[Q_CS2]         = 0.5 * cS;
-            r[Q_SQN]         = sqn;
-            r[Q_NINV]        = sqn > 0.0 ? 1.0 / sqn : 0.0;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-              r[Q_FACC + i] = prm.rho * w * (acc[i] - prm.body[i]);
-          }
-      }
-    __syncthreads();
-
-
-    __shared__ double s_q2[NQ * RQ2];
-    __shared__ double s_T1[NC * 9 * 16];
-    __shared__ double s_T2[NC * 81 * 4];
-    __shared__ double s_C[NC * NQ];
-    __shared__ double s_rpart[3 * NPC * DIM];
-
-    // ---- phase A2: derived per-point matrices
-    for (int q = tid; q < NQ; q += NT)
-      {
-        const double *r = &s_qp[q * RQS];
-        double       *o = &s_q2[q * RQ2];
-        const double  w = r[Q_W], cs2 = r[Q_CS2];
-        double        M[9], T[9], Ti[9], MT[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-          M[k] = r[Q_M + k];
-        // symmetric 3x3 from the 6-vectors
-        const double *t6 = &r[Q_TAU], *i6 = &r[Q_TISO];
-        T[0] = t6[0], T[4] = t6[1], T[8] = t6[2], T[1] = T[3] = t6[3], T[2] = T[6] = t6[4], T[5] = T[7] = t6[5];
-        Ti[0] = i6[0], Ti[4] = i6[1], Ti[8] = i6[2], Ti[1] = Ti[3] = i6[3], Ti[2] = Ti[6] = i6[4], Ti[5] = Ti[7] = i6[5];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-            {
-              double a = 0.0, b = 0.0;
-#pragma unroll
-              for (int m = 0; m < 3; ++m)
-                {
-                  a += M[k * 3 + m] * Ti[m * 3 + i];
-                  b += M[k * 3 + m] * T[m * 3 + i];
-                }
-              o[k * 3 + i]      = (-2.0 / 3.0) * a; // Tm
-              MT[k * 3 + i]     = b;
-              o[15 + k * 3 + i] = w * b; // R = w M tau
-            }
-        const int sk[6] = {0, 1, 2, 0, 0, 1}, sl[6] = {0, 1, 2, 1, 2, 2};
-#pragma unroll
-        for (int e = 0; e < 6; ++e)
-          {
-            double v = 0.0;
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-              v += (cs2 * M[sk[e] * 3 + m] + MT[sk[e] * 3 + m]) * M[sl[e] * 3 + m];
-            o[9 + e] = w * v; // S_kl
-          }
-      }
-    __syncthreads();
-
-    // ---- residual (:984-995): r_a,i = -sum_q [ sum_k d_k N_a R_ki + N_a rho w (acc - b)_i ], three point ranges
-    if (tid < 3 * NPC * DIM)
-      {
-        const int part = tid / (NPC * DIM), ai = tid - part * (NPC * DIM);
-        const int a = ai / DIM, i = ai - a * DIM;
-        double    rres = 0.0;
-        for (int q = part * 22; q < min(NQ, (part + 1) * 22); ++q)
-          {
-            double N, dN[3];
-            shape_at_qp<DIM, P>(s_N1, s_dN1, q, a, N, dN);
-            const double *o = &s_q2[q * RQ2];
-            rres -= dN[0] * o[15 + i] + dN[1] * o[18 + i] + dN[2] * o[21 + i] + N * s_qp[q * RQS + Q_FACC + i];
-          }
-        s_rpart[tid] = rres;
-      }
-    __syncthreads();
-    if (tid < NPC * DIM)
-      {
-        const int     a = tid / DIM, i = tid - a * DIM;
-        const int32_t A = s_conn[a];
-        if (!((prm.cmask[A] >> i) & 1))
-          prm.rhs[int64_t(A) * DIM + i] += s_rpart[tid] + s_rpart[NPC * DIM + tid] + s_rpart[2 * NPC * DIM + tid];
-      }
-
-    // ---- tangent: thread (g = a1 b1 a2 b2, s = a3) owns the node pairs (a, b3 = 0..2)
-    const bool active = tid < 243;
-    const int  g = tid / 3, s3 = tid - g * 3;
-    const int  ab1 = g / 9, ab2 = g - ab1 * 9;
-    const int  a1 = ab1 % 3, b1 = ab1 / 3, a2 = ab2 % 3, b2 = ab2 / 3;
-    double     K[3][DD];
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int k = 0; k < DD; ++k)
-        K[b][k] = 0.0;
-
-#pragma unroll
-    for (int ij = 0; ij < 9; ++ij)
-      {
-        const int i = ij / 3, j = ij - i * 3;
-        // coefficients C^{ij}_{kl}(q) of this (i,j): one (combination, point) per thread, point fastest
-        for (int item = tid; item < NC * NQ; item += NT)
-          {
-            const int     c = item >> 6, q = item & 63;
-            const double *r = &s_qp[q * RQS], *o = &s_q2[q * RQ2];
-            double        v;
-            if (c == 9)
-              v = (i == j) ? r[Q_SQN] * r[Q_SQN] : 0.0;
-            else
-              {
-                const int    k = c / 3, l = c - (c / 3) * 3;
-                const double w = r[Q_W];
-                v = (r[Q_WCII] * r[Q_M + k * 3 + i] + w * o[k * 3 + i]) * r[Q_M + l * 3 + j] +
-                    w * (r[Q_M + k * 3 + i] * o[l * 3 + j] + r[Q_CS2] * r[Q_M + k * 3 + j] * r[Q_M + l * 3 + i]);
-                if (i == j)
-                  v += o[9 + ((k == l) ? k : (k + l + 2))]; // (0,1)->3 (0,2)->4 (1,2)->5
-              }
-            s_C[item] = v;
-          }
-        __syncthreads();
-        // stage 1: contract q1.  item = (combination c, q2 q3)
-        for (int item = tid; item < NC * 16; item += NT)
-          {
-            const int  c = item >> 4, q23 = item & 15;
-            const bool mass = (c == 9);
-            const int  k = mass ? 0 : c / 3, l = mass ? 0 : c - (c / 3) * 3;
-            double     Cq[4];
-#pragma unroll
-            for (int q1 = 0; q1 < 4; ++q1)
-              Cq[q1] = s_C[c * 64 + q1 + 4 * q23];
-            const double *ta = (!mass && k == 0) ? s_dN1 : s_N1, *tb = (!mass && l == 0) ? s_dN1 : s_N1;
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-              for (int aa = 0; aa < 3; ++aa)
-                {
-                  double t = 0.0;
-#pragma unroll
-                  for (int q1 = 0; q1 < 4; ++q1)
-                    t += ta[q1 * 3 + aa] * tb[q1 * 3 + bb] * Cq[q1];
-                  s_T1[(c * 9 + aa + 3 * bb) * 16 + q23] = t;
-                }
-          }
-        __syncthreads();
-        // stage 2: contract q2.  item = (c, a1 b1, q3)
-        for (int item = tid; item < NC * 36; item += NT)
-          {
-            const int  c = item / 36, rem = item - c * 36, p1 = rem >> 2, q3 = rem & 3;
-            const bool mass = (c == 9);
-            const int  k = mass ? 0 : c / 3, l = mass ? 0 : c - (c / 3) * 3;
-            double     t1[4];
-#pragma unroll
-            for (int q2 = 0; q2 < 4; ++q2)
-              t1[q2] = s_T1[(c * 9 + p1) * 16 + q2 + 4 * q3];
-            const double *ta = (!mass && k == 1) ? s_dN1 : s_N1, *tb = (!mass && l == 1) ? s_dN1 : s_N1;
-#pragma unroll
-            for (int bb = 0; bb < 3; ++bb)
-#pragma unroll
-              for (int aa = 0; aa < 3; ++aa)
-                {
-                  double t = 0.0;
-#pragma unroll
-                  for (int q2 = 0; q2 < 4; ++q2)
-                    t += ta[q2 * 3 + aa] * tb[q2 * 3 + bb] * t1[q2];
-                  s_T2[(c * 4 + q3) * 81 + p1 * 9 + aa + 3 * bb] = t;
-                }
-          }
-        __syncthreads();
-        // stage 3: contract q3 into the registers of the owning thread
-        if (active)
-          {
-            for (int c = 0; c < NC; ++c)
-              {
-                const bool    mass = (c == 9);
-                const int     k = mass ? 0 : c / 3, l = mass ? 0 : c - (c / 3) * 3;
-                const double *ta = (!mass && k == 2) ? s_dN1 : s_N1, *tb = (!mass && l == 2) ? s_dN1 : s_N1;
-#pragma unroll
-                for (int q3 = 0; q3 < 4; ++q3)
-                  {
-                    const double t2 = s_T2[(c * 4 + q3) * 81 + g] * ta[q3 * 3 + s3];
-#pragma unroll
-                    for (int b3 = 0; b3 < 3; ++b3)
-                      K[b3][ij] += t2 * tb[q3 * 3 + b3];
-                  }
-              }
-          }
-      }
-
-    // ---- scatter of the three blocks (a, b3)
-    if (active)
-      {
-        const int       a    = a1 + 3 * a2 + 9 * s3;
-        const int32_t   A    = s_conn[a];
-        const int       ma   = prm.cmask[A];
-        const uint16_t *offc = prm.off + cell * (NPC * NPC);
-        const int64_t   rowA = prm.rowptr[A];
-#pragma unroll
-        for (int b3 = 0; b3 < 3; ++b3)
-          {
-            const int      b   = b1 + 3 * b2 + 9 * b3;
-            const int      mb  = prm.cmask[s_conn[b]];
-            const uint16_t oab = offc[a * NPC + b];
-            double *__restrict__ pab = prm.vals + (rowA + (oab & 0x7fff)) * DD;
-            double v[DD];
-#pragma unroll
-            for (int i = 0; i < DIM; ++i)
-#pragma unroll
-              for (int j = 0; j < DIM; ++j)
-                {
-                  double x = K[b3][i * DIM + j];
-                  if (((ma >> i) | (mb >> j)) & 1)
-                    x = (a == b && i == j) ? fabs(x) : 0.0;
-                  v[i * DIM + j] = x;
-                }
-            if (!(oab >> 15))
-#pragma unroll
-              for (int k = 0; k < DD; ++k)
-                v[k] += pab[k];
-#pragma unroll
-            for (int k = 0; k < DD; ++k)
-              pab[k] = v[k];
-          }
-      }
-  }
-
   // ------------------------------------------------------------------ Neumann faces (:791-859)
   // one 64-thread workgroup per cell of the current colour that owns interface faces; the cell's faces are
   // processed one after the other (faces of one cell share edge/corner nodes, cells of one colour do not)
@@ -3506,9 +3135,6 @@ namespace mi
               break;
             case 2:
               launch_asm<3, 2, 2, 256, 4>(p, s); // 27 kB LDS: no faster than QC = 8 (register limited)
-              break;
-            case 5:
-              hipLaunchKernelGGL(assemble_cells_sf, dim3(p.cell_count), dim3(256), 0, s, p); // sum factorisation
               break;
             case 6:
               launch_asm<3, 2, 2, 256, 8, 1, 1>(p, s); // timing only: no tangent scatter
