@@ -2132,7 +2132,29 @@ namespace mi
     const double *__restrict__ src = bsr_vals + int64_t(rowptr[node]) * DD;
     double *__restrict__ dst       = sell_vals + off * (DD * 64) + lane;
     float *__restrict__ dst32      = sell_vals32 ? sell_vals32 + off * (DD * 64) + lane : nullptr;
-    for (int k = 0; k < len; ++k)
+    // U blocks per trip: a lane then consumes U * 72 contiguous bytes while their cache lines are hot (one block per trip
+    // re-fetched half of every line: 12.0 GB read for 7.6 GB)
+    constexpr int U = 5; // the row lengths of 3D Q2 (27 / 45 / 75 / 125 blocks) are multiples of 5 but for the first
+    int           k = 0;
+    for (; k + U <= len; k += U)
+      {
+        double v[U][DD];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < DD; ++e)
+            v[u][e] = src[(k + u) * DD + e];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int e = 0; e < DD; ++e)
+            {
+              dst[(int64_t(k + u) * DD + e) * 64] = v[u][e];
+              if (dst32)
+                dst32[(int64_t(k + u) * DD + e) * 64] = float(v[u][e]);
+            }
+      }
+    for (; k < len; ++k)
       {
         double v[DD];
 #pragma unroll
