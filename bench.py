@@ -478,7 +478,7 @@ def main():
             out["roofline"] = {
                 "kernel": ("mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
                            "point numbers per cell the tangent is linearised at (sum factorisation, no stored K_e; 4.8x fewer bytes "
-                           "than the element tangents it replaced, which takes the product off the HBM roofline: VALU 46 %, LDS 31 % "
+                           "than the element tangents it replaced, which takes the product off the HBM roofline: VALU 57 %, LDS 43 % "
                            "busy, profiles/r02/pmc_counters_mf_spmv_n59.json); "
                            if form == 2 else
                            "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
