@@ -478,8 +478,8 @@ def main():
             out["roofline"] = {
                 "kernel": ("mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
                            "point numbers per cell the tangent is linearised at (sum factorisation, no stored K_e; 4.8x fewer bytes "
-                           "than the element tangents it replaced, which takes the product off the HBM roofline: VALU 57 %, LDS 43 % "
-                           "busy, profiles/r02/pmc_counters_mf_spmv_n59.json); "
+                           "than the element tangents it replaced, which takes the product off the HBM roofline: VALU, LDS and HBM "
+                           "are each half to three quarters busy, profiles/r02/pmc_counters_mf_spmv_n59.json); "
                            if form == 2 else
                            "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
                            "tangents (378 lower-triangle 3x3 blocks per cell); ") +
