@@ -8,6 +8,7 @@ import ctypes as C
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -225,6 +226,19 @@ def test_launcher_rank_environment_is_validated(tmp_path):
     out = subprocess.run([os.path.join(HOST, "elasticity3d")], cwd=tmp_path, capture_output=True, text=True, timeout=120,
                          env=dict(os.environ, MI_WORLD_SIZE="2", MI_RANK="0"))
     assert out.returncode == 1 and "MI_UID_FILE" in out.stderr
+
+
+def test_launcher_ends_all_ranks_when_one_fails(tmp_path):
+    """tools/launch_elasticity.py -n 2 on a box with ONE GPU: rank 1 has no device and exits with the executable's
+    message; the launcher must end rank 0 (which waits for its partner in RCCL) instead of hanging, and report failure"""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a single-GPU box")
+    for f in ("parameters.prm", "precice-config.xml"):
+        (tmp_path / f).write_text(open(os.path.join(CASES, "block_neo_3d_q2", f)).read())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "launch_elasticity.py"), "-n", "2", "parameters.prm"],
+                         cwd=tmp_path, capture_output=True, text=True, timeout=100)
+    assert out.returncode == 1 and "out of range" in out.stderr
 
 
 def _check_vtk(path, P, zero):

@@ -14,6 +14,7 @@ import os
 import subprocess
 import sys
 import tempfile
+import time
 
 
 def main():
@@ -33,14 +34,17 @@ def main():
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen([a.exe, a.prm], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
         rc = 0
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):  # one rank failed: the others may wait in a collective for ever
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.05)
         for p in procs:
             p.wait()
             rc = rc or p.returncode
-        if rc:  # one rank failed: the others may be waiting in a collective
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-    sys.exit(rc)
+    sys.exit(1 if rc else 0)
 
 
 if __name__ == "__main__":
