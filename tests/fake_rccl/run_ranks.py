@@ -54,9 +54,10 @@ def scenario(G, M, kw, log):
         if precond == 1 and kw.get("ebe"):
             # the smoother on the element tangents (as on big meshes): unfused smoother, every slab multiplies with all its
             # local cells after the halo exchange
-            G.set_tuning("element_tangents", 1)
+            # (ebe = 2: matrix-free from the quadrature-point records, one launch + the gather that applies the step)
+            G.set_tuning("element_tangents", int(kw["ebe"]))
             G.set_tuning("mg_fuse", 0)
-            assert G.get_tuning("smoother_operator_active") == 1
+            assert G.get_tuning("smoother_operator_active") == int(kw["ebe"])
         its = []
         for step in range(2):
             G.set_interface_traction((0.0, -1.5e3 * (step + 1), 0.0)[:G.dim])
