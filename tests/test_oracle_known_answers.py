@@ -472,3 +472,22 @@ def test_linear_model_theta_half_conserves_energy():
         rc, its, res = P2.step(O.SOLVER_CG_SSOR, True)
         assert rc == 0 and res <= 1e-10
     assert np.abs(P2.vec(O.L_D) - P.vec(O.L_D)).max() / np.abs(P.vec(O.L_D)).max() < 1e-6
+
+
+def test_kernel_algebra_prototypes_against_the_independent_mirror():
+    """the quadrature-point form of the tangent that mf_spmv applies and the sum-factorised element tangent that
+    assemble_q2sf forms (coefficient fields C^{ij}_{kl}, x/y/z contractions, symmetric pruning), restated in numpy with
+    the kernels' decomposition (tools/proto/*.py), reproduce the dense element tangent of tests/golden/mirror.py"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script in ("mf_product.py", "sf_assembly.py"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "proto", script)], capture_output=True, text=True,
+                             timeout=120)
+        assert out.returncode == 0, out.stderr[-2000:]
+        err = float(re.search(r"rel err ([0-9.eE+-]+)", out.stdout).group(1))
+        assert err < 1e-13, (script, out.stdout)
+        if script == "sf_assembly.py":
+            assert "covered True" in out.stdout
