@@ -128,7 +128,7 @@ namespace mi_detail
     p.conn   = c->d_conn;
     p.cverts = c->d_cverts;
     p.off    = c->d_off;
-    p.rowptr = c->d_rowptr;
+    p.rowbase = c->d_rowbase;
     p.cmask  = c->d_cmask;
     p.tab1d  = c->d_tab;
     p.u      = c->vec(MI_V_TOTAL_DISPLACEMENT);
@@ -144,6 +144,7 @@ namespace mi_detail
     for (int i = 0; i < 3; ++i)
       p.body[i] = c->mat.body_force[i];
     p.variant = c->asm_variant;
+    p.kstride = getenv("MI_LAYOUT_TEST") ? 1 : 64;
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
     return p;
@@ -175,7 +176,8 @@ namespace mi_detail
     mi::SpmvParams p{};
     p.rowptr           = c->d_rowptr;
     p.col              = c->d_col;
-    p.vals             = c->d_vals;
+    p.rowbase          = c->d_rowbase;
+    p.vals             = c->active_sell_vals ? c->active_sell_vals : c->d_vals;
     p.x                = x;
     p.y                = y;
     p.dotv             = dotv;
@@ -183,7 +185,7 @@ namespace mi_detail
     p.done             = done;
     p.row0             = c->slab.own_begin;
     p.nrows            = c->slab.own_end - c->slab.own_begin;
-    p.rowptr_host_nnzb = c->mesh.nnzb;
+    p.nvalblocks       = c->mesh.nvalblocks();
     return p;
   }
 
@@ -198,7 +200,7 @@ namespace mi_detail
     p.rowbox    = c->sell_icol ? c->d_sell_box : nullptr;
     p.nn0       = c->mesh.nn[0];
     p.nn1       = c->mesh.nn[1];
-    p.vals      = c->active_sell_vals ? c->active_sell_vals : c->d_sell_vals;
+    p.vals      = c->active_sell_vals ? c->active_sell_vals : c->d_vals;
     p.x         = x;
     p.y         = y;
     p.dotv      = dotv;
@@ -211,17 +213,15 @@ namespace mi_detail
     return p;
   }
 
-  // SpMV-side copy of the tangent (owned rows) in sliced-ELL order.  Lazy: the last assembly of a Newton loop only
-  // serves the convergence check (nonlinear_elasticity.cc:446-469) and is never multiplied.
-  void refresh_sell(mi_ctx *c)
+  // The tangent is assembled straight into the layout the SpMV reads (mi_mesh.hpp: slice-interleaved block rows), so no
+  // copy stands between an assembly and the first product.  Only the opt-in fp32-rounded smoother storage
+  // ("precond_storage" 32) keeps a second array, refreshed lazily before the first product with a new tangent.
+  void refresh_vals32(mi_ctx *c)
   {
-    if (!c->sell_stale || c->active_sell_vals)
+    if (!c->vals32_stale || c->precond_storage != 32 || !c->d_sell_vals32)
       return;
-    const int t = tic(c->team->members[0], MI_T_SELL_COPY);
-    mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
-                           c->d_sell_vals, c->precond_storage == 32 ? c->d_sell_vals32 : nullptr, c->stream);
-    toc(c->team->members[0], t);
-    c->sell_stale = false;
+    mi::launch_vals_to_f32(c->d_vals, c->d_sell_vals32, c->mesh.nvalblocks() * int64_t(c->dim * c->dim), c->stream);
+    c->vals32_stale = false;
   }
 
   // which unassembled form of the current tangent the element products use: 2 quadrature-point records (mf_spmv),
@@ -317,7 +317,7 @@ namespace mi_detail
       }
     if (c->spmv_variant == 3 || c->spmv_variant == 4 || c->active_sell_vals) // linear-model operators exist in sliced-ELL form only
       {
-        refresh_sell(c);
+        refresh_vals32(c);
         mi::SellParams p   = sell_params(c, x, y, dotv, partials, done);
         if (smoother && c->precond_storage == 32 && c->d_sell_vals32 && !c->active_sell_vals)
           p.vals32 = c->d_sell_vals32;
@@ -347,7 +347,7 @@ namespace mi_detail
             mi::launch_sell_spmv(c->dim, p, c->grid_spmv_bnd, c->stream, c->sell_unroll);
           }
       }
-    else if (part != 1) // block-CSR cross-check kernel: not split, runs after the halo
+    else if (part != 1) // row-per-wave cross-check kernel: not split, runs after the halo
       mi::launch_spmv(c->dim, spmv_params(c, x, y, dotv, partials, done), c->grid_spmv, c->stream, c->spmv_variant,
                       c->maxrow);
   }
@@ -532,7 +532,7 @@ namespace mi_detail
           HIPCHK(c, hipMalloc((void **)&c->d_dinv_blk, size_t(c->mesh.nnodes) * c->dim * c->dim * sizeof(double)));
         mi::launch_extract_dinv_blk(c->dim, c->d_vals, c->d_diagpos, c->d_dinv_blk, c->mesh.nnodes, c->stream);
       }
-    c->sell_stale = true; // the SpMV-side copy is refreshed by the first product that needs it (enqueue_spmv)
+    c->vals32_stale = true; // the opt-in fp32 copy is refreshed by the first product that needs it (enqueue_spmv)
     HIPCHK(c, hipGetLastError());
     c->mg_stale = true; // the coarse operators belong to an older state
     return MI_OK;
@@ -642,8 +642,7 @@ namespace mi_detail
     mi_ctx    *c0   = T.members[0];
     const bool dist = T.size > 1;
     for (mi_ctx *m : T.members) // outside the timed SpMV launches
-      if (!(m->cg_operator == 1 && element_form(m) && !m->active_sell_vals))
-        refresh_sell(m);
+      refresh_vals32(m);
     const int  tt   = tic(c0, MI_T_CG_TOTAL);
     std::vector<mi::CgParams> cgs;
     for (mi_ctx *m : T.members)
@@ -868,7 +867,7 @@ namespace mi_detail
         HIPCHK(c, hipMemsetAsync(c->d_sell_vals32, 0, cnt * sizeof(float), c->stream));
       }
     c->precond_storage = bits;
-    c->sell_stale      = true; // refreshed (both copies) before the next product
+    c->vals32_stale    = true; // refreshed before the next product
     return mg_set_storage(c, bits);
   }
 
@@ -886,7 +885,7 @@ namespace mi_detail
     void *ptrs[] = {c->d_conn,      c->d_rowptr,    c->d_col,         c->d_diagpos,     c->d_iface_nodes, c->d_faces,
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
-                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_sell_vals,
+                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowbase,
                     c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base};
     for (void *p : ptrs)
       if (p)
@@ -948,6 +947,8 @@ namespace mi_detail
     UP(c->d_rowptr, m.rowptr)
     UP(c->d_col, m.colidx)
     UP(c->d_diagpos, m.diagpos)
+    if (getenv("MI_LAYOUT_TEST")) { std::vector<int32_t> rb(m.rowptr.begin(), m.rowptr.end() - 1); UP(c->d_rowbase, rb) } else
+    UP(c->d_rowbase, m.rowbase)
     UP(c->d_cmask, m.cmask)
     UP(c->d_iface_nodes, m.iface_nodes)
     {
@@ -988,8 +989,10 @@ namespace mi_detail
 #undef UP
     const size_t dd = size_t(c->dim) * c->dim;
     HIPCHK(c, hipMalloc((void **)&c->d_sell_col, std::max<size_t>(1, size_t(m.sell_nblk64) * 64) * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc((void **)&c->d_sell_vals, std::max<size_t>(1, size_t(m.sell_nblk64) * 64 * dd) * sizeof(double)));
-    HIPCHK(c, hipMalloc((void **)&c->d_vals, (size_t(m.nnzb) * dd + 2) * sizeof(double)));
+    // the tangent: ONE array, written by the element scatter, read by the SpMV (padding rows of the last slice of a
+    // length class included: they are zeroed once and never written)
+    const size_t nvals = std::max<size_t>(1, size_t(m.nvalblocks()) * dd);
+    HIPCHK(c, hipMalloc((void **)&c->d_vals, (nvals + 2) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_vecs, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_work, size_t(W_COUNT) * size_t(c->n) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_saved, size_t(6) * size_t(c->n) * sizeof(double)));
@@ -1000,13 +1003,11 @@ namespace mi_detail
     HIPCHK(c, hipMalloc((void **)&c->d_iface_buf, nif * sizeof(double)));
     c->h_pinned_doubles = std::max(nif, T.iface_global.size() * size_t(c->dim)) + 64;
     HIPCHK(c, hipHostMalloc((void **)&c->h_pinned, c->h_pinned_doubles * sizeof(double), hipHostMallocDefault));
-    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, size_t(m.nnzb) * dd * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, nvals * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_work, 0, size_t(W_COUNT) * size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sc, 0, 16 * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_flags, 0, 4 * sizeof(int32_t), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_sell_vals, 0, std::max<size_t>(1, size_t(m.sell_nblk64) * 64 * dd) * sizeof(double),
-                             c->stream));
     mi::launch_sell_build_cols(sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_col,
                                c->d_sell_col, c->stream);
     HIPCHK(c, hipGetLastError());
@@ -1770,7 +1771,7 @@ int mi_matrix_get_csr(mi_ctx *c, int64_t *rowptr, int32_t *col, double *val)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int           D = c->dim, DD = D * D;
   const mi::HostMesh &m = c->mesh;
-  std::vector<double> bv(size_t(m.nnzb) * DD);
+  std::vector<double> bv(size_t(m.nvalblocks()) * DD);
   HIPCHK(c, hipMemcpy(bv.data(), c->d_vals, bv.size() * sizeof(double), hipMemcpyDeviceToHost));
   int64_t k = 0;
   for (int64_t nd = 0; nd < m.nnodes; ++nd)
@@ -1781,7 +1782,7 @@ int mi_matrix_get_csr(mi_ctx *c, int64_t *rowptr, int32_t *col, double *val)
           for (int j = 0; j < D; ++j)
             {
               col[k] = m.colidx[size_t(b)] * D + j;
-              val[k] = bv[size_t(b) * DD + i * D + j];
+              val[k] = bv[size_t(m.valpos(nd, int(b - m.rowptr[size_t(nd)]))) * DD + i * D + j];
               ++k;
             }
       }

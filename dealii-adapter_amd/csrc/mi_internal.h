@@ -88,12 +88,13 @@ struct mi_ctx
   // device memory
   int32_t  *d_conn = nullptr, *d_rowptr = nullptr, *d_col = nullptr, *d_diagpos = nullptr, *d_iface_nodes = nullptr,
           *d_faces = nullptr, *d_flags = nullptr;
+  int32_t  *d_rowbase = nullptr; // [nnodes] where the row of a node starts in d_vals (mi::HostMesh::rowbase)
   double   *d_cverts = nullptr, *d_tab = nullptr, *d_vals = nullptr, *d_vecs = nullptr, *d_work = nullptr,
          *d_saved = nullptr, *d_part = nullptr, *d_sc = nullptr, *d_iface_buf = nullptr;
   int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr, *d_sell_box = nullptr;
   int       sell_icol = 1; // 1: the SpMV generates the column indices from the rows' column boxes, 0: reads them
   int64_t  *d_sell_off = nullptr;
-  double   *d_sell_vals = nullptr;
+  // d_vals IS the sliced-ELL matrix (slice-interleaved block rows): the element scatter writes what the SpMV reads
   double   *d_dinv_blk = nullptr; // inverse diagonal blocks (block-Jacobi smoother), allocated when it is switched on
   bool      want_dinv_blk = false;
   double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
@@ -154,7 +155,7 @@ struct mi_ctx
   // multigrid preconditioner of this slab (mi_mg.cpp); precond: 0 Jacobi, 1 multigrid V-cycle
   mi_detail::Multigrid *mg = nullptr;
   int                   precond = 1;
-  bool                  sell_stale = false; // the sliced-ELL copy is older than the block-CSR tangent
+  bool                  vals32_stale = false; // the fp32-rounded copy (opt-in) is older than the tangent
   bool                  mg_stale = true; // the coarse operators belong to an older state than the fine tangent
   bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
   int                   asm_variant = 0;
@@ -171,7 +172,7 @@ namespace mi_detail
   int  tic(mi_ctx *c, int cls, bool ext = false);
   void toc(mi_ctx *c, int id);
   int  sync(mi_ctx *c);
-  void           refresh_sell(mi_ctx *c); // sliced-ELL copy of the current tangent, if stale
+  void           refresh_vals32(mi_ctx *c); // fp32-rounded copy of the current tangent (opt-in smoother storage), if stale
   int            element_form(const mi_ctx *c); // 2 quadrature-point records, 1 element tangents, 0 none (current tangent)
   bool           mf_gather_fusable(const mi_ctx *c); // the smoother's product is the single-launch matrix-free form
   mi::SellParams sell_params(mi_ctx *c, const double *x, double *y, const double *dotv, double *partials,

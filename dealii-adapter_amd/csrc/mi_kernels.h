@@ -11,17 +11,19 @@ namespace mi
     const int32_t  *conn;   // [ncells][npc]       colour-sorted
     const double   *cverts; // [ncells][2^dim][dim]
     const uint16_t *off;    // [ncells][npc][npc]
-    const int32_t  *rowptr; // [nnodes+1] block rows
+    const int32_t  *rowbase; // [nnodes] position (in blocks) of slot 0 of the node's row in `vals`, slot k is 64 blocks
+                             // further (mi::HostMesh::rowbase); -1: no row here (ghost node of a slab) -> nothing stored
     const uint8_t  *cmask;  // [nnodes]
     const double   *tab1d;  // N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1]
     const double   *u, *du, *acc, *stress;
     double         *rhs;
-    double         *vals;   // block-CSR values [nnzb][dim*dim]
+    double         *vals;   // tangent, slice-interleaved block rows [(off+k)*64 + lane][dim*dim] -- the layout the SpMV reads
     double          mu, kappa, rho, alpha1;
     double          body[3];
     int64_t         cell_begin;
     int32_t         cell_count;
     int32_t         variant; // kernel variant for A/B timing
+    int32_t         kstride; // EXPERIMENT
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
     double         *qrec;   // optional (3D Q2): the quadrature-point records the tangent is made of, [cell][MF_NREC][64] (see mf_spmv)
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
@@ -46,8 +48,8 @@ namespace mi
     const int32_t  *conn;    // [ncells][27] colour-sorted
     const uint32_t *first;   // as EbeParams
     const uint8_t  *cmask;   // [nnodes]
-    const double   *vals;    // assembled tangent (block-CSR): diagonal entries of constrained dofs
-    const int32_t  *diagpos; // [nnodes] block index of (node,node)
+    const double   *vals;    // assembled tangent: diagonal entries of constrained dofs
+    const int32_t  *diagpos; // [nnodes] position of block (node,node) in vals (in blocks), -1: no row here
     const double   *tab1d;   // N1[4][3], dN1[4][3], qw[4], qx[4] (the assembly's tables)
     const double   *cverts;  // [ncells][8][3]
     double          mu, kappa;
@@ -62,10 +64,12 @@ namespace mi
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
   };
 
+  // row-per-wave cross-check product (tests) and the streaming calibration kernels
   struct SpmvParams
   {
-    const int32_t *rowptr;
+    const int32_t *rowptr;  // [nnodes+1] block pattern
     const int32_t *col;
+    const int32_t *rowbase; // [nnodes] as AsmParams::rowbase
     const double  *vals;
     const double  *x;
     double        *y;
@@ -73,7 +77,7 @@ namespace mi
     double        *partials; // [grid]
     const int32_t *done;     // optional early-exit flag
     int64_t        row0, nrows;
-    int64_t        rowptr_host_nnzb; // number of stored blocks (timing-only stream kernels)
+    int64_t        nvalblocks; // number of stored blocks (timing-only stream kernels)
   };
 
   // sliced-ELL SpMV (see mi_kernels.hip)
@@ -86,7 +90,7 @@ namespace mi
     const int32_t *rowbox; // optional [nslices*64][2]: first column and box widths of every row; when set the kernel
                            // generates the column indices instead of reading `col` (lattice meshes: columns form a box)
     int32_t        nn0, nn1; // lattice points along x and y (column = x + nn0 * (y + nn1 * z))
-    const double  *vals; // [nblk64*DD*64]
+    const double  *vals; // [(off+k)*64 + lane][DD]: the 64 blocks of one k are one contiguous chunk
     const float   *vals32; // same layout, rounded to fp32: the smoother's copy (null: use vals)
     // fused Chebyshev-Jacobi epilogue (multigrid smoother; cheb_d == null: plain product).  Per owned row i:
     //   res = cheb_b - (K x); d = c1 d + c2 dinv res; cheb_xout = x + d   (x itself stays: other rows still gather it)
@@ -173,8 +177,7 @@ namespace mi
   int  launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s);
   void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s);
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
-  void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
-                          double *sell_vals, float *sell_vals32, hipStream_t s);
+  void launch_vals_to_f32(const double *vals, float *vals32, int64_t n, hipStream_t s); // the smoother's fp32-rounded copy (opt-in)
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s);
   void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, int grid, hipStream_t s);

@@ -1,11 +1,12 @@
 // mi_kernels.hip -- hand-written gfx950 kernels of the hot path (fp64, HBM/LDS/VALU; no MFMA by design).
 //
 //   assemble_cells   : per-cell tangent + residual of the neo-Hookean Newmark problem, one workgroup per
-//                      cell, scattered into the block-CSR by graph colouring
+//                      cell, scattered by graph colouring into the block rows of the global tangent (stored in the
+//                      slice-interleaved order the SpMV reads: one array for assembly and product)
 //                      (nonlinear_elasticity.cc:872-1036 + :760-774; maths restated in DESIGN.md section 4)
 //   neumann_faces    : interface traction with area pull-back incl. the reference's cell-QP quirk (:791-859)
-//   sell_spmv        : y = K x on the sliced-ELL copy of the tangent (lane = row), fused dot product
-//   bsr_spmv_mlp     : y = K x directly on the block-CSR (cross-check / baseline)
+//   sell_spmv        : y = K x on the sliced-ELL rows of the tangent (lane = row), fused dot product
+//   blockrow_spmv_check : y = K x one wavefront per block row through the block pattern (cross-check)
 //   cg_* / vec_*     : fused CG vector updates with deterministic two-level reductions (:1153-1191)
 //   newmark_*        : Newmark predictor/corrector vector updates (:592-622)
 #include <hip/hip_runtime.h>
@@ -605,8 +606,11 @@ namespace mi
             const int32_t A = s_conn[a], B = s_conn[b];
             const int     ma = prm.cmask[A], mb = prm.cmask[B];
             const uint16_t oab = offc[a * NPC + b], oba = offc[b * NPC + a];
-            double *__restrict__ pab = prm.vals + (int64_t(prm.rowptr[A]) + (oab & 0x7fff)) * DD;
-            double *__restrict__ pba = prm.vals + (int64_t(prm.rowptr[B]) + (oba & 0x7fff)) * DD;
+            // slot k of a row sits 64 blocks after slot k-1 (slice-interleaved block rows, mi_mesh.hpp); a node without
+            // a row here (ghost node of a slab) stores nothing
+            const int32_t ra = prm.rowbase[A], rb = prm.rowbase[B];
+            double *__restrict__ pab = prm.vals + (int64_t(ra) + int64_t(oab & 0x7fff) * 64) * DD;
+            double *__restrict__ pba = prm.vals + (int64_t(rb) + int64_t(oba & 0x7fff) * 64) * DD;
             // bit 15: first touch of the block in processing order -> plain store instead of read-modify-write
             const bool first_ab = oab >> 15, first_ba = oba >> 15;
             double     vab[DD], vba[DD];
@@ -629,14 +633,17 @@ namespace mi
                   for (int k = 0; k < DD; ++k)
                     kq[k * EBE_NBLK] = vab[k];
                 }
-            if (!first_ab)
+            if (ra >= 0)
+              {
+                if (!first_ab)
 #pragma unroll
-              for (int k = 0; k < DD; ++k)
-                vab[k] += pab[k];
+                  for (int k = 0; k < DD; ++k)
+                    vab[k] += pab[k];
 #pragma unroll
-            for (int k = 0; k < DD; ++k)
-              pab[k] = vab[k];
-            if (a != b)
+                for (int k = 0; k < DD; ++k)
+                  pab[k] = vab[k];
+              }
+            if (a != b && rb >= 0)
               {
                 if (!first_ba)
 #pragma unroll
@@ -710,13 +717,24 @@ namespace mi
           D[q][a] = prm.tab1d[12 + q * 3 + a];
         }
 
+    // state of wave 0 (lane = quadrature point) that lives across barrier (1); unused in waves 1-3
+    const int     lane = tid & 63;
+    double *const s0 = s_w, *const sE = s_w + 768;
+    const lds_cvp v0 = (lds_cvp)s0, vE = (lds_cvp)sE;
+    const int     q16 = lane & 15, pck = lane >> 2, pqx = lane & 3;
+    double        M[9], tau[6], w = 0.0, accq[3] = {0.0, 0.0, 0.0};
+    // state of waves 1-3 (lane = (ij, a1 >= b1, a2)) across barrier (1); unused in wave 0
+    const int  it     = tid - 64;
+    const bool active = tid >= 64 && it < 162;
+    const int  ij = active ? it / 18 : 0, r18 = active ? it - 18 * ij : 0, pr = r18 / 3, a2 = r18 - 3 * pr;
+    const int  a1 = pr >= 3 ? 2 : (pr >= 1 ? 1 : 0), b1 = pr - a1 * (a1 + 1) / 2; // pairs (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+    const int  ci = ij / 3, cj = ij - 3 * ci;
+    double     P1[4][4], phi2[2][4], mflag = 0.0;
+
     if (tid < 64)
       {
         // ================================================================= wave 0: quadrature points
-        const int     lane = tid;
-        double *const s0 = s_w, *const sE = s_w + 768;
-        const lds_cvp v0 = (lds_cvp)s0, vE = (lds_cvp)sE;
-        const int     qz = lane >> 4, q16 = lane & 15;
+        const int     qz = lane >> 4;
         double        Sz[3], Dz[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -726,7 +744,6 @@ namespace mi
           }
         const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
         double       xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
-        const int    pck = lane >> 2, pqx = lane & 3;
         int32_t      node = 0;
         double       accn[3] = {0.0, 0.0, 0.0};
         if (lane < NPC)
@@ -742,7 +759,7 @@ namespace mi
               }
           }
         // ---- two interpolations to the points: pass 0 = u (gradients), pass 1 = acceleration (values)
-        double gxi[3][3], accq[3];
+        double gxi[3][3];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass)
           {
@@ -820,7 +837,7 @@ namespace mi
               }
           }
         // ---- geometry, kinematics, material at this point (nonlinear_elasticity.cc:927-934)
-        double M[9], tau[6], tiso[6], w, cII, cS;
+        double tiso[6], cII, cS;
         {
           const double *__restrict__ cv = prm.cverts + cell * 24;
           double verts[24], Jm[9], Ji[9], gu[9], Finv[9], J, Fq[9], Jmq, rJq;
@@ -898,8 +915,31 @@ namespace mi
                       s_C[((i * 3 + j) * 9 + k * 3 + l) * FS + lane] = c;
                     }
             s_C[81 * FS + lane] = prm.alpha1 * prm.rho * w;
-            __syncthreads(); // (1) fields complete
           }
+      }
+    else if constexpr (!RES_ONLY)
+      {
+        // ================================================================= waves 1-3: per-lane tables
+        // P1[kx*2+lx][qx] = phi^kx_a1(qx) phi^lx_b1(qx), phi2[ky][qy] = phi^ky_a2(qy); phi^1 = N', phi^0 = N
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          {
+            const double sa = prm.tab1d[q * 3 + a1], da = prm.tab1d[12 + q * 3 + a1];
+            const double sb = prm.tab1d[q * 3 + b1], db = prm.tab1d[12 + q * 3 + b1];
+            P1[0][q]        = sa * sb;
+            P1[1][q]        = sa * db;
+            P1[2][q]        = da * sb;
+            P1[3][q]        = da * db;
+            phi2[0][q]      = prm.tab1d[q * 3 + a2];
+            phi2[1][q]      = prm.tab1d[12 + q * 3 + a2];
+          }
+        mflag = (ci == cj) ? 1.0 : 0.0;
+      }
+    if constexpr (!RES_ONLY)
+      __syncthreads(); // (1) fields complete -- the one barrier every wave of the workgroup passes, outside the role branches
+    if (tid < 64)
+      {
+        const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
         // ---- residual: Q[i][k] = w sum_j tau_ij M_kj, V[i] = rho w (acc - b)_i, integrated against grad N_a / N_a
         MI_WAVE_SYNC();
 #pragma unroll
@@ -1002,11 +1042,6 @@ namespace mi
     if constexpr (!RES_ONLY)
       {
         // ================================================================= waves 1-3: the element tangent
-        const int  it     = tid - 64;
-        const bool active = tid >= 64 && it < 162;
-        const int  ij = active ? it / 18 : 0, r18 = active ? it - 18 * ij : 0, pr = r18 / 3, a2 = r18 - 3 * pr;
-        const int  a1 = pr >= 3 ? 2 : (pr >= 1 ? 1 : 0), b1 = pr - a1 * (a1 + 1) / 2; // pairs (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
-        const int  ci = ij / 3, cj = ij - 3 * ci;
         double     Kacc[3][3][3]; // [a3][b3][b2]
 #pragma unroll
         for (int a3 = 0; a3 < 3; ++a3)
@@ -1017,22 +1052,6 @@ namespace mi
               Kacc[a3][b3][b2] = 0.0;
         if (tid >= 64)
           {
-            // per-lane tables: P1[kx*2+lx][qx] = phi^kx_a1(qx) phi^lx_b1(qx), phi2[ky][qy] = phi^ky_a2(qy); phi^1 = N', phi^0 = N
-            double P1[4][4], phi2[2][4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-              {
-                const double sa = prm.tab1d[q * 3 + a1], da = prm.tab1d[12 + q * 3 + a1];
-                const double sb = prm.tab1d[q * 3 + b1], db = prm.tab1d[12 + q * 3 + b1];
-                P1[0][q]        = sa * sb;
-                P1[1][q]        = sa * db;
-                P1[2][q]        = da * sb;
-                P1[3][q]        = da * db;
-                phi2[0][q]      = prm.tab1d[q * 3 + a2];
-                phi2[1][q]      = prm.tab1d[12 + q * 3 + a2];
-              }
-            const double mflag = (ci == cj) ? 1.0 : 0.0;
-            __syncthreads(); // (1) fields complete
             const double *__restrict__ cb = s_C + ij * 9 * FS;
 #pragma unroll
             for (int qz = 0; qz < 4; ++qz)
@@ -1107,75 +1126,66 @@ namespace mi
                   }
           }
         __syncthreads(); // (3) image complete
-        // ---- tangent scatter, one thread per node-pair block (two blocks for the first 122 threads).  [DEAL.II
-        // distribute_local_to_global] constrained rows/cols are dropped, the diagonal of a constrained dof receives
-        // |K_e(i,i)|.  The old values of BOTH blocks are requested before anything is stored: one round trip, not two.
+        // ---- tangent scatter.  [DEAL.II distribute_local_to_global] constrained rows/cols are dropped, the diagonal of a
+        // constrained dof receives |K_e(i,i)|.  Pass 1, one thread per node pair (a, b): position of the block in the
+        // global matrix (slot k of row A sits 64 blocks after slot k-1, mi_mesh.hpp; -1 when the node has no row here),
+        // first-touch flag, constraint bits -> LDS, in the part of s_C that the image leaves free.  Pass 2, lane = ENTRY
+        // of a block (9 consecutive lanes = one 72-byte block): a wave instruction then covers 7 whole blocks = 7 to 14
+        // cache lines instead of 64 pieces of 64 different blocks (one thread per block and nine 8-byte accesses each, the
+        // form of round 2, kept the address path busy with 10 k line accesses per cell: with the blocks of a row 4.6 kB
+        // apart in the single layout of round 3 that scatter took 35 % of a workgroup's life).  The old values of a batch
+        // of nine entries per lane are requested before anything is stored: three round trips per cell.
         const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
-        constexpr int NB = 2;
-        int           sa[NB], sb[NB], sma[NB], smb[NB];
-        bool          act[NB], fab[NB], fba[NB];
-        double       *pab[NB], *pba[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u)
+        uint64_t *const s_tab = reinterpret_cast<uint64_t *>(s_C + 9 * EBE_NBLK); // [729] behind the image [9][378]
+        static_assert(9 * EBE_NBLK + NPC * NPC <= NF * FS, "block table behind the tangent image");
+        for (int blk = tid; blk < NPC * NPC; blk += 256)
           {
-            const int blk = tid + u * 256;
-            act[u]        = blk < EBE_NBLK;
-            int a         = int((sqrtf(8.0f * float(blk) + 1.0f) - 1.0f) * 0.5f);
-            while ((a + 1) * (a + 2) / 2 <= blk)
-              ++a;
-            while (a * (a + 1) / 2 > blk)
-              --a;
-            a                  = act[u] ? a : 0;
-            const int     b    = act[u] ? blk - a * (a + 1) / 2 : 0;
-            const int32_t A    = s_conn[a], B = s_conn[b];
-            const uint16_t oab = offc[a * NPC + b], oba = offc[b * NPC + a];
-            sa[u]              = a;
-            sb[u]              = b;
-            sma[u]             = prm.cmask[A];
-            smb[u]             = prm.cmask[B];
-            pab[u]             = prm.vals + (int64_t(prm.rowptr[A]) + (oab & 0x7fff)) * 9;
-            pba[u]             = prm.vals + (int64_t(prm.rowptr[B]) + (oba & 0x7fff)) * 9;
-            fab[u]             = oab >> 15; // first touch in processing order: plain store
-            fba[u]             = oba >> 15;
+            const int      a = blk / NPC, b = blk - NPC * a;
+            const int32_t  A = s_conn[a], B = s_conn[b];
+            const uint16_t o  = offc[blk];
+            const int32_t  ra = prm.rowbase[A];
+            const int32_t  pos = ra >= 0 ? ra + int32_t(o & 0x7fff) * prm.kstride : -1;
+            s_tab[blk] = uint64_t(uint32_t(pos)) | (uint64_t(o >> 15) << 32) | (uint64_t(prm.cmask[A] & 7) << 33) |
+                         (uint64_t(prm.cmask[B] & 7) << 36);
           }
-        double oab_[NB][9], oba_[NB][9];
+        __syncthreads(); // (4) block table complete
+        constexpr int NE = NPC * NPC * 9, UB = 9; // 6561 entries, 27 per lane in 3 batches of 9
+#pragma unroll 1
+        for (int base = 0; base < 27; base += UB)
+          {
+            double  val[UB], old[UB];
+            double *ptr[UB];
+            bool    rd[UB];
 #pragma unroll
-        for (int u = 0; u < NB; ++u)
+            for (int u = 0; u < UB; ++u)
+              {
+                const int  i  = (base + u) * 256 + tid;
+                const bool in = i < NE;
+                const int  blk = in ? i / 9 : 0, e = in ? i - 9 * blk : 0;
+                const int  a = blk / NPC, b = blk - NPC * a, ei = e / 3, ej = e - 3 * ei;
+                const uint64_t t   = s_tab[blk];
+                const int32_t  pos = int32_t(uint32_t(t));
+                const int      ma = int(t >> 33) & 7, mb = int(t >> 36) & 7;
+                // the image holds the lower triangle of the node order; (a, b) with a < b is the transposed block of (b, a)
+                const bool low = a >= b;
+                const int  hi = low ? a : b, lo = low ? b : a, es = low ? e : ej * 3 + ei, li = es * EBE_NBLK + hi * (hi + 1) / 2 + lo;
+                double     v  = s_C[li];
+                if (((ma >> ei) | (mb >> ej)) & 1)
+                  v = (a == b && ei == ej) ? fabs(v) : 0.0;
+                if (prm.ke && low && in) // the cell's own masked block, before it is summed into the global matrix (a concurrent
+                  s_C[li] = v;           // reader of the transposed entry masks it the same way: idempotent)
+                val[u] = v;
+                ptr[u] = (in && pos >= 0) ? prm.vals + int64_t(pos) * 9 + e : nullptr;
+                rd[u]  = ptr[u] && !((t >> 32) & 1); // first touch in processing order: plain store
+              }
 #pragma unroll
-          for (int k = 0; k < 9; ++k)
-            {
-              oab_[u][k] = (act[u] && !fab[u]) ? pab[u][k] : 0.0;
-              oba_[u][k] = (act[u] && !fba[u] && sa[u] != sb[u]) ? pba[u][k] : 0.0;
-            }
+            for (int u = 0; u < UB; ++u)
+              old[u] = rd[u] ? *ptr[u] : 0.0;
 #pragma unroll
-        for (int u = 0; u < NB; ++u)
-          if (act[u])
-            {
-              const int blk = tid + u * 256, a = sa[u], b = sb[u], ma = sma[u], mb = smb[u];
-              double    vab[9], vba[9];
-#pragma unroll
-              for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-                  {
-                    double v = s_C[(i * 3 + j) * EBE_NBLK + blk];
-                    if (((ma >> i) | (mb >> j)) & 1)
-                      v = (a == b && i == j) ? fabs(v) : 0.0;
-                    vab[i * 3 + j] = v;
-                    vba[j * 3 + i] = v;
-                  }
-              if (prm.ke) // the cell's own masked block, before it is summed into the global matrix
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                  s_C[k * EBE_NBLK + blk] = vab[k];
-#pragma unroll
-              for (int k = 0; k < 9; ++k)
-                pab[u][k] = vab[k] + oab_[u][k];
-              if (a != b)
-#pragma unroll
-                for (int k = 0; k < 9; ++k)
-                  pba[u][k] = vba[k] + oba_[u][k];
-            }
+            for (int u = 0; u < UB; ++u)
+              if (ptr[u])
+                *ptr[u] = val[u] + old[u];
+          }
         if (prm.ke)
           {
             __syncthreads();
@@ -1367,86 +1377,46 @@ namespace mi
       }
   }
 
-  // ------------------------------------------------------------------ block-CSR SpMV (cross-check variant)
-  // y = K x directly on the block-CSR: one wavefront per block row, lane = (block slot kb, entry e), so a wave
-  // reads 64/DD whole blocks (504 or 512 contiguous bytes) per step; the loads of up to MAXSTEPS steps are all
-  // issued before the first use.  Kept as an independent implementation to cross-check the sliced-ELL kernel
-  // (tests) and as the measured baseline in profiles/ (2.1 ms vs 1.45 ms at 5M DoFs).
-  // ABL (timing-only ablations, results wrong): 1 = x index independent of the column, 2 = no column / x loads
-  template <int D, int MAXSTEPS, int ABL = 0>
-  __global__ __launch_bounds__(256) void bsr_spmv_mlp(SpmvParams prm)
+  // ------------------------------------------------------------------ row-per-wave product (cross-check variant)
+  // y = K x read the other way round: one wavefront per block row, lane = (block of the row, entry), through the block
+  // pattern (rowptr / col) and the row's position in the value array -- shares neither the slice bookkeeping nor the
+  // column generator of the production kernel, which is what makes it a cross-check (tests; "spmv_variant" 1).
+  template <int D>
+  __global__ __launch_bounds__(256) void blockrow_spmv_check(SpmvParams prm)
   {
     if (prm.done && *prm.done)
       return;
-    constexpr int DD = D * D, BPW = 64 / DD, PW = (BPW > 8 ? 16 : 8);
+    constexpr int DD = D * D, BPW = 64 / DD;
     __shared__ double s_red[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int lb  = b;
+    const int     lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int     nwg = gridDim.x, b = blockIdx.x;
     const int64_t per = (prm.nrows + nwg - 1) / nwg;
-    const int64_t r0 = prm.row0 + lb * per, r1 = imin64(prm.row0 + prm.nrows, r0 + per);
+    const int64_t r0 = prm.row0 + b * per, r1 = imin64(prm.row0 + prm.nrows, r0 + per);
     const int     kb = lane / DD, e = lane - kb * DD, i = e / D, j = e - i * D;
-    const bool    act = kb < BPW;
     double        dsum = 0.0;
     for (int64_t row = r0 + wave; row < r1; row += 4)
       {
-        const int rr = __builtin_amdgcn_readfirstlane(int(row));
-        const int s = prm.rowptr[rr], nb = prm.rowptr[rr + 1] - s;
-        double    sacc = 0.0;
-        for (int base = 0; base < nb; base += MAXSTEPS * BPW)
+        const int     rr   = __builtin_amdgcn_readfirstlane(int(row));
+        const int     s    = prm.rowptr[rr], nb = prm.rowptr[rr + 1] - s;
+        const int64_t base = prm.rowbase[rr];
+        double        sacc = 0.0;
+        if (base >= 0 && kb < BPW)
+          for (int k = kb; k < nb; k += BPW)
+            sacc += prm.vals[(base + int64_t(k) * 64) * DD + e] * prm.x[int64_t(prm.col[s + k]) * D + j];
+        // sum over the lanes with the same i: entries (kb, i, *)
+        double tot[D];
+#pragma unroll
+        for (int ii = 0; ii < D; ++ii)
+          tot[ii] = wave_sum((kb < BPW && i == ii) ? sacc : 0.0);
+        if (lane < D && base >= 0)
           {
-            const int32_t *__restrict__ cp = prm.col + s + base + kb;
-            const double *__restrict__ vp  = prm.vals + int64_t(s + base) * DD + lane;
-            int32_t c[MAXSTEPS];
-            double  v[MAXSTEPS], xv[MAXSTEPS];
+            double v = tot[0];
 #pragma unroll
-            for (int st = 0; st < MAXSTEPS; ++st)
-              {
-                const bool ok = act && (base + st * BPW + kb < nb);
-                if constexpr (ABL == 2)
-                  c[st] = ok ? 0 : -1;
-                else
-                  c[st] = ok ? cp[st * BPW] : -1;
-              }
-#pragma unroll
-            for (int st = 0; st < MAXSTEPS; ++st)
-              v[st] = (c[st] >= 0) ? vp[st * BPW * DD] : 0.0;
-#pragma unroll
-            for (int st = 0; st < MAXSTEPS; ++st)
-              {
-                if constexpr (ABL == 0)
-                  xv[st] = (c[st] >= 0) ? prm.x[int64_t(c[st]) * D + j] : 0.0;
-                else if constexpr (ABL == 1)
-                  {
-                    asm volatile("" ::"v"(c[st]));
-                    xv[st] = (c[st] >= 0) ? prm.x[(row + st) * D + j] : 0.0;
-                  }
-                else
-                  xv[st] = 1.0;
-              }
-#pragma unroll
-            for (int st = 0; st < MAXSTEPS; ++st)
-              sacc += v[st] * xv[st];
-          }
-        if constexpr (D == 3)
-          {
-            const double t1 = __shfl_down(sacc, 1, 64), t2 = __shfl_down(sacc, 2, 64);
-            sacc += t1 + t2;
-          }
-        else
-          sacc += __shfl_down(sacc, 1, 64);
-#pragma unroll
-        for (int o = PW / 2; o >= 1; o >>= 1)
-          {
-            const double t1 = __shfl_down(sacc, o * DD, 64);
-            if (kb < o && kb + o < BPW)
-              sacc += t1;
-          }
-        if (kb == 0 && j == 0)
-          {
-            prm.y[row * D + i] = sacc;
+            for (int ii = 1; ii < D; ++ii)
+              v = lane == ii ? tot[ii] : v;
+            prm.y[row * D + lane] = v;
             if (prm.dotv)
-              dsum += sacc * prm.dotv[row * D + i];
+              dsum += v * prm.dotv[row * D + lane];
           }
       }
     if (prm.partials)
@@ -1459,31 +1429,56 @@ namespace mi
 
   // ------------------------------------------------------------------ sliced-ELL SpMV (production variant)
   // The block pattern of a box mesh has only dim+1 distinct row lengths, so rows are grouped by length into
-  // slices of 64 rows without padding inside a slice.  Layout: col[(off+k)*64 + lane],
-  // vals[((off+k)*DD + e)*64 + lane] -> every load of a wave is one contiguous 512-byte (256-byte for col)
-  // segment, lane = row, so there is no cross-lane reduction and neighbouring rows gather neighbouring x.
-  // One wavefront per slice (grid-stride), U blocks in flight per lane.
-  // ABL (timing only): 1 = x read at a coalesced slot-based index, 2 = no column / x loads
-  // NTL: 1 = matrix values and column indices loaded with the non-temporal hint (streamed once, no reuse: keeps the
-  //      L2 for the gathered x), 2 = values only
+  // slices of 64 rows without padding inside a slice, lane = row: no cross-lane reduction, neighbouring rows gather
+  // neighbouring x.  Since round 3 the values are stored the way the element scatter writes them -- block k of lane l
+  // at vals[((off+k)*64 + l)*DD + e], a block = DD contiguous doubles -- so that ONE array serves assembly and product
+  // (rounds 1-2 copied the block-CSR tangent into a [(off+k)*DD + e][64] layout before every solve: 3.3 ms and 15 GB
+  // of traffic per tangent at 5 M dofs).  For one k the 64 blocks of a slice are one contiguous chunk of 64*DD
+  // doubles; a wave loads G k-steps (G*64*DD*sizeof = 9 KiB for 3x3 fp64 blocks, G = 2) with fully coalesced 16-byte
+  // loads (1 KiB per wave instruction, non-temporal: the matrix is streamed once, the L2 is kept for the gathered x),
+  // stores the chunk linearly in the wave's own LDS buffer and reads its row's blocks back at a stride of DD
+  // doubles (ds_read_b64 at 72-byte stride: conflict-free, the bank of byte address a is (a/4) mod 64 and
+  // 18 l mod 64 takes 32 different even values over 32 lanes).  Measured with tools/probe/sellb_probe.hip at 5 M
+  // dofs: 1.30 ms against 1.34 ms for the transposed layout of round 2 (each lane loading its own 72 bytes straight
+  // from memory: 1.60 ms; LDS-DMA instead of register staging: 1.33-1.37 ms).  A row length that G does not divide
+  // leaves a tail of k-steps that every lane loads directly.
+  // One wavefront per slice (workgroups take contiguous runs of slices).
   // DOT: the CG's q = K p with the fused partials of p.q -- a separate instantiation so that profilers list the
   //      product the roofline figure is quoted on apart from the preconditioner's products
-  // F32: the matrix values come from the fp32-rounded copy (smoother only); all arithmetic stays fp64
+  // F32: the matrix values come from the fp32-rounded copy (smoother only, opt-in); all arithmetic stays fp64
   // CHEB: Chebyshev-Jacobi update fused into the epilogue (see SellParams), y is not written
   // ICOL: column indices generated from the row's column box (SellParams::rowbox) instead of read from memory
-  template <int D, int U, int ABL = 0, int NTL = 0, bool DOT = false, bool F32 = false, bool CHEB = false, bool ICOL = false>
+  // NTL: matrix values (and column indices) loaded with the non-temporal hint
+  template <int D, bool F32>
+  struct SellGroup
+  {
+    static constexpr int DD    = D * D;
+    static constexpr int VB    = F32 ? 4 : 8;                 // bytes per stored value
+    static constexpr int G     = (D == 3) ? (F32 ? 4 : 2) : 4; // k-steps per group: G*64*DD*VB is a multiple of 1 KiB
+    static constexpr int BYTES = G * 64 * DD * VB;
+    static constexpr int NLD   = BYTES / 1024; // 16-byte loads per lane and group
+    static_assert(BYTES % 1024 == 0, "a group is a whole number of 1 KiB wave loads");
+  };
+  template <int D, bool NTL = true, bool DOT = false, bool F32 = false, bool CHEB = false, bool ICOL = false>
   __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
       return;
-    constexpr int DD = D * D;
+    using SG                 = SellGroup<D, F32>;
+    constexpr int DD         = D * D, G = SG::G, NLD = SG::NLD;
+    using VT                 = typename std::conditional<F32, float, double>::type;
+    typedef int v4i __attribute__((ext_vector_type(4)));
     __shared__ double s_red[4];
+    __shared__ __attribute__((aligned(16))) char s_stage[4][SG::BYTES];
+    typedef const volatile __attribute__((address_space(3))) VT *lds_cvp;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwg = gridDim.x, b = blockIdx.x;
     const int lb  = (prm.xcd_remap && nwg % 8 == 0) ? (b % 8) * (nwg / 8) + b / 8 : b;
     const int per = (prm.nslices + nwg - 1) / nwg;
     const int s0 = prm.slice0 + lb * per, s1 = min(prm.slice0 + prm.nslices, s0 + per);
     double    dsum = 0.0;
+    v4i *const    stage_w = reinterpret_cast<v4i *>(s_stage[wave]) + lane;
+    const lds_cvp stage_r = (lds_cvp)(reinterpret_cast<VT *>(s_stage[wave]) + lane * DD);
     for (int sl0 = s0 + wave; sl0 < s1; sl0 += 4)
       {
         const int     sl  = __builtin_amdgcn_readfirstlane(sl0);
@@ -1491,9 +1486,9 @@ namespace mi
         const int64_t off = prm.off[sl];
         const int     node = prm.perm[int64_t(sl) * 64 + lane];
         const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
-        using VT = typename std::conditional<F32, float, double>::type;
-        const VT *__restrict__ vp = (F32 ? reinterpret_cast<const VT *>(prm.vals32) : reinterpret_cast<const VT *>(prm.vals)) +
-                                    off * (DD * 64) + lane;
+        const VT *__restrict__ vbase = (F32 ? reinterpret_cast<const VT *>(prm.vals32) : reinterpret_cast<const VT *>(prm.vals)) +
+                                       off * (DD * 64);
+        const v4i *__restrict__ gp = reinterpret_cast<const v4i *>(vbase) + lane;
         double acc[D];
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -1525,47 +1520,47 @@ namespace mi
           return c;
         };
         int k = 0;
-        for (; k + U <= len; k += U)
+        for (; k + G <= len; k += G)
           {
-            int32_t c[U];
-            double  v[U][DD], xx[U][D];
+            v4i     t[NLD];
+            int32_t c[G];
+            double  xx[G][D];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int j = 0; j < NLD; ++j)
+              t[j] = NTL ? __builtin_nontemporal_load(&gp[int64_t(k) * (DD * SG::VB * 4) + j * 64]) : gp[int64_t(k) * (DD * SG::VB * 4) + j * 64];
+#pragma unroll
+            for (int u = 0; u < G; ++u)
               {
                 if constexpr (ICOL)
                   c[u] = next_col();
                 else
-                  c[u] = (ABL == 2) ? 0 : (NTL == 1 ? __builtin_nontemporal_load(&cp[int64_t(k + u) * 64]) : cp[int64_t(k + u) * 64]);
+                  c[u] = NTL ? __builtin_nontemporal_load(&cp[int64_t(k + u) * 64]) : cp[int64_t(k + u) * 64];
               }
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-              for (int e = 0; e < DD; ++e)
-                v[u][e] = NTL ? __builtin_nontemporal_load(&vp[(int64_t(k + u) * DD + e) * 64]) : vp[(int64_t(k + u) * DD + e) * 64];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < G; ++u)
 #pragma unroll
               for (int j = 0; j < D; ++j)
-                {
-                  if constexpr (ABL == 1)
-                    {
-                      asm volatile("" ::"v"(c[u]));
-                      xx[u][j] = prm.x[(int64_t(sl) * 64 + lane) * D + j];
-                    }
-                  else if constexpr (ABL == 2)
-                    xx[u][j] = 1.0;
-                  else
-                    xx[u][j] = prm.x[int64_t(c[u]) * D + j];
-                }
+                xx[u][j] = prm.x[int64_t(c[u]) * D + j];
+            MI_WAVE_SYNC(); // the previous group's reads are done (the buffer is private to the wave)
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int j = 0; j < NLD; ++j)
+              stage_w[j * 64] = t[j];
+            MI_WAVE_SYNC();
 #pragma unroll
-              for (int i = 0; i < D; ++i)
+            for (int u = 0; u < G; ++u)
+              {
+                double v[DD];
 #pragma unroll
-                for (int j = 0; j < D; ++j)
-                  acc[i] += v[u][i * D + j] * xx[u][j];
+                for (int e = 0; e < DD; ++e)
+                  v[e] = double(stage_r[u * (64 * DD) + e]);
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                  for (int j = 0; j < D; ++j)
+                    acc[i] += v[i * D + j] * xx[u][j];
+              }
           }
-        for (; k < len; ++k)
+        for (; k < len; ++k) // tail: every lane loads its own block
           {
             int32_t c;
             if constexpr (ICOL)
@@ -1575,7 +1570,7 @@ namespace mi
             double v[DD], xx[D];
 #pragma unroll
             for (int e = 0; e < DD; ++e)
-              v[e] = vp[(int64_t(k) * DD + e) * 64];
+              v[e] = double(vbase[(int64_t(k) * 64 + lane) * DD + e]);
 #pragma unroll
             for (int j = 0; j < D; ++j)
               xx[j] = prm.x[int64_t(c) * D + j];
@@ -2035,7 +2030,10 @@ namespace mi
             if ((s_cm[a] >> lc) & 1)
               {
                 if (first)
-                  prm.y[yi] = prm.vals[int64_t(prm.diagpos[s_conn[a]]) * 9 + lc * 4] * prm.x[yi];
+                  {
+                    const int32_t dp = prm.diagpos[s_conn[a]]; // -1: ghost node of a slab (its y is never read)
+                    prm.y[yi]        = dp >= 0 ? prm.vals[int64_t(dp) * 9 + lc * 4] * prm.x[yi] : 0.0;
+                  }
               }
             else
               prm.y[yi] = first ? yv : yold[i] + yv;
@@ -2054,7 +2052,8 @@ namespace mi
     const int     c = int(g - n * 3);
     if ((prm.cmask[n] >> c) & 1)
       {
-        prm.y[g] = prm.vals[int64_t(prm.diagpos[n]) * 9 + c * 4] * prm.x[g];
+        const int32_t dp = prm.diagpos[n]; // -1: ghost node of a slab (its y is never read)
+        prm.y[g]         = dp >= 0 ? prm.vals[int64_t(dp) * 9 + c * 4] * prm.x[g] : 0.0;
         return;
       }
     const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
@@ -2114,60 +2113,11 @@ namespace mi
     xio[g]          = xio[g] + dn;
   }
 
-  // block-CSR -> sliced-ELL copy of the values (after every assembly); one wavefront per slice
-  template <int D>
-  __global__ __launch_bounds__(256) void bsr_to_sell(SellParams prm, const int32_t *__restrict__ rowptr,
-                                                     const double *__restrict__ bsr_vals, double *sell_vals,
-                                                     float *sell_vals32)
+  // fp32-rounded copy of the value array for the multigrid smoother (opt-in "precond_storage" 32; same layout)
+  __global__ __launch_bounds__(256) void vals_to_f32(const double *__restrict__ v, float *__restrict__ o, int64_t n)
   {
-    constexpr int DD = D * D;
-    const int     sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (sl >= prm.nslices)
-      return;
-    const int     node = prm.perm[int64_t(sl) * 64 + lane];
-    if (node < 0)
-      return; // padding rows stay zero
-    const int     len = prm.len[sl];
-    const int64_t off = prm.off[sl];
-    const double *__restrict__ src = bsr_vals + int64_t(rowptr[node]) * DD;
-    double *__restrict__ dst       = sell_vals + off * (DD * 64) + lane;
-    float *__restrict__ dst32      = sell_vals32 ? sell_vals32 + off * (DD * 64) + lane : nullptr;
-    // U blocks per trip: a lane then consumes U * 72 contiguous bytes while their cache lines are hot (one block per trip
-    // re-fetched half of every line: 12.0 GB read for 7.6 GB)
-    constexpr int U = 5; // the row lengths of 3D Q2 (27 / 45 / 75 / 125 blocks) are multiples of 5 but for the first
-    int           k = 0;
-    for (; k + U <= len; k += U)
-      {
-        double v[U][DD];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int e = 0; e < DD; ++e)
-            v[u][e] = src[(k + u) * DD + e];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int e = 0; e < DD; ++e)
-            {
-              dst[(int64_t(k + u) * DD + e) * 64] = v[u][e];
-              if (dst32)
-                dst32[(int64_t(k + u) * DD + e) * 64] = float(v[u][e]);
-            }
-      }
-    for (; k < len; ++k)
-      {
-        double v[DD];
-#pragma unroll
-        for (int e = 0; e < DD; ++e)
-          v[e] = src[k * DD + e];
-#pragma unroll
-        for (int e = 0; e < DD; ++e)
-          dst[(int64_t(k) * DD + e) * 64] = v[e];
-        if (dst32)
-#pragma unroll
-          for (int e = 0; e < DD; ++e)
-            dst32[(int64_t(k) * DD + e) * 64] = float(v[e]);
-      }
+    for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256)
+      o[i] = float(v[i]);
   }
 
   // one-off: sliced-ELL column indices from the block-CSR pattern (padding rows point at column 0)
@@ -2602,7 +2552,7 @@ namespace mi
         const int64_t off  = prm.off[sl];
         const int     node = prm.perm[int64_t(sl) * 64 + lane];
         const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
-        const double *__restrict__ vp  = prm.vals + off * (DD * 64) + lane;
+        const double *__restrict__ vp  = prm.vals + (off * 64 + lane) * DD; // the lane's own blocks (matrix <= 1 MiB: L2 hits)
         double acc[D];
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -2621,7 +2571,7 @@ namespace mi
             for (int u = 0; u < U; ++u)
 #pragma unroll
               for (int e = 0; e < DD; ++e)
-                v[u][e] = vp[(int64_t(k + u) * DD + e) * 64];
+                v[u][e] = vp[int64_t(k + u) * (64 * DD) + e];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -2641,7 +2591,7 @@ namespace mi
             double        v[DD], xx[D];
 #pragma unroll
             for (int e = 0; e < DD; ++e)
-              v[e] = vp[(int64_t(k) * DD + e) * 64];
+              v[e] = vp[int64_t(k) * (64 * DD) + e];
 #pragma unroll
             for (int j = 0; j < D; ++j)
               xx[j] = x[int64_t(c) * D + j];
@@ -2761,7 +2711,7 @@ namespace mi
             for (int i = 0; i < D; ++i)
 #pragma unroll
               for (int j = 0; j < D; ++j)
-                A[(node * D + i) * n + c * D + j] += prm.vals[((off + k) * DD + i * D + j) * 64 + lane];
+                A[(node * D + i) * n + c * D + j] += prm.vals[((off + k) * 64 + lane) * DD + i * D + j];
           }
       }
     __syncthreads();
@@ -2815,7 +2765,8 @@ namespace mi
       return;
     const int64_t n = i / D;
     const int     c = int(i - n * D);
-    dinv[i]         = 1.0 / vals[int64_t(diagpos[n]) * (D * D) + c * D + c];
+    const int32_t dp = diagpos[n]; // -1: the node has no row here (ghost node of a slab; its entries are never read)
+    dinv[i]          = dp >= 0 ? 1.0 / vals[int64_t(dp) * (D * D) + c * D + c] : 0.0;
   }
 
   // inverse of the DxD diagonal block of every node (block-Jacobi smoother of the multigrid).  Dirichlet rows and
@@ -2827,8 +2778,15 @@ namespace mi
     const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
     if (n >= nnodes)
       return;
-    const double *a = vals + int64_t(diagpos[n]) * (D * D);
     double       *o = dinv + n * (D * D);
+    if (diagpos[n] < 0) // no row here (ghost node of a slab; never read)
+      {
+#pragma unroll
+        for (int k = 0; k < D * D; ++k)
+          o[k] = 0.0;
+        return;
+      }
+    const double *a = vals + int64_t(diagpos[n]) * (D * D);
     if constexpr (D == 2)
       {
         const double r = 1.0 / (a[0] * a[3] - a[1] * a[2]);
@@ -3214,54 +3172,29 @@ namespace mi
   }
 
   template <int D>
-  static void launch_spmv_d(const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow)
+  static void launch_spmv_d(const SpmvParams &p, int grid, hipStream_t s, int variant)
   {
-    constexpr int DD = D * D, BPW = 64 / DD;
-    if (variant == 1)
-      {
-        const int steps = (maxrow + BPW - 1) / BPW;
-#define MI_MLP(N_)                                                                                   \
-  if (steps <= N_)                                                                                   \
-    {                                                                                                \
-      hipLaunchKernelGGL((bsr_spmv_mlp<D, N_>), dim3(grid), dim3(256), 0, s, p);                     \
-      return;                                                                                        \
-    }
-        MI_MLP(1) MI_MLP(2) MI_MLP(4) MI_MLP(6) MI_MLP(10) MI_MLP(18)
-#undef MI_MLP
-        hipLaunchKernelGGL((bsr_spmv_mlp<D, 18>), dim3(grid), dim3(256), 0, s, p);
-        return;
-      }
-    if (variant == 11 || variant == 12) // ablations of the mlp kernel (timing only)
-      {
-        if (variant == 11)
-          hipLaunchKernelGGL((bsr_spmv_mlp<D, 18, 1>), dim3(grid), dim3(256), 0, s, p);
-        else
-          hipLaunchKernelGGL((bsr_spmv_mlp<D, 18, 2>), dim3(grid), dim3(256), 0, s, p);
-        return;
-      }
+    constexpr int DD = D * D;
     if (variant == 13 || variant == 14) // pure streaming read of the value array, 8- / 16-byte loads
       {
-        const int64_t nvals = int64_t(p.rowptr_host_nnzb) * DD;
+        const int64_t nvals = p.nvalblocks * DD;
         if (variant == 13)
           hipLaunchKernelGGL((stream_read<8>), dim3(grid), dim3(256), 0, s, p.vals, nvals, p.y);
         else
           hipLaunchKernelGGL((stream_read<16>), dim3(grid), dim3(256), 0, s, p.vals, nvals, p.y);
         return;
       }
-    hipLaunchKernelGGL((bsr_spmv_mlp<D, 18>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((blockrow_spmv_check<D>), dim3(grid), dim3(256), 0, s, p);
   }
 
-  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow)
+  void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int /*maxrow*/)
   {
     if (dim == 3)
-      launch_spmv_d<3>(p, grid, s, variant, maxrow);
+      launch_spmv_d<3>(p, grid, s, variant);
     else
-      launch_spmv_d<2>(p, grid, s, variant, maxrow);
+      launch_spmv_d<2>(p, grid, s, variant);
   }
 
-  // unroll: 1..4 blocks in flight per lane; 5..7 = 2..4 with non-temporal matrix loads (5 is the default),
-  // 8 = 2 with non-temporal values only; -1, -2 timing-only ablations
-  // default load pipeline with generated column indices (SellParams::rowbox set)
   // profiling: events that bracket exactly the NEXT production sliced-ELL launch (kernel start / kernel end from the
   // dispatch itself, as a profiler sees it); plain events recorded around a launch also pick up the tails of its
   // neighbours in the stream
@@ -3272,90 +3205,54 @@ namespace mi
     g_ev_stop  = stop;
   }
 
-  template <int D, bool DOT, bool F32, bool CHEB>
-  static void sell_launch_icol(const SellParams &p, int grid, hipStream_t s)
+  template <int D, bool NTL, bool DOT, bool F32, bool CHEB, bool ICOL>
+  static void sell_launch(const SellParams &p, int grid, hipStream_t s)
   {
     const hipEvent_t a = g_ev_start, b = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
-    if constexpr (D == 3)
-      {
-        if (a && b)
-          hipExtLaunchKernelGGL((sell_spmv<3, 2, 0, 1, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, a, b, 0, p);
-        else
-          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
-      }
+    if (a && b)
+      hipExtLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(256), 0, s, a, b, 0, p);
     else
-      {
-        if (a && b)
-          hipExtLaunchKernelGGL((sell_spmv<2, 4, 0, 0, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, a, b, 0, p);
-        else
-          hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, DOT, F32, CHEB, true>), dim3(grid), dim3(256), 0, s, p);
-      }
+      hipLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(256), 0, s, p);
   }
-  template <int D>
-  static void sell_dispatch_icol(const SellParams &p, int grid, hipStream_t s)
+  template <int D, bool NTL, bool ICOL>
+  static void sell_dispatch(const SellParams &p, int grid, hipStream_t s)
   {
     const bool dot = p.dotv && p.partials, cheb = (p.cheb_d || p.cheb_b) && !dot, f32 = p.vals32 && !dot;
     if (dot)
-      sell_launch_icol<D, true, false, false>(p, grid, s);
+      sell_launch<D, NTL, true, false, false, ICOL>(p, grid, s);
     else if (cheb && f32)
-      sell_launch_icol<D, false, true, true>(p, grid, s);
+      sell_launch<D, NTL, false, true, true, ICOL>(p, grid, s);
     else if (cheb)
-      sell_launch_icol<D, false, false, true>(p, grid, s);
+      sell_launch<D, NTL, false, false, true, ICOL>(p, grid, s);
     else if (f32)
-      sell_launch_icol<D, false, true, false>(p, grid, s);
+      sell_launch<D, NTL, false, true, false, ICOL>(p, grid, s);
     else
-      sell_launch_icol<D, false, false, false>(p, grid, s);
+      sell_launch<D, NTL, false, false, false, ICOL>(p, grid, s);
   }
-
-  template <int D, bool DOT, bool F32 = false>
-  static void sell_dispatch(const SellParams &p, int grid, hipStream_t s, int unroll)
-  {
-#define MI_SELL(U, ABL, NTL) hipLaunchKernelGGL((sell_spmv<D, U, ABL, NTL, DOT, F32>), dim3(grid), dim3(256), 0, s, p)
-    if constexpr (D == 2)
-      MI_SELL(4, 0, 0);
-    else
-      switch (unroll)
-        {
-        case 1: MI_SELL(1, 0, 0); break;
-        case 2: MI_SELL(2, 0, 0); break;
-        case 3: MI_SELL(3, 0, 0); break;
-        case 4: MI_SELL(4, 0, 0); break;
-        case 6: MI_SELL(3, 0, 1); break;
-        case 7: MI_SELL(4, 0, 1); break;
-        case 8: MI_SELL(2, 0, 2); break;
-        case -1: MI_SELL(2, 1, 0); break;
-        case -2: MI_SELL(2, 2, 0); break;
-        default: MI_SELL(2, 0, 1); break;
-        }
-#undef MI_SELL
-  }
+  // unroll (tuning "sell_unroll"): 5 (default) = matrix loads with the non-temporal hint, anything else = plain loads;
+  // column indices are generated when SellParams::rowbox is set (lattice meshes), read from memory otherwise
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll)
   {
-    const bool dot = p.dotv && p.partials;
-    if (p.rowbox && unroll == 5) // production pipeline, columns generated
-      {
-        dim == 3 ? sell_dispatch_icol<3>(p, grid, s) : sell_dispatch_icol<2>(p, grid, s);
-        return;
-      }
-    if ((p.cheb_d || p.cheb_b) && !dot) // smoother step / residual fused into the product (default load pipeline only)
-      {
-        if (dim == 3 && p.vals32)
-          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, false, true, true>), dim3(grid), dim3(256), 0, s, p);
-        else if (dim == 3)
-          hipLaunchKernelGGL((sell_spmv<3, 2, 0, 1, false, false, true>), dim3(grid), dim3(256), 0, s, p);
-        else if (p.vals32)
-          hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, false, true, true>), dim3(grid), dim3(256), 0, s, p);
-        else
-          hipLaunchKernelGGL((sell_spmv<2, 4, 0, 0, false, false, true>), dim3(grid), dim3(256), 0, s, p);
-        return;
-      }
-    if (p.vals32 && !dot) // smoother products on the fp32-rounded copy
-      dim == 3 ? sell_dispatch<3, false, true>(p, grid, s, unroll) : sell_dispatch<2, false, true>(p, grid, s, unroll);
-    else if (dim == 3)
-      dot ? sell_dispatch<3, true>(p, grid, s, unroll) : sell_dispatch<3, false>(p, grid, s, unroll);
+    const bool nt = unroll == 5, icol = p.rowbox != nullptr;
+#define MI_SELL_GO(D_)                                                                               \
+  do                                                                                                 \
+    {                                                                                                \
+      if (nt && icol)                                                                                \
+        sell_dispatch<D_, true, true>(p, grid, s);                                                   \
+      else if (nt)                                                                                   \
+        sell_dispatch<D_, true, false>(p, grid, s);                                                  \
+      else if (icol)                                                                                 \
+        sell_dispatch<D_, false, true>(p, grid, s);                                                  \
+      else                                                                                           \
+        sell_dispatch<D_, false, false>(p, grid, s);                                                 \
+    }                                                                                                \
+  while (0)
+    if (dim == 3)
+      MI_SELL_GO(3);
     else
-      dot ? sell_dispatch<2, true>(p, grid, s, unroll) : sell_dispatch<2, false>(p, grid, s, unroll);
+      MI_SELL_GO(2);
+#undef MI_SELL_GO
   }
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,
                       hipEvent_t ev_stop)
@@ -3413,14 +3310,9 @@ namespace mi
     else
       hipLaunchKernelGGL(ebe_spmv, dim3(cell_count), dim3(384), 0, s, p, cell_begin);
   }
-  void launch_bsr_to_sell(int dim, const SellParams &p, const int32_t *rowptr, const double *bsr_vals,
-                          double *sell_vals, float *sell_vals32, hipStream_t s)
+  void launch_vals_to_f32(const double *vals, float *vals32, int64_t n, hipStream_t s)
   {
-    const int grid = (p.nslices + 3) / 4;
-    if (dim == 3)
-      hipLaunchKernelGGL((bsr_to_sell<3>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals, sell_vals32);
-    else
-      hipLaunchKernelGGL((bsr_to_sell<2>), dim3(grid), dim3(256), 0, s, p, rowptr, bsr_vals, sell_vals, sell_vals32);
+    hipLaunchKernelGGL(vals_to_f32, dim3(int(std::min<int64_t>((n + 255) / 256, 16384))), dim3(256), 0, s, vals, vals32, n);
   }
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s)

@@ -2,8 +2,8 @@
 // on the device context.
 //
 // Stiffness K and mass M are constant: they are assembled ONCE on the host (linear_elasticity.cc:248-374, the
-// reference does the same on the CPU) into the block-CSR pattern and converted to the sliced-ELL SpMV layout
-// in HBM.  The per-step path (assemble_rhs :378-454, solve :525-575, update_displacement :579-586) runs on the
+// reference does the same on the CPU) into the block pattern and uploaded in the device layout of the tangent
+// (slice-interleaved block rows, mi_mesh.hpp).  The per-step path (assemble_rhs :378-454, solve :525-575, update_displacement :579-586) runs on the
 // device: fused vector kernels, 2 SpMVs (M v - K (theta(1-theta)dt^2 v + dt d)) and the warm-started PCG.
 #include <cmath>
 #include <cstring>
@@ -130,17 +130,18 @@ namespace mi_detail
         }
     }
 
+    // host block-CSR values -> the device layout of the tangent (slice-interleaved block rows, owned rows only)
     int to_device_sell(mi_ctx *c, const std::vector<double> &bsr, double **d_sell)
     {
-      const size_t dd = size_t(c->dim) * c->dim;
-      HIPCHK(c, hipMalloc((void **)d_sell, size_t(c->mesh.sell_nblk64) * 64 * dd * sizeof(double)));
-      HIPCHK(c, hipMemsetAsync(*d_sell, 0, size_t(c->mesh.sell_nblk64) * 64 * dd * sizeof(double), c->stream));
-      HIPCHK(c, hipStreamSynchronize(c->stream));
-      HIPCHK(c, hipMemcpy(c->d_vals, bsr.data(), bsr.size() * sizeof(double), hipMemcpyHostToDevice));
-      mi::launch_bsr_to_sell(c->dim, sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr), c->d_rowptr, c->d_vals,
-                             *d_sell, nullptr, c->stream);
-      HIPCHK(c, hipGetLastError());
-      HIPCHK(c, hipStreamSynchronize(c->stream));
+      const mi::HostMesh &m  = c->mesh;
+      const size_t        dd = size_t(c->dim) * c->dim;
+      std::vector<double> v(std::max<size_t>(1, size_t(m.nvalblocks()) * dd), 0.0);
+      for (int64_t nd = 0; nd < m.nnodes; ++nd)
+        if (m.rowbase[size_t(nd)] >= 0)
+          for (int32_t b = m.rowptr[size_t(nd)]; b < m.rowptr[size_t(nd) + 1]; ++b)
+            std::memcpy(&v[size_t(m.valpos(nd, int(b - m.rowptr[size_t(nd)]))) * dd], &bsr[size_t(b) * dd], dd * sizeof(double));
+      HIPCHK(c, hipMalloc((void **)d_sell, v.size() * sizeof(double)));
+      HIPCHK(c, hipMemcpy(*d_sell, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
       return MI_OK;
     }
   } // namespace
@@ -321,7 +322,7 @@ static int linear_setup_member(mi_ctx *c, double theta)
       (rc = to_device_sell(c, L.hA, &L.d_A)))
     return rc;
   HIPCHK(c, hipMalloc((void **)&L.d_dinvA, size_t(c->n) * sizeof(double)));
-  mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, L.d_dinvA, m.nnodes, c->stream); // d_vals holds A
+  mi::launch_extract_dinv(c->dim, L.d_A, c->d_diagpos, L.d_dinvA, m.nnodes, c->stream);
   HIPCHK(c, hipGetLastError());
   if (L.body_force_enabled)
     {

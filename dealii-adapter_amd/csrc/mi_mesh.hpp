@@ -5,7 +5,10 @@
 // FE_Q(p)^dim DoFs, the all-components-couple sparsity (:339-345) and the Dirichlet index set of
 // make_constraints (:1094-1150).  Layout is chosen for the GPU, not translated from deal.II:
 //   * node-major DoF numbering  dof = dim*node + comp,  nodes lexicographic on the (p*reps+1)^dim lattice
-//   * tangent stored as block CSR with dim x dim blocks over nodes (every node pair couples in all components)
+//   * tangent stored as block rows with dim x dim blocks over nodes (every node pair couples in all components), in
+//     ONE layout shared by the element scatter and the SpMV: "slice-interleaved block rows" -- rows grouped by length
+//     into slices of 64, block k of the row in lane l of slice s at vals[((off[s] + k)*64 + l)*dim*dim + e]: a block is
+//     dim*dim contiguous doubles for the scatter, the 64 blocks a wave needs for one k are one contiguous chunk
 //   * cells grouped by parity colour (2^dim colours): two cells of one colour share no node, so a colour
 //     scatters into the matrix with plain read-modify-write
 //   * all per-cell arrays are stored in colour-sorted order so a colour's launch reads them contiguously
@@ -291,7 +294,13 @@ namespace mi
     std::vector<int64_t>  colour_begin; // [ncolours+1] into the colour-sorted order
     std::vector<int32_t>  rowptr;       // [nnodes+1] block rows
     std::vector<int32_t>  colidx;       // [nnzb]
-    std::vector<int32_t>  diagpos;      // [nnodes] block index of (node,node)
+    std::vector<int32_t>  diagpos;      // [nnodes] position of block (node,node) in the value array (in blocks; see rowbase),
+                                        // -1: the node has no row here
+    std::vector<int32_t>  diagk;        // [nnodes] slot of (node,node) within its row
+    std::vector<int32_t>  rowbase;      // [nnodes] position (in blocks) of slot 0 of the node's row in the value array; slot k
+                                        // is VAL_KSTRIDE blocks further; -1: no row here (ghost node of a slab: the row is
+                                        // complete on the neighbouring slab only)
+    static constexpr int  VAL_KSTRIDE = 64;
     std::vector<uint16_t> off;          // [ncells][npc][npc]: column slot of node b in block row of node a (bits 0-14);
                                         // bit 15: this cell is the FIRST (in processing order) to touch that block
     std::vector<uint32_t> node_first;   // [ncells] bit a set: this cell is the FIRST (in processing order) that contains
@@ -301,8 +310,8 @@ namespace mi
     std::vector<InterfaceFace> iface_faces;         // sorted by colour
     std::vector<int64_t>       iface_colour_begin;  // [ncolours+1]
 
-    // sliced-ELL view of the block pattern for the SpMV: rows grouped by length (a box mesh has at most
-    // 2^dim... in fact dim+1 distinct lengths), 64 rows per slice, lane = row, no padding inside a slice
+    // sliced-ELL view of the block pattern = THE storage order of the tangent: rows grouped by length (a box mesh has
+    // dim+1 distinct lengths), 64 rows per slice, lane = row, no padding inside a slice
     int64_t              sell_nslices = 0, sell_nblk64 = 0; // sum over slices of their length (units of 64 blocks)
     int64_t              sell_nslices_interior = 0;         // slices [0, this) hold rows without ghost columns
     std::vector<int32_t> sell_perm;                         // [nslices*64] node of a slot, -1 = padding row
@@ -435,7 +444,7 @@ namespace mi
         nnzb = run;
       }
       colidx.resize(size_t(nnzb));
-      diagpos.resize(size_t(nnodes));
+      diagk.resize(size_t(nnodes));
       for (int64_t n = 0; n < nnodes; ++n)
         {
           int ni[3], a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
@@ -449,7 +458,7 @@ namespace mi
                 {
                   const int64_t m = x + int64_t(nn[0]) * (y + int64_t(nn[1]) * z);
                   if (m == n)
-                    diagpos[size_t(n)] = int32_t(k);
+                    diagk[size_t(n)] = int32_t(k - rowptr[size_t(n)]);
                   colidx[size_t(k++)] = int32_t(m);
                 }
         }
@@ -662,6 +671,27 @@ namespace mi
       for (int64_t sl = 0; sl < sell_nslices; ++sl)
         sell_off[size_t(sl) + 1] = sell_off[size_t(sl)] + sell_len[size_t(sl)];
       sell_nblk64 = sell_off[size_t(sell_nslices)];
+      if (sell_nblk64 * 64 > INT32_MAX)
+        throw std::invalid_argument("more than 2^31 stored blocks: partition the mesh over more GPUs");
+      // where the element scatter finds the rows
+      rowbase.assign(size_t(nnodes), -1);
+      diagpos.assign(size_t(nnodes), -1);
+      for (size_t slot = 0; slot < sell_perm.size(); ++slot)
+        {
+          const int32_t n = sell_perm[slot];
+          if (n < 0)
+            continue;
+          rowbase[size_t(n)] = int32_t(sell_off[slot / 64] * 64 + int64_t(slot % 64));
+          diagpos[size_t(n)] = rowbase[size_t(n)] + diagk[size_t(n)] * VAL_KSTRIDE;
+        }
+    }
+
+    // number of dim x dim blocks of the value array (padding rows of the last slice of a length class included)
+    int64_t nvalblocks() const { return sell_nblk64 * 64; }
+    // position (in blocks) of slot k of the row of node n, -1 if the node has no row here
+    int64_t valpos(int64_t n, int k) const
+    {
+      return rowbase[size_t(n)] < 0 ? -1 : int64_t(rowbase[size_t(n)]) + int64_t(k) * VAL_KSTRIDE;
     }
   };
 } // namespace mi

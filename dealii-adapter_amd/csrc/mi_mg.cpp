@@ -564,7 +564,6 @@ namespace mi_detail
             for (mi_ctx *m : T.members)
               {
                 MgLevel &L = m->mg->levels[l];
-                refresh_sell(L.ctx);
                 mi::SellParams sp = sell_params(L.ctx, nullptr, nullptr, nullptr, nullptr, nullptr);
                 if (mi::launch_dense_inverse_from_sell(L.ctx->dim, sp, int(L.ctx->n), L.dense_inv, L.ctx->stream))
                   return fail(c0, MI_EINVAL, "multigrid: coarsest level too large for the dense solve");

@@ -1498,6 +1498,11 @@ double *orc_linear_vec(orc_linear *p, int which)
 // one pass of the time loop body: assemble_rhs :378-454, solve :525-575, update_displacement :579-586
 int orc_linear_step(orc_linear *p, int solver, int data_consistent, int *its, double *res)
 {
+  return orc_linear_step_tol(p, solver, data_consistent, 1e-10 /* :542 */, its, res);
+}
+// the same with the absolute CG tolerance of :542 as an argument (fixtures at tolerances tighter than the reference's)
+int orc_linear_step_tol(orc_linear *p, int solver, int data_consistent, double abs_tol, int *its, double *res)
+{
   const Mesh &m   = p->mesh;
   const int   dim = m.dim, npc = m.npc, n = p->ndofs;
   double     *rhs = p->v[ORC_L_SYSTEM_RHS].data();
@@ -1576,7 +1581,7 @@ int orc_linear_step(orc_linear *p, int solver, int data_consistent, int *its, do
   if (solver == ORC_SOLVER_DIRECT) // :553-559
     rc = solver_direct(A, vel, rhs);
   else // :531-551  abs tol 1e-10, SSOR 1.2, start from previous velocity
-    rc = solver_cg(A, vel, rhs, solver == ORC_SOLVER_CG_SSOR ? 0 : 1, 1.2, n /* multiplier 1 */, 1e-10, its, res);
+    rc = solver_cg(A, vel, rhs, solver == ORC_SOLVER_CG_SSOR ? 0 : 1, 1.2, n /* multiplier 1 */, abs_tol, its, res);
   for (int i = 0; i < n; ++i) // update_displacement :579-586
     {
       dis[i] += dt * theta * vel[i];

@@ -130,6 +130,8 @@ enum
 double *orc_linear_vec(orc_linear *p, int which);
 /* assemble_rhs + solve + update_displacement; data_consistent: 1 Stress, 0 Force */
 int orc_linear_step(orc_linear *p, int solver, int data_consistent, int *its, double *res);
+/* the same with the absolute CG tolerance (1e-10 at linear_elasticity.cc:542) as an argument */
+int orc_linear_step_tol(orc_linear *p, int solver, int data_consistent, double abs_tol, int *its, double *res);
 
 /* ---- Adapter::Time (time_handler.h:21-84) ---- */
 typedef struct

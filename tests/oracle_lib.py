@@ -142,6 +142,8 @@ def lib():
         L.orc_linear_vec.argtypes = [C.c_void_p, C.c_int]
         L.orc_linear_step.restype = C.c_int
         L.orc_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_int, ip, dp]
+        L.orc_linear_step_tol.restype = C.c_int
+        L.orc_linear_step_tol.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, ip, dp]
         L.orc_time_init.argtypes = [C.POINTER(Time), C.c_double, C.c_double]
         L.orc_time_increment.argtypes = [C.POINTER(Time)]
         L.orc_time_set_absolute.argtypes = [C.POINTER(Time), C.c_double]
@@ -337,7 +339,10 @@ class LinearProblem:
             return np.zeros(0, dtype=np.int32)
         return np.ctypeslib.as_array(lib().orc_linear_interface_nodes(self.h), shape=(k,)).copy()
 
-    def step(self, solver=SOLVER_DIRECT, data_consistent=True):
+    def step(self, solver=SOLVER_DIRECT, data_consistent=True, abs_tol=None):
         its, res = C.c_int(0), C.c_double(0)
-        rc = lib().orc_linear_step(self.h, solver, int(data_consistent), C.byref(its), C.byref(res))
+        if abs_tol is None:
+            rc = lib().orc_linear_step(self.h, solver, int(data_consistent), C.byref(its), C.byref(res))
+        else:
+            rc = lib().orc_linear_step_tol(self.h, solver, int(data_consistent), abs_tol, C.byref(its), C.byref(res))
         return rc, its.value, res.value

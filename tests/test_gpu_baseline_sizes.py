@@ -1,0 +1,152 @@
+"""The HIP path with DEFAULT tuning against oracle results at the BASELINE sizes (tests/golden/baseline_sizes.npz, written
+by tests/golden/make_golden_big.py from the CPU restatement of the reference algorithm).
+
+These are the sizes at which the product's default solver path is multigrid-PCG with the matrix-free smoother and the
+sum-factorised element kernel (above 100 k nodes); everything the oracle is compared with elsewhere runs on <= ~10 k DoFs,
+where the preconditioner is Jacobi and the smoother the assembled matrix.
+
+  blk24  24^3 Q2 cells (352,947 DoFs), two Newmark steps, linear tolerance 1e-12   [REF nonlinear_elasticity.cc:410-499]
+  cfg3   BASELINE configuration 3, 34^3 Q2 cells (985,527 DoFs), first step, "Residual" 1e-10
+  cfg4   BASELINE configuration 4, 59^3 Q2 cells (5,055,477 DoFs), one Newton iteration (residual, operator, update)
+  cfg2   BASELINE configuration 2, 40^3 Q1 cells of the linear model (206,763 DoFs), three theta-steps
+                                                                                    [REF linear_elasticity.cc:378-586]
+Compared: values at a lattice subsample of the nodes (same lexicographic node ids on both sides), the Euclidean norm of
+each whole vector and its inner product with w_i = cos(0.37 i + 0.11), the Newton table."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_pkg
+
+M = load_pkg()
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "baseline_sizes.npz")
+
+
+def _g():
+    return np.load(GOLD)
+
+
+def _w(n):
+    return np.cos(0.37 * np.arange(n, dtype=np.float64) + 0.11)
+
+
+def _fun(v):
+    return np.array([np.linalg.norm(v), float(v @ _w(v.size))])
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def _relfun(v, ref):
+    """functionals of a whole vector against the stored pair: both relative to the vector's norm"""
+    f = _fun(v)
+    return max(abs(f[0] / ref[0] - 1.0), abs(f[1] - ref[1]) / ref[0] / np.sqrt(v.size / 2.0))
+
+
+def test_fixture_layout():
+    g = _g()
+    for name, cells, p in (("blk24", 24, 2), ("cfg3", 34, 2), ("cfg4", 59, 2), ("cfg2", 40, 1)):
+        assert int(g[name + "_cells"]) == cells
+        ids = g[name + "_nodes"]
+        assert np.all(np.diff(ids) > 0) and ids[0] == 0 and ids[-1] == (p * cells + 1) ** 3 - 1
+    assert os.path.getsize(GOLD) < 1_000_000
+
+
+def test_oracle_reproduces_config2_fixture():
+    """seconds on CPU: the one case of the file the CPU suite can afford to regenerate"""
+    g = _g()
+    L = O.LinearProblem(O.make_desc(dim=3, degree=1, reps=(40,) * 3, hi=(10.0, 1.0, 1.0), theta=0.5))
+    inodes, ids = L.interface_nodes, g["cfg2_nodes"]
+    for s in range(2):
+        L.vec(O.L_STRESS)[:] = 0
+        for c in range(3):
+            L.vec(O.L_STRESS)[inodes * 3 + c] = g["cfg2_traction"][c]
+        rc, _, _ = L.step(O.SOLVER_CG_JACOBI, True, abs_tol=float(g["cfg2_abs_tol"]))
+        assert rc == 0
+        assert _rel(L.vec(O.L_D).reshape(-1, 3)[ids], g["cfg2_d"][s]) < 1e-11
+        assert _rel(L.vec(O.L_V).reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-11
+
+
+def _nonlinear(name, tol_u, tol_va):
+    g = _g()
+    n = int(g[name + "_cells"])
+    G = M.Context(dim=3, degree=2, reps=(n, n, n))
+    assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
+    ids = g[name + "_nodes"]
+    for s, trac in enumerate(g[name + "_traction"]):
+        G.set_interface_traction(trac)
+        rc, info = G.newmark_step(tol_lin=float(g[name + "_tol_lin"]), max_it_mult=2.0)
+        row = g[name + "_log"][s]
+        assert rc == 0 and info.converged == 1
+        assert [info.newton_iterations, info.assemblies] == [int(row[0]), int(row[1])]  # nonlinear_elasticity.cc:446-469
+        u = G.get(M.V_U)
+        assert _rel(u.reshape(-1, 3)[ids], g[name + "_u"][s]) < tol_u
+        assert _relfun(u, g[name + "_fun"][s][0]) < tol_u
+        for k, which in ((1, M.V_V), (2, M.V_A)):
+            assert _relfun(G.get(which), g[name + "_fun"][s][k]) < tol_va
+    assert G.get_tuning("smoother_operator_active") == 2  # the matrix-free smoother was what ran
+    assert _rel(G.get(M.V_V).reshape(-1, 3)[ids], g[name + "_v"]) < tol_va
+    assert _rel(G.get(M.V_A).reshape(-1, 3)[ids], g[name + "_a"]) < tol_va  # amplified by 1/dt^2
+    G.close()
+
+
+@pytest.mark.gpu
+def test_gpu_24cube_block_two_steps_default_path():
+    _nonlinear("blk24", 1e-8, 1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_config3_first_step_default_path():
+    _nonlinear("cfg3", 1e-8, 1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_config4_one_newton_iteration_default_path():
+    g = _g()
+    n = int(g["cfg4_cells"])
+    G = M.Context(dim=3, degree=2, reps=(n, n, n))
+    assert G.n == 5055477 and G.nnz == 952414353  # SURVEY.md section 8 size table
+    ids = g["cfg4_nodes"]
+    G.set_interface_traction(g["cfg4_traction"])
+    G.newton_begin_step()
+    G.update_acceleration()
+    rn = G.assemble()
+    assert abs(rn / float(g["cfg4_res_norm"]) - 1) < 1e-12                       # get_error_residual :549-560
+    rhs = G.get(M.V_RHS)
+    assert _rel(rhs.reshape(-1, 3)[ids], g["cfg4_rhs"]) < 1e-12 and _relfun(rhs, g["cfg4_rhs_fun"]) < 1e-12
+    Kw = G.spmv(_w(G.n))                                                         # the assembled tangent, 952 M non-zeros
+    assert _rel(Kw.reshape(-1, 3)[ids], g["cfg4_Kw"]) < 1e-12 and _relfun(Kw, g["cfg4_Kw_fun"]) < 1e-12
+    rc, its, res = G.cg_solve(float(g["cfg4_tol_lin"]), 2 * G.n)                 # :1153-1211, multigrid-PCG
+    assert rc == 0 and 0 < its < 40
+    assert G.get_tuning("smoother_operator_active") == 2
+    du = G.get(M.V_NEWTON)
+    assert _rel(du.reshape(-1, 3)[ids], g["cfg4_upd"]) < 1e-7 and _relfun(du, g["cfg4_upd_fun"]) < 1e-7
+    upd = G.apply_newton_update()
+    assert abs(upd / float(g["cfg4_upd_norm_unconstrained"]) - 1) < 1e-7         # get_error_update :564-576
+    G.close()
+
+
+@pytest.mark.gpu
+def test_gpu_config2_linear_model_three_steps():
+    g = _g()
+    n = int(g["cfg2_cells"])
+    G = M.Context(dim=3, degree=1, reps=(n, n, n), hi=(10.0, 1.0, 1.0))
+    assert G.n == 206763 and G.nnz == 15944049
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, 0.5) == 0, L.mi_last_error(G.h)
+    ids = g["cfg2_nodes"]
+    for s in range(3):
+        G.set_interface_traction(g["cfg2_traction"])
+        its, res = C.c_int(0), C.c_double(0)
+        assert L.mi_linear_step(G.h, 1, float(g["cfg2_abs_tol"]), 4 * G.n, C.byref(its), C.byref(res)) == 0, \
+            L.mi_last_error(G.h)
+        d, v = G.get(0), G.get(2)
+        assert _rel(d.reshape(-1, 3)[ids], g["cfg2_d"][s]) < 1e-8 and _rel(v.reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-8
+        assert _relfun(d, g["cfg2_fun"][s][0]) < 1e-8 and _relfun(v, g["cfg2_fun"][s][1]) < 1e-8
+    G.close()
