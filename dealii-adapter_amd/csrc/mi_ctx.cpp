@@ -128,7 +128,7 @@ namespace mi_detail
     p.conn   = c->d_conn;
     p.cverts = c->d_cverts;
     p.off    = c->d_off;
-    p.rowbase = c->d_rowbase;
+    p.rowinfo = reinterpret_cast<const int2 *>(c->d_rowinfo);
     p.cmask  = c->d_cmask;
     p.tab1d  = c->d_tab;
     p.u      = c->vec(MI_V_TOTAL_DISPLACEMENT);
@@ -144,7 +144,6 @@ namespace mi_detail
     for (int i = 0; i < 3; ++i)
       p.body[i] = c->mat.body_force[i];
     p.variant = c->asm_variant;
-    p.kstride = getenv("MI_LAYOUT_TEST") ? 1 : 64;
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
     return p;
@@ -176,7 +175,8 @@ namespace mi_detail
     mi::SpmvParams p{};
     p.rowptr           = c->d_rowptr;
     p.col              = c->d_col;
-    p.rowbase          = c->d_rowbase;
+    p.rowinfo          = reinterpret_cast<const int2 *>(c->d_rowinfo);
+    p.rowwx            = c->d_rowwx;
     p.vals             = c->active_sell_vals ? c->active_sell_vals : c->d_vals;
     p.x                = x;
     p.y                = y;
@@ -201,6 +201,7 @@ namespace mi_detail
     p.nn0       = c->mesh.nn[0];
     p.nn1       = c->mesh.nn[1];
     p.vals      = c->active_sell_vals ? c->active_sell_vals : c->d_vals;
+    p.wx        = c->d_sell_wx;
     p.x         = x;
     p.y         = y;
     p.dotv      = dotv;
@@ -885,7 +886,7 @@ namespace mi_detail
     void *ptrs[] = {c->d_conn,      c->d_rowptr,    c->d_col,         c->d_diagpos,     c->d_iface_nodes, c->d_faces,
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
-                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowbase,
+                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx,
                     c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base};
     for (void *p : ptrs)
       if (p)
@@ -947,8 +948,9 @@ namespace mi_detail
     UP(c->d_rowptr, m.rowptr)
     UP(c->d_col, m.colidx)
     UP(c->d_diagpos, m.diagpos)
-    if (getenv("MI_LAYOUT_TEST")) { std::vector<int32_t> rb(m.rowptr.begin(), m.rowptr.end() - 1); UP(c->d_rowbase, rb) } else
-    UP(c->d_rowbase, m.rowbase)
+    UP(c->d_rowinfo, m.rowinfo)
+    UP(c->d_rowwx, m.rowwx)
+    UP(c->d_sell_wx, m.sell_wx)
     UP(c->d_cmask, m.cmask)
     UP(c->d_iface_nodes, m.iface_nodes)
     {
@@ -1018,8 +1020,9 @@ namespace mi_detail
     c->grid_vec  = int(std::max<int64_t>(1, std::min<int64_t>(1024, (c->own_n + 255) / 256)));
     {
       const int64_t nin = m.sell_nslices_interior, nbd = m.sell_nslices - nin;
-      c->grid_spmv_bnd  = int(std::min<int64_t>(MAX_PART / 4, (nbd + 3) / 4));
-      c->grid_spmv_int  = int(std::min<int64_t>(MAX_PART - c->grid_spmv_bnd, (nin + 3) / 4));
+      constexpr int64_t W = mi::SELL_WPB; // one wavefront per slice, W wavefronts per workgroup
+      c->grid_spmv_bnd  = int(std::min<int64_t>(MAX_PART / 4, (nbd + W - 1) / W));
+      c->grid_spmv_int  = int(std::min<int64_t>(MAX_PART - c->grid_spmv_bnd, (nin + W - 1) / W));
       c->grid_spmv      = std::max(1, c->grid_spmv_int + c->grid_spmv_bnd);
       if (nin == 0 && nbd == 0)
         c->grid_spmv_int = 1;
@@ -2020,6 +2023,42 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_assembly = double(ms) / std::max(1, reps);
+  if (getenv("MI_ASM_STAMPS") && c->dim == 3 && c->degree == 2 && c->asm_variant == 0)
+    {
+      // diagnostic: where a workgroup of the sum-factorised element kernel spends its life (shader-clock stamps of one
+      // tangent wave at the phase boundaries), averaged over the cells of the first colour
+      const int64_t       ncell = c->mesh.colour_begin[1] - c->mesh.colour_begin[0];
+      unsigned long long *d_st  = nullptr;
+      HIPCHK(c, hipMalloc((void **)&d_st, size_t(ncell) * 8 * sizeof(unsigned long long)));
+      HIPCHK(c, hipMemsetAsync(d_st, 0, size_t(ncell) * 8 * sizeof(unsigned long long), c->stream));
+      mi::AsmParams p = asm_params(c);
+      p.cell_begin    = c->mesh.colour_begin[0];
+      p.cell_count    = int32_t(ncell);
+      p.stamps        = d_st;
+      mi::launch_assemble_cells(c->dim, c->degree, p, c->stream);
+      std::vector<unsigned long long> st(size_t(ncell) * 8);
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpy(st.data(), d_st, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      hipFree(d_st);
+      double             sum[7] = {0, 0, 0, 0, 0, 0, 0};
+      unsigned long long tmin = ~0ull, tmax = 0;
+      for (int64_t e = 0; e < ncell; ++e)
+        {
+          for (int i = 0; i < 6; ++i)
+            sum[i] += double(st[size_t(e) * 8 + i + 1] - st[size_t(e) * 8 + i]);
+          tmin = std::min(tmin, st[size_t(e) * 8]);
+          tmax = std::max(tmax, st[size_t(e) * 8 + 6]);
+        }
+      const char *name[6] = {"prologue (wave 0; tangent waves wait)", "contractions", "wait at barrier (2)", "image",
+                             "block table", "scatter"};
+      double      tot     = 0;
+      for (int i = 0; i < 6; ++i)
+        tot += sum[i];
+      fprintf(stderr, "assemble_q2sf phases, first colour (%lld cells; launch spans %.0f ticks):\n", (long long)ncell,
+              double(tmax - tmin));
+      for (int i = 0; i < 6; ++i)
+        fprintf(stderr, "  %-40s %8.0f ticks  %5.1f %%\n", name[i], sum[i] / double(ncell), 100.0 * sum[i] / tot);
+    }
   return sync(c);
 }
 

@@ -88,7 +88,9 @@ struct mi_ctx
   // device memory
   int32_t  *d_conn = nullptr, *d_rowptr = nullptr, *d_col = nullptr, *d_diagpos = nullptr, *d_iface_nodes = nullptr,
           *d_faces = nullptr, *d_flags = nullptr;
-  int32_t  *d_rowbase = nullptr; // [nnodes] where the row of a node starts in d_vals (mi::HostMesh::rowbase)
+  int32_t  *d_rowinfo = nullptr; // [nnodes][2] where the row of a node starts in d_vals and its g-stride (mi::HostMesh::rowinfo)
+  uint8_t  *d_rowwx = nullptr;   // [nnodes] x-width of the row's column box
+  int32_t  *d_sell_wx = nullptr; // [nslices]
   double   *d_cverts = nullptr, *d_tab = nullptr, *d_vals = nullptr, *d_vecs = nullptr, *d_work = nullptr,
          *d_saved = nullptr, *d_part = nullptr, *d_sc = nullptr, *d_iface_buf = nullptr;
   int32_t  *d_sell_perm = nullptr, *d_sell_len = nullptr, *d_sell_col = nullptr, *d_sell_box = nullptr;

@@ -11,21 +11,23 @@ namespace mi
     const int32_t  *conn;   // [ncells][npc]       colour-sorted
     const double   *cverts; // [ncells][2^dim][dim]
     const uint16_t *off;    // [ncells][npc][npc]
-    const int32_t  *rowbase; // [nnodes] position (in blocks) of slot 0 of the node's row in `vals`, slot k is 64 blocks
-                             // further (mi::HostMesh::rowbase); -1: no row here (ghost node of a slab) -> nothing stored
+    const int2     *rowinfo; // [nnodes] {base, gstride}: block (g, kx) of the node's row sits at base + g * gstride + kx of
+                             // `vals` (mi::HostMesh::rowinfo; off[] holds g << 4 | kx); base -1: no row here (ghost
+                             // node of a slab) -> nothing stored
     const uint8_t  *cmask;  // [nnodes]
     const double   *tab1d;  // N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1]
     const double   *u, *du, *acc, *stress;
     double         *rhs;
-    double         *vals;   // tangent, slice-interleaved block rows [(off+k)*64 + lane][dim*dim] -- the layout the SpMV reads
+    double         *vals;   // tangent, slice-interleaved block rows (mi_mesh.hpp) -- the layout the SpMV reads
     double          mu, kappa, rho, alpha1;
     double          body[3];
     int64_t         cell_begin;
     int32_t         cell_count;
     int32_t         variant; // kernel variant for A/B timing
-    int32_t         kstride; // EXPERIMENT
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
     double         *qrec;   // optional (3D Q2): the quadrature-point records the tangent is made of, [cell][MF_NREC][64] (see mf_spmv)
+    unsigned long long *stamps; // diagnostic (null in production): [cells of the launch][8] shader-clock stamps of one
+                                // tangent wave at the phase boundaries of assemble_q2sf (mi_bench_assemble, MI_ASM_STAMPS)
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
   };
@@ -69,7 +71,8 @@ namespace mi
   {
     const int32_t *rowptr;  // [nnodes+1] block pattern
     const int32_t *col;
-    const int32_t *rowbase; // [nnodes] as AsmParams::rowbase
+    const int2    *rowinfo; // [nnodes] as AsmParams::rowinfo
+    const uint8_t *rowwx;   // [nnodes] x-width of the row's column box
     const double  *vals;
     const double  *x;
     double        *y;
@@ -90,7 +93,8 @@ namespace mi
     const int32_t *rowbox; // optional [nslices*64][2]: first column and box widths of every row; when set the kernel
                            // generates the column indices instead of reading `col` (lattice meshes: columns form a box)
     int32_t        nn0, nn1; // lattice points along x and y (column = x + nn0 * (y + nn1 * z))
-    const double  *vals; // [(off+k)*64 + lane][DD]: the 64 blocks of one k are one contiguous chunk
+    const double  *vals; // x-line-interleaved block rows (mi_mesh.hpp)
+    const int32_t *wx;   // [nslices] x-width of the rows' column boxes
     const float   *vals32; // same layout, rounded to fp32: the smoother's copy (null: use vals)
     // fused Chebyshev-Jacobi epilogue (multigrid smoother; cheb_d == null: plain product).  Per owned row i:
     //   res = cheb_b - (K x); d = c1 d + c2 dinv res; cheb_xout = x + d   (x itself stays: other rows still gather it)
@@ -176,6 +180,7 @@ namespace mi
   // coarsest multigrid level: dense inverse of the level's sliced-ELL matrix (n <= 96, -1 otherwise) and its application
   int  launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s);
   void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s);
+  constexpr int SELL_WPB = 3;   // wavefronts (= slices in flight) per workgroup of sell_spmv: launch grids and dot partials count in these
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_vals_to_f32(const double *vals, float *vals32, int64_t n, hipStream_t s); // the smoother's fp32-rounded copy (opt-in)
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,

@@ -606,11 +606,12 @@ namespace mi
             const int32_t A = s_conn[a], B = s_conn[b];
             const int     ma = prm.cmask[A], mb = prm.cmask[B];
             const uint16_t oab = offc[a * NPC + b], oba = offc[b * NPC + a];
-            // slot k of a row sits 64 blocks after slot k-1 (slice-interleaved block rows, mi_mesh.hpp); a node without
-            // a row here (ghost node of a slab) stores nothing
-            const int32_t ra = prm.rowbase[A], rb = prm.rowbase[B];
-            double *__restrict__ pab = prm.vals + (int64_t(ra) + int64_t(oab & 0x7fff) * 64) * DD;
-            double *__restrict__ pba = prm.vals + (int64_t(rb) + int64_t(oba & 0x7fff) * 64) * DD;
+            // block (g, kx) of a row sits at base + g * gstride + kx (slice-interleaved block rows, mi_mesh.hpp); a node
+            // without a row here (ghost node of a slab) stores nothing
+            const int2    ia = prm.rowinfo[A], ib = prm.rowinfo[B];
+            const int32_t ra = ia.x, rb = ib.x;
+            double *__restrict__ pab = prm.vals + (int64_t(ra) + ((oab >> 4) & 0x7ff) * ia.y + (oab & 15)) * DD;
+            double *__restrict__ pba = prm.vals + (int64_t(rb) + ((oba >> 4) & 0x7ff) * ib.y + (oba & 15)) * DD;
             // bit 15: first touch of the block in processing order -> plain store instead of read-modify-write
             const bool first_ab = oab >> 15, first_ba = oba >> 15;
             double     vab[DD], vba[DD];
@@ -702,7 +703,9 @@ namespace mi
     constexpr int PS = 20, PW = 9 * PS, AO = 552;
     __shared__ __attribute__((aligned(16))) double s_C[RES_ONLY ? 2 : NF * FS]; // later the element tangent [9][378]
     __shared__ __attribute__((aligned(16))) double s_w[768 + 216];              // wave 0's scratch (as in mf_spmv)
-    __shared__ int s_conn[NPC];
+    __shared__ int  s_conn[NPC];
+    __shared__ int2 s_ri[RES_ONLY ? 1 : NPC]; // rowinfo of the cell's nodes (where their rows are in the global matrix)
+    __shared__ int  s_cm[RES_ONLY ? 1 : NPC]; // their constraint bits
     typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
     const int     tid  = threadIdx.x;
     const int64_t cell = prm.cell_begin + blockIdx.x;
@@ -717,6 +720,15 @@ namespace mi
           D[q][a] = prm.tab1d[12 + q * 3 + a];
         }
 
+    // diagnostic phase stamps (thread 64 = a lane of the first tangent wave; thread 0 in the residual-only form)
+#define MI_STAMP(i_)                                                                                   \
+  do                                                                                                   \
+    {                                                                                                  \
+      if (prm.stamps && tid == (RES_ONLY ? 0 : 64))                                                    \
+        prm.stamps[int64_t(blockIdx.x) * 8 + (i_)] = __builtin_amdgcn_s_memtime();                    \
+    }                                                                                                  \
+  while (0)
+    MI_STAMP(0);
     // state of wave 0 (lane = quadrature point) that lives across barrier (1); unused in waves 1-3
     const int     lane = tid & 63;
     double *const s0 = s_w, *const sE = s_w + 768;
@@ -750,6 +762,11 @@ namespace mi
           {
             node         = prm.conn[cell * NPC + lane];
             s_conn[lane] = node;
+            if constexpr (!RES_ONLY)
+              {
+                s_ri[lane] = prm.rowinfo[node];
+                s_cm[lane] = prm.cmask[node] & 7;
+              }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
               {
@@ -937,6 +954,7 @@ namespace mi
       }
     if constexpr (!RES_ONLY)
       __syncthreads(); // (1) fields complete -- the one barrier every wave of the workgroup passes, outside the role branches
+    MI_STAMP(1);
     if (tid < 64)
       {
         const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
@@ -1038,6 +1056,36 @@ namespace mi
           }
         if constexpr (RES_ONLY)
           return;
+        // ---- while the tangent waves contract: where the 729 node-pair blocks of this cell go.  One 64-bit word per
+        // block (a, b) in wave 0's own scratch, which the residual no longer needs: bits 0-31 position of the block in
+        // the global matrix (base + g * gstride + kx, mi_mesh.hpp; 0xffffffff: the node has no row here), 32-40 its place
+        // in the lower-triangle image of the element tangent, 41 a >= b (else: the transposed block of (b, a)),
+        // 42 first touch in processing order (plain store), 43 a == b, 44-46 / 47-49 constraint bits of A / B.
+        MI_WAVE_SYNC();
+        {
+          const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
+          uint64_t *const tab = reinterpret_cast<uint64_t *>(s_w);
+          uint16_t        o[12];
+#pragma unroll
+          for (int r = 0; r < 12; ++r) // all twelve (coalesced) loads in flight at once
+            o[r] = (r * 64 + lane < NPC * NPC) ? offc[r * 64 + lane] : uint16_t(0);
+#pragma unroll
+          for (int r = 0; r < 12; ++r)
+            {
+              const int blk = r * 64 + lane;
+              if (blk < NPC * NPC)
+                {
+                  const int      a = blk / NPC, b = blk - NPC * a;
+                  const int2     ri = s_ri[a];
+                  const uint32_t pos = ri.x >= 0 ? uint32_t(ri.x + int32_t((o[r] >> 4) & 0x7ff) * ri.y + int32_t(o[r] & 15)) : 0xffffffffu;
+                  const bool     low = a >= b;
+                  const int      hi = low ? a : b, lo = low ? b : a;
+                  tab[blk] = uint64_t(pos) | (uint64_t(hi * (hi + 1) / 2 + lo) << 32) | (uint64_t(low) << 41) |
+                             (uint64_t(o[r] >> 15) << 42) | (uint64_t(a == b) << 43) | (uint64_t(s_cm[a]) << 44) |
+                             (uint64_t(s_cm[b]) << 47);
+                }
+            }
+        }
       }
     if constexpr (!RES_ONLY)
       {
@@ -1104,7 +1152,9 @@ namespace mi
                       }
               }
           }
+        MI_STAMP(2);
         __syncthreads(); // (2) fields consumed: the element tangent image goes on top of them
+        MI_STAMP(3);
         if (active)
           {
 #pragma unroll
@@ -1126,66 +1176,94 @@ namespace mi
                   }
           }
         __syncthreads(); // (3) image complete
+        MI_STAMP(4);
+        MI_STAMP(5);
         // ---- tangent scatter.  [DEAL.II distribute_local_to_global] constrained rows/cols are dropped, the diagonal of a
-        // constrained dof receives |K_e(i,i)|.  Pass 1, one thread per node pair (a, b): position of the block in the
-        // global matrix (slot k of row A sits 64 blocks after slot k-1, mi_mesh.hpp; -1 when the node has no row here),
-        // first-touch flag, constraint bits -> LDS, in the part of s_C that the image leaves free.  Pass 2, lane = ENTRY
-        // of a block (9 consecutive lanes = one 72-byte block): a wave instruction then covers 7 whole blocks = 7 to 14
-        // cache lines instead of 64 pieces of 64 different blocks (one thread per block and nine 8-byte accesses each, the
-        // form of round 2, kept the address path busy with 10 k line accesses per cell: with the blocks of a row 4.6 kB
-        // apart in the single layout of round 3 that scatter took 35 % of a workgroup's life).  The old values of a batch
-        // of nine entries per lane are requested before anything is stored: three round trips per cell.
-        const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
-        uint64_t *const s_tab = reinterpret_cast<uint64_t *>(s_C + 9 * EBE_NBLK); // [729] behind the image [9][378]
-        static_assert(9 * EBE_NBLK + NPC * NPC <= NF * FS, "block table behind the tangent image");
-        for (int blk = tid; blk < NPC * NPC; blk += 256)
-          {
-            const int      a = blk / NPC, b = blk - NPC * a;
-            const int32_t  A = s_conn[a], B = s_conn[b];
-            const uint16_t o  = offc[blk];
-            const int32_t  ra = prm.rowbase[A];
-            const int32_t  pos = ra >= 0 ? ra + int32_t(o & 0x7fff) * prm.kstride : -1;
-            s_tab[blk] = uint64_t(uint32_t(pos)) | (uint64_t(o >> 15) << 32) | (uint64_t(prm.cmask[A] & 7) << 33) |
-                         (uint64_t(prm.cmask[B] & 7) << 36);
-          }
-        __syncthreads(); // (4) block table complete
-        constexpr int NE = NPC * NPC * 9, UB = 9; // 6561 entries, 27 per lane in 3 batches of 9
+        // constrained dof receives |K_e(i,i)|.  Lane = ENTRY of a block: thread t owns entry e = t % 9 of block t / 9 of
+        // every group of 28 blocks, so 9 consecutive lanes store one 72-byte block and a wave instruction covers 7 whole
+        // blocks (round 2: one thread per block and nine 8-byte accesses each, i.e. 64 pieces of 64 different blocks per
+        // instruction).  Everything that depends on the block comes out of wave 0's table in one LDS read; what depends
+        // on the entry is constant per thread.
+        {
+          const uint64_t *const tab = reinterpret_cast<const uint64_t *>(s_w);
+          const int      tq = tid / 9, e = tid - 9 * tq, ei = e / 3, ej = e - 3 * ei;
+          const int      src_low = e * EBE_NBLK, src_tr = (ej * 3 + ei) * EBE_NBLK; // image rows of the entry / its transpose
+          const uint32_t cm      = (1u << ei) | (8u << ej);                          // constraint bits that kill this entry
+          const bool     on_diag = ei == ej;
+          double *const  vbase   = prm.vals + e;
+          // phase A: the old values of every entry that is not a first touch, all requested before anything is stored
+          // (loads and stores share the wave's memory counter: a load issued after a store waits for that store).
+          // Batches of nine: the table words of a batch in one LDS round trip, then its nine loads.
+          double old[27];
+#pragma unroll
+          for (int bb = 0; bb < 27; bb += 9)
+            {
+              uint64_t t[9];
+#pragma unroll
+              for (int u = 0; u < 9; ++u)
+                {
+                  const int blk = (bb + u) * 28 + tq;
+                  t[u]          = tab[(tq < 28 && blk < NPC * NPC) ? blk : 0];
+                }
+#pragma unroll
+              for (int u = 0; u < 9; ++u)
+                {
+                  const int  blk = (bb + u) * 28 + tq;
+                  const bool rd  = tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu && !((t[u] >> 42) & 1);
+                  old[bb + u]    = rd ? vbase[int64_t(uint32_t(t[u])) * 9] : 0.0;
+                }
+            }
+          // phase B: masked entries out of the image, summed, stored; per batch two LDS round trips (table words, image)
+#pragma unroll
+          for (int bb = 0; bb < 27; bb += 9)
+            {
+              uint64_t t[9];
+              double   v[9];
+#pragma unroll
+              for (int u = 0; u < 9; ++u)
+                {
+                  const int blk = (bb + u) * 28 + tq;
+                  t[u]          = tab[(tq < 28 && blk < NPC * NPC) ? blk : 0];
+                }
+#pragma unroll
+              for (int u = 0; u < 9; ++u)
+                {
+                  const uint32_t fl = uint32_t(t[u] >> 32);
+                  v[u]              = s_C[((fl >> 9) & 1 ? src_low : src_tr) + int(fl & 511)];
+                }
+#pragma unroll
+              for (int u = 0; u < 9; ++u)
+                {
+                  const int      blk = (bb + u) * 28 + tq;
+                  const uint32_t fl  = uint32_t(t[u] >> 32);
+                  double         w_  = v[u];
+                  if ((fl >> 12) & cm)
+                    w_ = (((fl >> 11) & 1) && on_diag) ? fabs(w_) : 0.0;
+                  if (tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu)
+                    vbase[int64_t(uint32_t(t[u])) * 9] = w_ + old[bb + u];
+                }
+            }
+          if (prm.ke) // the cell's own masked blocks (what entered the global matrix) for the element-tangent product: the
+            {         // image is masked in place, in a pass of its own so that nothing above waits for LDS stores
+              __syncthreads();
 #pragma unroll 1
-        for (int base = 0; base < 27; base += UB)
-          {
-            double  val[UB], old[UB];
-            double *ptr[UB];
-            bool    rd[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-              {
-                const int  i  = (base + u) * 256 + tid;
-                const bool in = i < NE;
-                const int  blk = in ? i / 9 : 0, e = in ? i - 9 * blk : 0;
-                const int  a = blk / NPC, b = blk - NPC * a, ei = e / 3, ej = e - 3 * ei;
-                const uint64_t t   = s_tab[blk];
-                const int32_t  pos = int32_t(uint32_t(t));
-                const int      ma = int(t >> 33) & 7, mb = int(t >> 36) & 7;
-                // the image holds the lower triangle of the node order; (a, b) with a < b is the transposed block of (b, a)
-                const bool low = a >= b;
-                const int  hi = low ? a : b, lo = low ? b : a, es = low ? e : ej * 3 + ei, li = es * EBE_NBLK + hi * (hi + 1) / 2 + lo;
-                double     v  = s_C[li];
-                if (((ma >> ei) | (mb >> ej)) & 1)
-                  v = (a == b && ei == ej) ? fabs(v) : 0.0;
-                if (prm.ke && low && in) // the cell's own masked block, before it is summed into the global matrix (a concurrent
-                  s_C[li] = v;           // reader of the transposed entry masks it the same way: idempotent)
-                val[u] = v;
-                ptr[u] = (in && pos >= 0) ? prm.vals + int64_t(pos) * 9 + e : nullptr;
-                rd[u]  = ptr[u] && !((t >> 32) & 1); // first touch in processing order: plain store
-              }
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-              old[u] = rd[u] ? *ptr[u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-              if (ptr[u])
-                *ptr[u] = val[u] + old[u];
-          }
+              for (int u = 0; u < 27; ++u)
+                {
+                  const int blk = u * 28 + tq;
+                  if (tq < 28 && blk < NPC * NPC)
+                    {
+                      const uint32_t fl = uint32_t(tab[blk] >> 32);
+                      if (((fl >> 9) & 1) && ((fl >> 12) & cm))
+                        {
+                          const int li = src_low + int(fl & 511);
+                          s_C[li]      = (((fl >> 11) & 1) && on_diag) ? fabs(s_C[li]) : 0.0;
+                        }
+                    }
+                }
+            }
+        }
+        MI_STAMP(6);
+#undef MI_STAMP
         if (prm.ke)
           {
             __syncthreads();
@@ -1398,11 +1476,13 @@ namespace mi
       {
         const int     rr   = __builtin_amdgcn_readfirstlane(int(row));
         const int     s    = prm.rowptr[rr], nb = prm.rowptr[rr + 1] - s;
-        const int64_t base = prm.rowbase[rr];
+        const int2    ri   = prm.rowinfo[rr];
+        const int64_t base = ri.x;
+        const int     wx   = prm.rowwx[rr];
         double        sacc = 0.0;
         if (base >= 0 && kb < BPW)
           for (int k = kb; k < nb; k += BPW)
-            sacc += prm.vals[(base + int64_t(k) * 64) * DD + e] * prm.x[int64_t(prm.col[s + k]) * D + j];
+            sacc += prm.vals[(base + int64_t(k / wx) * ri.y + k % wx) * DD + e] * prm.x[int64_t(prm.col[s + k]) * D + j];
         // sum over the lanes with the same i: entries (kb, i, *)
         double tot[D];
 #pragma unroll
@@ -1428,202 +1508,196 @@ namespace mi
   }
 
   // ------------------------------------------------------------------ sliced-ELL SpMV (production variant)
-  // The block pattern of a box mesh has only dim+1 distinct row lengths, so rows are grouped by length into
-  // slices of 64 rows without padding inside a slice, lane = row: no cross-lane reduction, neighbouring rows gather
-  // neighbouring x.  Since round 3 the values are stored the way the element scatter writes them -- block k of lane l
-  // at vals[((off+k)*64 + l)*DD + e], a block = DD contiguous doubles -- so that ONE array serves assembly and product
-  // (rounds 1-2 copied the block-CSR tangent into a [(off+k)*DD + e][64] layout before every solve: 3.3 ms and 15 GB
-  // of traffic per tangent at 5 M dofs).  For one k the 64 blocks of a slice are one contiguous chunk of 64*DD
-  // doubles; a wave loads G k-steps (G*64*DD*sizeof = 9 KiB for 3x3 fp64 blocks, G = 2) with fully coalesced 16-byte
-  // loads (1 KiB per wave instruction, non-temporal: the matrix is streamed once, the L2 is kept for the gathered x),
-  // stores the chunk linearly in the wave's own LDS buffer and reads its row's blocks back at a stride of DD
-  // doubles (ds_read_b64 at 72-byte stride: conflict-free, the bank of byte address a is (a/4) mod 64 and
-  // 18 l mod 64 takes 32 different even values over 32 lanes).  Measured with tools/probe/sellb_probe.hip at 5 M
-  // dofs: 1.30 ms against 1.34 ms for the transposed layout of round 2 (each lane loading its own 72 bytes straight
-  // from memory: 1.60 ms; LDS-DMA instead of register staging: 1.33-1.37 ms).  A row length that G does not divide
-  // leaves a tail of k-steps that every lane loads directly.
-  // One wavefront per slice (workgroups take contiguous runs of slices).
+  // The block pattern of a box mesh has only a handful of distinct row shapes, so rows are grouped by (length, x-width
+  // of the column box) into slices of 64 rows without padding inside a slice, lane = row: no cross-lane reduction,
+  // neighbouring rows gather neighbouring x.  Since round 3 the values are stored the way the element scatter writes
+  // them, ONE array for assembly and product (rounds 1-2 copied the block-CSR tangent into a [(off+k)*DD + e][64]
+  // layout before every solve: 3.3 ms and 15 GB of traffic per tangent at 5 M dofs): x-line-interleaved block rows
+  // (mi_mesh.hpp) -- a block is DD contiguous doubles, the wx blocks of one x-line of a row's column box stay
+  // together (the runs of 3 blocks = 216 bytes a cell writes), and for one x-line g the 64 rows of a slice form ONE
+  // contiguous chunk of 64*wx*DD doubles (13.5 / 22.5 KiB for 3D Q2).  A wave brings a chunk into its own LDS buffer by
+  // LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, fully coalesced, no VGPRs, non-temporal: the matrix
+  // is streamed once, the L2 is kept for the gathered x) and reads its row's wx blocks back with ds_read_b64 at a
+  // stride of wx*DD doubles (216 / 360 bytes: conflict-free, the bank is (a/4) mod 64 and 54 l resp. 90 l mod 64 takes
+  // 32 different even values over a 32-lane group).  The columns of an x-line are consecutive nodes, so a lane's x
+  // values are one contiguous run of wx*D doubles.  Measured with tools/probe/sellb_probe.hip at 5 M dofs, same
+  // process: 1.255 ms (6.15 TB/s) against 1.358 ms for the transposed layout of round 2 and 1.32 ms for the
+  // slot-interleaved order [(off+k)*64 + lane][DD] (whose scatter, 72-byte blocks 4.6 kB apart, was 40 % slower).
+  // Chunks beyond the buffer (3D Q3 / Q4) are staged in two halves of 32 rows.
+  // One wavefront per slice; SELL_WPB waves per workgroup (their buffers: 3 x 22.5 KiB, two workgroups per CU).
   // DOT: the CG's q = K p with the fused partials of p.q -- a separate instantiation so that profilers list the
   //      product the roofline figure is quoted on apart from the preconditioner's products
   // F32: the matrix values come from the fp32-rounded copy (smoother only, opt-in); all arithmetic stays fp64
   // CHEB: Chebyshev-Jacobi update fused into the epilogue (see SellParams), y is not written
   // ICOL: column indices generated from the row's column box (SellParams::rowbox) instead of read from memory
-  // NTL: matrix values (and column indices) loaded with the non-temporal hint
-  template <int D, bool F32>
-  struct SellGroup
+  // NTL: matrix values loaded with the non-temporal hint
+  constexpr int SELL_STAGE_BYTES = 23040; // 64 rows x 5 blocks x 72 bytes: the largest chunk of 3D Q2
+  template <int D, int WXT, bool NTL, bool DOT, bool F32, bool CHEB, bool ICOL>
+  __device__ __forceinline__ void sell_slice(const SellParams &prm, const int sl, const int wx_rt, const int lane, char *stage,
+                                             double &dsum)
   {
-    static constexpr int DD    = D * D;
-    static constexpr int VB    = F32 ? 4 : 8;                 // bytes per stored value
-    static constexpr int G     = (D == 3) ? (F32 ? 4 : 2) : 4; // k-steps per group: G*64*DD*VB is a multiple of 1 KiB
-    static constexpr int BYTES = G * 64 * DD * VB;
-    static constexpr int NLD   = BYTES / 1024; // 16-byte loads per lane and group
-    static_assert(BYTES % 1024 == 0, "a group is a whole number of 1 KiB wave loads");
-  };
+    constexpr int DD = D * D, VB = F32 ? 4 : 8;
+    using VT         = typename std::conditional<F32, float, double>::type;
+    typedef const volatile __attribute__((address_space(3))) VT *lds_cvp;
+    typedef __attribute__((address_space(3))) void              *lds_vp;
+    typedef const __attribute__((address_space(1))) void        *glb_vp;
+    const int     wx    = WXT ? WXT : wx_rt;
+    const int     len   = prm.len[sl], ng = len / wx;
+    const int64_t off   = prm.off[sl];
+    const int     node  = prm.perm[int64_t(sl) * 64 + lane];
+    const int     chunk = 64 * wx * DD * VB;                    // bytes of one x-line of the slice
+    const int     ns    = chunk > SELL_STAGE_BYTES ? 2 : 1;     // staged whole, or in two halves of 32 rows
+    const int     rows  = 64 / ns, seg = chunk / ns, nfull = seg / 1024, rem = (seg % 1024) / 16;
+    const char *__restrict__ vbytes =
+      (F32 ? reinterpret_cast<const char *>(prm.vals32) : reinterpret_cast<const char *>(prm.vals)) + off * (64 * DD * VB) + lane * 16;
+    const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
+    const lds_cvp rd = (lds_cvp)(reinterpret_cast<VT *>(stage) + (lane % rows) * (wx * DD));
+    double        acc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      acc[i] = 0.0;
+    // first column of the current x-line of the row's column box; x-lines advance along y, then z
+    int32_t c0 = 0, gy = 0, wy = 1;
+    if constexpr (ICOL)
+      {
+        c0 = prm.rowbox[(int64_t(sl) * 64 + lane) * 2];
+        wy = (prm.rowbox[(int64_t(sl) * 64 + lane) * 2 + 1] >> 8) & 255;
+      }
+    constexpr int WXM = WXT ? WXT : 9; // widest x-line (3D / 2D Q4)
+    for (int g = 0; g < ng; ++g)
+      {
+        // x of the wx columns of this x-line
+        double xx[WXM * D];
+        if constexpr (ICOL)
+          {
+#pragma unroll
+            for (int j = 0; j < WXM * D; ++j)
+              if (WXT || j < wx * D)
+                xx[j] = prm.x[int64_t(c0) * D + j];
+            c0 += prm.nn0;
+            if (++gy == wy)
+              {
+                gy = 0;
+                c0 += prm.nn0 * (prm.nn1 - wy);
+              }
+          }
+        else
+          {
+#pragma unroll
+            for (int kx = 0; kx < WXM; ++kx)
+              if (WXT || kx < wx)
+                {
+                  const int32_t c = cp[int64_t(g * wx + kx) * 64];
+#pragma unroll
+                  for (int j = 0; j < D; ++j)
+                    xx[kx * D + j] = prm.x[int64_t(c) * D + j];
+                }
+          }
+        for (int s = 0; s < ns; ++s)
+          {
+            const char *src = vbytes + int64_t(g) * chunk + s * seg;
+            if constexpr (WXT != 0)
+              {
+#pragma unroll
+                for (int j = 0; j < (64 * WXT * DD * VB) / 1024; ++j)
+                  __builtin_amdgcn_global_load_lds((glb_vp)(src + j * 1024), (lds_vp)(stage + j * 1024), 16, 0, NTL ? 2 : 0);
+              }
+            else
+              for (int j = 0; j < nfull; ++j)
+                __builtin_amdgcn_global_load_lds((glb_vp)(src + j * 1024), (lds_vp)(stage + j * 1024), 16, 0, NTL ? 2 : 0);
+            if (lane < rem)
+              __builtin_amdgcn_global_load_lds((glb_vp)(src + nfull * 1024), (lds_vp)(stage + nfull * 1024), 16, 0, NTL ? 2 : 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the chunk has landed (and x has arrived)
+            MI_WAVE_SYNC();
+            if (ns == 1 || lane / rows == s)
+              {
+#pragma unroll
+                for (int kx = 0; kx < WXM; ++kx)
+                  if (WXT || kx < wx)
+                    {
+                      double v[DD];
+#pragma unroll
+                      for (int e = 0; e < DD; ++e)
+                        v[e] = double(rd[kx * DD + e]);
+#pragma unroll
+                      for (int i = 0; i < D; ++i)
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                          acc[i] += v[i * D + j] * xx[kx * D + j];
+                    }
+              }
+            MI_WAVE_SYNC(); // the buffer is free again
+          }
+      }
+    if (node >= 0)
+      {
+        double res[D];
+        if constexpr (CHEB)
+          {
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+              res[i] = prm.cheb_b[int64_t(node) * D + i] - acc[i];
+          }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          {
+            const int64_t idx = int64_t(node) * D + i;
+            if constexpr (CHEB)
+              {
+                if (prm.cheb_d)
+                  {
+                    double s = prm.cheb_dinv[idx] * res[i];
+                    if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
+                      {
+                        s = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D; ++j)
+                          s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
+                      }
+                    // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a
+                    // solve that broke down)
+                    const double dn    = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * prm.cheb_d[idx] : 0.0) + prm.cheb_c2 * s;
+                    prm.cheb_d[idx]    = dn;
+                    prm.cheb_xout[idx] = prm.x[idx] + dn;
+                  }
+                else
+                  prm.y[idx] = res[i]; // residual mode: y = b - K x
+              }
+            else
+              prm.y[idx] = acc[i];
+            if (DOT && node >= prm.own_begin && node < prm.own_end)
+              dsum += acc[i] * prm.dotv[idx];
+          }
+      }
+  }
+
   template <int D, bool NTL = true, bool DOT = false, bool F32 = false, bool CHEB = false, bool ICOL = false>
-  __global__ __launch_bounds__(256) void sell_spmv(SellParams prm)
+  __global__ __launch_bounds__(SELL_WPB * 64) void sell_spmv(SellParams prm)
   {
     if (prm.done && *prm.done)
       return;
-    using SG                 = SellGroup<D, F32>;
-    constexpr int DD         = D * D, G = SG::G, NLD = SG::NLD;
-    using VT                 = typename std::conditional<F32, float, double>::type;
-    typedef int v4i __attribute__((ext_vector_type(4)));
     __shared__ double s_red[4];
-    __shared__ __attribute__((aligned(16))) char s_stage[4][SG::BYTES];
-    typedef const volatile __attribute__((address_space(3))) VT *lds_cvp;
+    __shared__ __attribute__((aligned(16))) char s_stage[SELL_WPB][SELL_STAGE_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nwg = gridDim.x, b = blockIdx.x;
     const int lb  = (prm.xcd_remap && nwg % 8 == 0) ? (b % 8) * (nwg / 8) + b / 8 : b;
     const int per = (prm.nslices + nwg - 1) / nwg;
     const int s0 = prm.slice0 + lb * per, s1 = min(prm.slice0 + prm.nslices, s0 + per);
     double    dsum = 0.0;
-    v4i *const    stage_w = reinterpret_cast<v4i *>(s_stage[wave]) + lane;
-    const lds_cvp stage_r = (lds_cvp)(reinterpret_cast<VT *>(s_stage[wave]) + lane * DD);
-    for (int sl0 = s0 + wave; sl0 < s1; sl0 += 4)
+    for (int sl0 = s0 + wave; sl0 < s1; sl0 += SELL_WPB)
       {
-        const int     sl  = __builtin_amdgcn_readfirstlane(sl0);
-        const int     len = prm.len[sl];
-        const int64_t off = prm.off[sl];
-        const int     node = prm.perm[int64_t(sl) * 64 + lane];
-        const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
-        const VT *__restrict__ vbase = (F32 ? reinterpret_cast<const VT *>(prm.vals32) : reinterpret_cast<const VT *>(prm.vals)) +
-                                       off * (DD * 64);
-        const v4i *__restrict__ gp = reinterpret_cast<const v4i *>(vbase) + lane;
-        double acc[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-          acc[i] = 0.0;
-        // column generator: x fastest inside the box, then y, then z
-        int32_t g_cur = 0, g_cx = 0, g_cy = 0, g_wx = 1, g_wy = 1, g_jy = 0, g_jz = 0;
-        if constexpr (ICOL)
-          {
-            const int32_t b0 = prm.rowbox[(int64_t(sl) * 64 + lane) * 2], b1 = prm.rowbox[(int64_t(sl) * 64 + lane) * 2 + 1];
-            g_cur            = b0;
-            g_wx             = b1 & 255;
-            g_wy             = (b1 >> 8) & 255;
-            g_jy             = prm.nn0 - g_wx;
-            g_jz             = prm.nn0 * (prm.nn1 - g_wy);
-          }
-        auto next_col = [&]() {
-          const int32_t c = g_cur;
-          ++g_cur;
-          if (++g_cx == g_wx)
-            {
-              g_cx = 0;
-              g_cur += g_jy;
-              if (++g_cy == g_wy)
-                {
-                  g_cy = 0;
-                  g_cur += g_jz;
-                }
-            }
-          return c;
-        };
-        int k = 0;
-        for (; k + G <= len; k += G)
-          {
-            v4i     t[NLD];
-            int32_t c[G];
-            double  xx[G][D];
-#pragma unroll
-            for (int j = 0; j < NLD; ++j)
-              t[j] = NTL ? __builtin_nontemporal_load(&gp[int64_t(k) * (DD * SG::VB * 4) + j * 64]) : gp[int64_t(k) * (DD * SG::VB * 4) + j * 64];
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-              {
-                if constexpr (ICOL)
-                  c[u] = next_col();
-                else
-                  c[u] = NTL ? __builtin_nontemporal_load(&cp[int64_t(k + u) * 64]) : cp[int64_t(k + u) * 64];
-              }
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-#pragma unroll
-              for (int j = 0; j < D; ++j)
-                xx[u][j] = prm.x[int64_t(c[u]) * D + j];
-            MI_WAVE_SYNC(); // the previous group's reads are done (the buffer is private to the wave)
-#pragma unroll
-            for (int j = 0; j < NLD; ++j)
-              stage_w[j * 64] = t[j];
-            MI_WAVE_SYNC();
-#pragma unroll
-            for (int u = 0; u < G; ++u)
-              {
-                double v[DD];
-#pragma unroll
-                for (int e = 0; e < DD; ++e)
-                  v[e] = double(stage_r[u * (64 * DD) + e]);
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-#pragma unroll
-                  for (int j = 0; j < D; ++j)
-                    acc[i] += v[i * D + j] * xx[u][j];
-              }
-          }
-        for (; k < len; ++k) // tail: every lane loads its own block
-          {
-            int32_t c;
-            if constexpr (ICOL)
-              c = next_col();
-            else
-              c = cp[int64_t(k) * 64];
-            double v[DD], xx[D];
-#pragma unroll
-            for (int e = 0; e < DD; ++e)
-              v[e] = double(vbase[(int64_t(k) * 64 + lane) * DD + e]);
-#pragma unroll
-            for (int j = 0; j < D; ++j)
-              xx[j] = prm.x[int64_t(c) * D + j];
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-              for (int j = 0; j < D; ++j)
-                acc[i] += v[i * D + j] * xx[j];
-          }
-        if (node >= 0)
-          {
-            double res[D];
-            if constexpr (CHEB)
-              {
-#pragma unroll
-                for (int i = 0; i < D; ++i)
-                  res[i] = prm.cheb_b[int64_t(node) * D + i] - acc[i];
-              }
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-              {
-                const int64_t idx = int64_t(node) * D + i;
-                if constexpr (CHEB)
-                  {
-                    if (prm.cheb_d)
-                      {
-                        double s = prm.cheb_dinv[idx] * res[i];
-                        if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
-                          {
-                            s = 0.0;
-#pragma unroll
-                            for (int j = 0; j < D; ++j)
-                              s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
-                          }
-                        // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a
-                        // solve that broke down)
-                        const double dn    = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * prm.cheb_d[idx] : 0.0) + prm.cheb_c2 * s;
-                        prm.cheb_d[idx]    = dn;
-                        prm.cheb_xout[idx] = prm.x[idx] + dn;
-                      }
-                    else
-                      prm.y[idx] = res[i]; // residual mode: y = b - K x
-                  }
-                else
-                  prm.y[idx] = acc[i];
-                if (DOT && node >= prm.own_begin && node < prm.own_end)
-                  dsum += acc[i] * prm.dotv[idx];
-              }
-          }
+        const int sl = __builtin_amdgcn_readfirstlane(sl0);
+        const int wx = prm.wx[sl];
+        if (D == 3 && wx == 3) // the two x-widths of 3D Q2 rows, unrolled
+          sell_slice<D, (D == 3 ? 3 : 0), NTL, DOT, F32, CHEB, ICOL>(prm, sl, wx, lane, s_stage[wave], dsum);
+        else if (D == 3 && wx == 5)
+          sell_slice<D, (D == 3 ? 5 : 0), NTL, DOT, F32, CHEB, ICOL>(prm, sl, wx, lane, s_stage[wave], dsum);
+        else
+          sell_slice<D, 0, NTL, DOT, F32, CHEB, ICOL>(prm, sl, wx, lane, s_stage[wave], dsum);
       }
     if (DOT)
       {
-        const double tot = block_sum<256>(dsum, s_red);
+        const double tot = block_sum<SELL_WPB * 64>(dsum, s_red);
         if (threadIdx.x == 0)
           prm.partials[prm.part0 + b] = tot;
       }
@@ -2552,7 +2626,9 @@ namespace mi
         const int64_t off  = prm.off[sl];
         const int     node = prm.perm[int64_t(sl) * 64 + lane];
         const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
-        const double *__restrict__ vp  = prm.vals + (off * 64 + lane) * DD; // the lane's own blocks (matrix <= 1 MiB: L2 hits)
+        const int     wx   = prm.wx[sl]; // block k = (g, kx) of the lane at (off*64 + g*64*wx + lane*wx + kx) (mi_mesh.hpp)
+        const double *__restrict__ vp  = prm.vals + (off * 64 + int64_t(lane) * wx) * DD; // the lane's own blocks (matrix <= 1 MiB: L2 hits)
+        auto          bpos = [&](int k) { return (int64_t(k / wx) * (64 * wx) + k % wx) * DD; };
         double acc[D];
 #pragma unroll
         for (int i = 0; i < D; ++i)
@@ -2571,7 +2647,7 @@ namespace mi
             for (int u = 0; u < U; ++u)
 #pragma unroll
               for (int e = 0; e < DD; ++e)
-                v[u][e] = vp[int64_t(k + u) * (64 * DD) + e];
+                v[u][e] = vp[bpos(k + u) + e];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -2591,7 +2667,7 @@ namespace mi
             double        v[DD], xx[D];
 #pragma unroll
             for (int e = 0; e < DD; ++e)
-              v[e] = vp[int64_t(k) * (64 * DD) + e];
+              v[e] = vp[bpos(k) + e];
 #pragma unroll
             for (int j = 0; j < D; ++j)
               xx[j] = x[int64_t(c) * D + j];
@@ -2702,7 +2778,7 @@ namespace mi
         const int node = prm.perm[r];
         if (node < 0)
           continue;
-        const int     len = prm.len[sl];
+        const int     len = prm.len[sl], wx = prm.wx[sl];
         const int64_t off = prm.off[sl];
         for (int k = 0; k < len; ++k)
           {
@@ -2711,7 +2787,8 @@ namespace mi
             for (int i = 0; i < D; ++i)
 #pragma unroll
               for (int j = 0; j < D; ++j)
-                A[(node * D + i) * n + c * D + j] += prm.vals[((off + k) * 64 + lane) * DD + i * D + j];
+                A[(node * D + i) * n + c * D + j] +=
+                  prm.vals[(off * 64 + int64_t(k / wx) * (64 * wx) + lane * wx + k % wx) * DD + i * D + j];
           }
       }
     __syncthreads();
@@ -3211,9 +3288,9 @@ namespace mi
     const hipEvent_t a = g_ev_start, b = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
     if (a && b)
-      hipExtLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(256), 0, s, a, b, 0, p);
+      hipExtLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(SELL_WPB * 64), 0, s, a, b, 0, p);
     else
-      hipLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(SELL_WPB * 64), 0, s, p);
   }
   template <int D, bool NTL, bool ICOL>
   static void sell_dispatch(const SellParams &p, int grid, hipStream_t s)

@@ -137,7 +137,7 @@ namespace mi_detail
       const size_t        dd = size_t(c->dim) * c->dim;
       std::vector<double> v(std::max<size_t>(1, size_t(m.nvalblocks()) * dd), 0.0);
       for (int64_t nd = 0; nd < m.nnodes; ++nd)
-        if (m.rowbase[size_t(nd)] >= 0)
+        if (m.rowinfo[2 * size_t(nd)] >= 0)
           for (int32_t b = m.rowptr[size_t(nd)]; b < m.rowptr[size_t(nd) + 1]; ++b)
             std::memcpy(&v[size_t(m.valpos(nd, int(b - m.rowptr[size_t(nd)]))) * dd], &bsr[size_t(b) * dd], dd * sizeof(double));
       HIPCHK(c, hipMalloc((void **)d_sell, v.size() * sizeof(double)));
@@ -220,7 +220,8 @@ static int linear_setup_member(mi_ctx *c, double theta)
           const int32_t A = m.conn[size_t(cell) * npc + a];
           for (int b = 0; b < npc; ++b)
             {
-              const size_t blk = size_t(m.rowptr[size_t(A)]) + (off[a * npc + b] & 0x7fff); // bit 15 is the first-touch flag
+              // off = g << 4 | kx (bit 15: first-touch flag): slot k = g * wx + kx of the block row of A (mi_mesh.hpp)
+              const size_t blk = size_t(m.rowptr[size_t(A)]) + ((off[a * npc + b] >> 4) & 0x7ff) * m.rowwx[size_t(A)] + (off[a * npc + b] & 15);
               for (int ci = 0; ci < dim; ++ci)
                 {
                   for (int cj = 0; cj < dim; ++cj)

@@ -6,9 +6,10 @@
 // make_constraints (:1094-1150).  Layout is chosen for the GPU, not translated from deal.II:
 //   * node-major DoF numbering  dof = dim*node + comp,  nodes lexicographic on the (p*reps+1)^dim lattice
 //   * tangent stored as block rows with dim x dim blocks over nodes (every node pair couples in all components), in
-//     ONE layout shared by the element scatter and the SpMV: "slice-interleaved block rows" -- rows grouped by length
-//     into slices of 64, block k of the row in lane l of slice s at vals[((off[s] + k)*64 + l)*dim*dim + e]: a block is
-//     dim*dim contiguous doubles for the scatter, the 64 blocks a wave needs for one k are one contiguous chunk
+//     ONE layout shared by the element scatter and the SpMV: "x-line-interleaved block rows" -- rows grouped by shape
+//     into slices of 64; a block is dim*dim contiguous doubles, the blocks of one x-line of a row's column box stay
+//     together (what a cell writes in one run), and one x-line of all 64 rows of a slice is one contiguous chunk
+//     (what a wave of the SpMV streams in one go); see HostMesh::rowinfo
 //   * cells grouped by parity colour (2^dim colours): two cells of one colour share no node, so a colour
 //     scatters into the matrix with plain read-modify-write
 //   * all per-cell arrays are stored in colour-sorted order so a colour's launch reads them contiguously
@@ -16,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -297,12 +299,18 @@ namespace mi
     std::vector<int32_t>  diagpos;      // [nnodes] position of block (node,node) in the value array (in blocks; see rowbase),
                                         // -1: the node has no row here
     std::vector<int32_t>  diagk;        // [nnodes] slot of (node,node) within its row
-    std::vector<int32_t>  rowbase;      // [nnodes] position (in blocks) of slot 0 of the node's row in the value array; slot k
-                                        // is VAL_KSTRIDE blocks further; -1: no row here (ghost node of a slab: the row is
-                                        // complete on the neighbouring slab only)
-    static constexpr int  VAL_KSTRIDE = 64;
-    std::vector<uint16_t> off;          // [ncells][npc][npc]: column slot of node b in block row of node a (bits 0-14);
-                                        // bit 15: this cell is the FIRST (in processing order) to touch that block
+    std::vector<int32_t>  rowinfo;      // [nnodes][2] = {base, gstride}: slot k = (g, kx) of the node's row sits at block
+                                        // base + g * gstride + kx of the value array; base -1: no row here (ghost node of
+                                        // a slab: the row is complete on the neighbouring slab only)
+    std::vector<uint8_t>  rowwx;        // [nnodes] width of the row's column box along x
+    // storage order of the tangent, "x-line-interleaved block rows": rows grouped by (length, x-width wx of the column
+    // box) into slices of 64, lane = row (see build_sell); the wx blocks of one x-line of a row's column box stay
+    // together: block (g, kx) of lane l at off * 64 + g * 64 wx + l * wx + kx, i.e. gstride = 64 wx.  A cell writes runs
+    // of 3 blocks = 216 contiguous bytes (as it would into block-CSR rows), and for one x-line g the 64 rows of a slice
+    // are one contiguous chunk of 64 wx blocks for the SpMV.
+    std::vector<uint16_t> off;          // [ncells][npc][npc]: where block (a, b) sits in the row of node a: bits 0-3 kx,
+                                        // bits 4-14 g (see rowinfo); bit 15: this cell is the FIRST (in processing order)
+                                        // to touch that block
     std::vector<uint32_t> node_first;   // [ncells] bit a set: this cell is the FIRST (in processing order) that contains
                                         // its local node a -> a cell-by-cell product may store instead of add (no memset)
     std::vector<uint8_t>  cmask;        // [nnodes] bit c set: dof (node,c) is Dirichlet-constrained
@@ -316,6 +324,7 @@ namespace mi
     int64_t              sell_nslices_interior = 0;         // slices [0, this) hold rows without ghost columns
     std::vector<int32_t> sell_perm;                         // [nslices*64] node of a slot, -1 = padding row
     std::vector<int32_t> sell_len;                          // [nslices] blocks per row in the slice
+    std::vector<int32_t> sell_wx;                           // [nslices] x-width of the rows' column boxes (one per slice)
     std::vector<int64_t> sell_off;                          // [nslices+1] prefix sum of sell_len
     std::vector<int32_t> sell_box;                          // [nslices*64][2] first column, widths (wx | wy << 8) of the
                                                             // row's column box: columns need not be read from memory
@@ -580,6 +589,31 @@ namespace mi
                 }
           }
       }
+      // plain slot k -> (g, kx) of the storage order
+      rowwx.assign(size_t(nnodes), 0);
+      for (int64_t n = 0; n < nnodes; ++n)
+        {
+          int ni[3], a0, b0;
+          split(n, nn, dim, ni);
+          couple_range(0, ni[0], a0, b0);
+          rowwx[size_t(n)] = uint8_t(b0 - a0 + 1);
+        }
+      for (int64_t pos = 0; pos < ncells; ++pos)
+        {
+          const int32_t *cn = &conn[size_t(pos) * npc];
+          uint16_t      *co = &off[size_t(pos) * npc * npc];
+          for (int a = 0; a < npc; ++a)
+            {
+              const int wx = rowwx[size_t(cn[a])];
+              for (int b = 0; b < npc; ++b)
+                {
+                  const int k = co[a * npc + b] & 0x7fff, g = k / wx, kx = k % wx;
+                  if (g > 2047 || kx > 15)
+                    throw std::invalid_argument("row too long for the 11+4-bit scatter offsets");
+                  co[a * npc + b] = uint16_t((co[a * npc + b] & 0x8000) | (g << 4) | kx);
+                }
+            }
+        }
       // the same for nodes (cells with up to 32 nodes: every element of the 3D Q2 product; empty otherwise)
       node_first.clear();
       if (npc <= 32)
@@ -618,11 +652,16 @@ namespace mi
       std::vector<int32_t> lens;
       for (int64_t n = 0; n < nnodes; ++n)
         lens.push_back(rowptr[size_t(n) + 1] - rowptr[size_t(n)]);
-      std::vector<int32_t> classes(lens);
+      // a class = rows of one length and one x-width of the column box
+      auto cls = [&](int64_t n) { return int32_t(lens[size_t(n)] * 16 + rowwx[size_t(n)]); };
+      std::vector<int32_t> classes;
+      for (int64_t n = 0; n < nnodes; ++n)
+        classes.push_back(cls(n));
       std::sort(classes.begin(), classes.end());
       classes.erase(std::unique(classes.begin(), classes.end()), classes.end());
       sell_perm.clear();
       sell_len.clear();
+      sell_wx.clear();
       // interior rows (all columns owned) first, then the boundary rows, which read ghost columns and have to wait
       // for the halo exchange; the columns of a row ascend, so its first and last one decide
       auto boundary = [&](int64_t n) {
@@ -634,7 +673,7 @@ namespace mi
             {
               int64_t cnt = 0;
               for (int64_t n = own_begin; n < own_end; ++n)
-                if (lens[size_t(n)] == L && int(boundary(n)) == bnd)
+                if (cls(n) == L && int(boundary(n)) == bnd)
                   {
                     sell_perm.push_back(int32_t(n));
                     ++cnt;
@@ -645,7 +684,10 @@ namespace mi
                   ++cnt;
                 }
               for (int64_t sl = 0; sl < cnt / 64; ++sl)
-                sell_len.push_back(L);
+                {
+                  sell_len.push_back(L / 16);
+                  sell_wx.push_back(L % 16);
+                }
             }
           if (bnd == 0)
             sell_nslices_interior = int64_t(sell_len.size());
@@ -674,15 +716,17 @@ namespace mi
       if (sell_nblk64 * 64 > INT32_MAX)
         throw std::invalid_argument("more than 2^31 stored blocks: partition the mesh over more GPUs");
       // where the element scatter finds the rows
-      rowbase.assign(size_t(nnodes), -1);
+      rowinfo.assign(size_t(nnodes) * 2, -1);
       diagpos.assign(size_t(nnodes), -1);
       for (size_t slot = 0; slot < sell_perm.size(); ++slot)
         {
           const int32_t n = sell_perm[slot];
           if (n < 0)
             continue;
-          rowbase[size_t(n)] = int32_t(sell_off[slot / 64] * 64 + int64_t(slot % 64));
-          diagpos[size_t(n)] = rowbase[size_t(n)] + diagk[size_t(n)] * VAL_KSTRIDE;
+          const int wx               = rowwx[size_t(n)];
+          rowinfo[2 * size_t(n)]     = int32_t(sell_off[slot / 64] * 64 + int64_t(slot % 64) * wx);
+          rowinfo[2 * size_t(n) + 1] = 64 * wx;
+          diagpos[size_t(n)]         = int32_t(valpos(n, diagk[size_t(n)]));
         }
     }
 
@@ -691,7 +735,10 @@ namespace mi
     // position (in blocks) of slot k of the row of node n, -1 if the node has no row here
     int64_t valpos(int64_t n, int k) const
     {
-      return rowbase[size_t(n)] < 0 ? -1 : int64_t(rowbase[size_t(n)]) + int64_t(k) * VAL_KSTRIDE;
+      if (rowinfo[2 * size_t(n)] < 0)
+        return -1;
+      const int wx = rowwx[size_t(n)];
+      return int64_t(rowinfo[2 * size_t(n)]) + int64_t(k / wx) * rowinfo[2 * size_t(n) + 1] + k % wx;
     }
   };
 } // namespace mi

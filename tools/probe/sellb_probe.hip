@@ -48,6 +48,24 @@ __device__ __forceinline__ double hash_val(int64_t i)
   return double(int64_t(z >> 12) - (int64_t(1) << 51)) * (1.0 / double(int64_t(1) << 51));
 }
 
+// x-line-interleaved order (mi_mesh.hpp, val_layout 1): block (g, kx) of lane l of a slice with x-width wx at
+// off*64 + g*64*wx + l*wx + kx; one thread per (slice, k, lane)
+__global__ void fill_c(double *vc, const int64_t *off, const int32_t *len, const int32_t *wxs, int nslices)
+{
+  const int sl = blockIdx.x;
+  if (sl >= nslices)
+    return;
+  const int     L = len[sl], wx = wxs[sl];
+  const int64_t o = off[sl];
+  for (int i = threadIdx.x; i < L * 64; i += blockDim.x)
+    {
+      const int     k = i / 64, lane = i - 64 * k, g = k / wx, kx = k - g * wx;
+      const int64_t blk = o * 64 + int64_t(g) * 64 * wx + lane * wx + kx;
+      for (int e = 0; e < 9; ++e)
+        vc[blk * 9 + e] = hash_val(((o + k) * 64 + lane) * 9 + e); // the value the other layouts hold for (slice, k, lane, e)
+    }
+}
+
 // logical entry (slice-block index sb = off+k, lane, e) -> both layouts
 __global__ void fill(double *vt, double *vb, int64_t nblk64)
 {
@@ -380,6 +398,82 @@ __global__ __launch_bounds__(WPB * 64) void k_glds(P p)
     }
 }
 
+// ---------------------------------------------------------------- 4: x-line-interleaved order, LDS-DMA of a whole group
+// group g of a slice = 64 lanes x wx blocks = one contiguous chunk of 64*wx*72 bytes (13.5 / 22.5 KiB); the columns of a
+// group are consecutive nodes, so x is one contiguous run of 3*wx doubles per lane
+template <int WX>
+__device__ __forceinline__ void sellc_slice(const P &p, const int32_t *wxs, int sl, int lane, double *stage)
+{
+  typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
+  typedef __attribute__((address_space(3))) void                  *lds_vp;
+  typedef const __attribute__((address_space(1))) void            *glb_vp;
+  constexpr int CH = 64 * WX * 72, NFULL = CH / 1024, REM = (CH % 1024) / 16; // REM lanes in the last, partial DMA
+  const int     len = p.len[sl], ng = len / WX;
+  const int64_t off = p.off[sl];
+  const int     node = p.perm[int64_t(sl) * 64 + lane];
+  const char *__restrict__ gbase = reinterpret_cast<const char *>(p.vals + off * 576) + lane * 16;
+  // column box of the row: first column, widths
+  const int32_t b0 = p.rowbox[(int64_t(sl) * 64 + lane) * 2], b1 = p.rowbox[(int64_t(sl) * 64 + lane) * 2 + 1];
+  const int     wy = (b1 >> 8) & 255;
+  int32_t       c0 = b0;
+  int           gy = 0;
+  double        acc[3] = {0, 0, 0};
+  const lds_cvp rd = (lds_cvp)(stage + lane * (WX * 9));
+  for (int g = 0; g < ng; ++g)
+    {
+      const char *src = gbase + int64_t(g) * CH;
+#pragma unroll
+      for (int j = 0; j < NFULL; ++j)
+        __builtin_amdgcn_global_load_lds((glb_vp)(src + j * 1024), (lds_vp)(stage + j * 128), 16, 0, 2);
+      if (REM > 0 && lane < REM)
+        __builtin_amdgcn_global_load_lds((glb_vp)(src + NFULL * 1024), (lds_vp)(stage + NFULL * 128), 16, 0, 2);
+      double xx[WX * 3];
+#pragma unroll
+      for (int j = 0; j < WX * 3; ++j)
+        xx[j] = p.x[int64_t(c0) * 3 + j];
+      // next group's first column: next x-line of the box
+      c0 += p.nn0;
+      if (++gy == wy)
+        {
+          gy = 0;
+          c0 += p.nn0 * (p.nn1 - wy);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      WAVE_SYNC();
+#pragma unroll
+      for (int kx = 0; kx < WX; ++kx)
+        {
+          double v[9];
+#pragma unroll
+          for (int e = 0; e < 9; ++e)
+            v[e] = rd[kx * 9 + e];
+          FMA9(acc, v, (&xx[kx * 3]));
+        }
+      WAVE_SYNC();
+    }
+  if (node >= 0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      p.y[int64_t(node) * 3 + i] = acc[i];
+}
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void k_sellc(P p, const int32_t *wxs)
+{
+  __shared__ __attribute__((aligned(16))) double s_buf[WPB][2880]; // 23,040 bytes per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per  = (p.nslices + gridDim.x - 1) / gridDim.x;
+  const int s0 = blockIdx.x * per, s1 = min(p.nslices, s0 + per);
+  for (int sl0 = s0 + wave; sl0 < s1; sl0 += WPB)
+    {
+      const int sl = __builtin_amdgcn_readfirstlane(sl0);
+      if (wxs[sl] == 3)
+        sellc_slice<3>(p, wxs, sl, lane, s_buf[wave]);
+      else
+        sellc_slice<5>(p, wxs, sl, lane, s_buf[wave]);
+    }
+}
+
 int main(int argc, char **argv)
 {
   const int n    = argc > 1 ? atoi(argv[1]) : 59;
@@ -400,6 +494,12 @@ int main(int argc, char **argv)
   CHK(hipMalloc(&d_len, m.sell_len.size() * 4));
   CHK(hipMalloc(&d_box, m.sell_box.size() * 4));
   CHK(hipMalloc(&d_off, m.sell_off.size() * 8));
+  double  *d_vc;
+  int32_t *d_wx;
+  CHK(hipMalloc(&d_vc, nv * 8));
+  CHK(hipMemset(d_vc, 0, nv * 8));
+  CHK(hipMalloc(&d_wx, m.sell_wx.size() * 4));
+  CHK(hipMemcpy(d_wx, m.sell_wx.data(), m.sell_wx.size() * 4, hipMemcpyHostToDevice));
   CHK(hipMalloc(&d_vt, nv * 8));
   CHK(hipMalloc(&d_vb, nv * 8));
   CHK(hipMalloc(&d_x, size_t(m.ndofs) * 8));
@@ -414,6 +514,7 @@ int main(int argc, char **argv)
     hx[i] = std::sin(0.001 * double(i)) + 0.5;
   CHK(hipMemcpy(d_x, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(fill, dim3(unsigned((nv + 255) / 256)), dim3(256), 0, 0, d_vt, d_vb, int64_t(m.sell_nblk64));
+  hipLaunchKernelGGL(fill_c, dim3(unsigned(m.sell_nslices)), dim3(256), 0, 0, d_vc, d_off, d_len, d_wx, int(m.sell_nslices));
   CHK(hipDeviceSynchronize());
 
   P p{d_perm, d_len, d_box, d_off, d_vt, d_x, d_y0, int32_t(m.sell_nslices), m.nn[0], m.nn[1]};
@@ -423,9 +524,10 @@ int main(int argc, char **argv)
   CHK(hipEventCreate(&e1));
   std::vector<double> y0(size_t(m.ndofs)), y1(size_t(m.ndofs));
 
+  const double *which_vals = nullptr;
   auto run = [&](const char *name, auto launch, bool reference) {
     P q = p;
-    q.vals = reference ? d_vt : d_vb;
+    q.vals = which_vals ? which_vals : (reference ? d_vt : d_vb);
     q.y    = reference ? d_y0 : d_y;
     CHK(hipMemset(q.y, 0, size_t(m.ndofs) * 8));
     launch(q);
@@ -454,7 +556,7 @@ int main(int argc, char **argv)
     printf("%-44s avg %.3f ms  best %.3f ms  %.2f TB/s   max|dy| %.1e\n", name, sum / reps, best, gbytes / (sum / reps), err);
   };
   const int ns = int(m.sell_nslices);
-  for (int grid : {(ns + 3) / 4, (ns + 7) / 8, 4096, 2048})
+  for (int grid : {(ns + 3) / 4, (ns + 7) / 8})
     {
       printf("grid %d\n", grid);
       run("0 transposed layout U=2 (round 2)", [&](const P &q) { hipLaunchKernelGGL((k_ref<2>), dim3(grid), dim3(256), 0, 0, q); }, true);
@@ -464,6 +566,11 @@ int main(int argc, char **argv)
       run("2 registers -> LDS, 4 waves", [&](const P &q) { hipLaunchKernelGGL((k_lds<4>), dim3(grid), dim3(256), 0, 0, q); }, false);
       run("3 LDS-DMA 1 buffer, 4 waves", [&](const P &q) { hipLaunchKernelGGL((k_glds<4, 1>), dim3(grid), dim3(256), 0, 0, q); }, false);
       run("3 LDS-DMA 2 buffers, 4 waves", [&](const P &q) { hipLaunchKernelGGL((k_glds<4, 2>), dim3(grid), dim3(256), 0, 0, q); }, false);
+      which_vals = d_vc;
+      run("4 x-line order, LDS-DMA per group, 1 wave/WG", [&](const P &q) { hipLaunchKernelGGL((k_sellc<1>), dim3(grid * 4), dim3(64), 0, 0, q, d_wx); }, false);
+      run("4 x-line order, LDS-DMA per group, 2 waves/WG", [&](const P &q) { hipLaunchKernelGGL((k_sellc<2>), dim3(grid * 2), dim3(128), 0, 0, q, d_wx); }, false);
+      run("4 x-line order, LDS-DMA per group, 3 waves/WG", [&](const P &q) { hipLaunchKernelGGL((k_sellc<3>), dim3((grid * 4 + 2) / 3), dim3(192), 0, 0, q, d_wx); }, false);
+      which_vals = nullptr;
     }
   return 0;
 }
