@@ -26,6 +26,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector (non-MFMA) peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+MF_FLOPS_PER_LANE = 1060.0  # FP64 flop per lane of a cell's wavefront in mf_spmv (counter pass of profiles/r03, see roofline.fp64)
 CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")
 
 
@@ -412,9 +414,10 @@ def main():
                 "residual_only_passes_per_step": tm["assemble_residual"][1] / args.steps,
             },
             "roofline": {
-                "kernel": "sell_spmv<3,2,0,1,true,false,false,true> = <D=3, 2 blocks in flight, no ablation, non-temporal matrix "
-                          "loads, DOT=true, fp64 values, no fused smoother update, generated column indices>: the CG's q = K p with fused p.q partials on "
-                          "the sliced-ELL copy of the block-CSR tangent",
+                "kernel": "sell_spmv<3,true,true,false,false,true> = <D=3, non-temporal matrix loads, DOT=true, fp64 values, no fused "
+                          "smoother update, generated column indices>: the CG's q = K p with fused p.q partials on the assembled "
+                          "tangent itself (x-line-interleaved block rows: the array the element scatter writes is the array the "
+                          "product streams, 13.5 / 22.5 KiB chunks by LDS-DMA; no layout copy since round 3)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -487,7 +490,10 @@ def main():
                            "node, in the order of the colour-by-colour update) " if single else "eight launches ") +
                           "= one fine-level product of the multigrid smoother; the kernel with the largest share "
                           "of the step's GPU time",
-                "bound": "hbm",
+                # a ridge kernel, not an HBM stream: it moves 4.8x fewer bytes than the element tangents it replaced and
+                # sits at about half of BOTH the HBM and the FP64 vector roof (`fp64` below); `frac` stays the HBM fraction
+                # of its algorithmic bytes, as the task defines it
+                "bound": "hbm+valu" if form == 2 else "hbm",
                 "achieved": per_launch / (ebe_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -501,6 +507,15 @@ def main():
                 "share_of_step": tm["spmv_precond"][0] / args.steps / ms_step,
                 "cg_product": cg,
             }
+            if form == 2 and single:
+                # FP64 operations of one launch: per cell and lane-slot the kernel issues MF_FP64_OPS_PER_CELL_WAVE wave
+                # instructions of FP64 arithmetic (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of the committed counter pass, FMA = 2),
+                # i.e. counted over all 64 lanes of the cell's wavefront whether a stage uses them or not
+                flops = G.ncells * 64.0 * MF_FLOPS_PER_LANE
+                out["roofline"]["fp64"] = {
+                    "flops_per_launch": flops, "TFLOP_per_s": flops / (ebe_ms * 1e-3) / 1e12, "peak_TFLOP_per_s": FP64_VECTOR_PEAK_TF,
+                    "frac": flops / (ebe_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,
+                    "source": "profiles/r03/pmc_counters_mf_spmv_n59.json (2 x FMA + MUL + ADD wave instructions x 64 lanes per cell)"}
         out["roofline"]["whole_step"] = {
             "fine_level_products_per_step": n_prod, "algorithmic_GB_per_step": step_bytes / 1e9,
             "GB_per_s": step_bytes / 1e9 / (ms_step * 1e-3), "frac": step_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,

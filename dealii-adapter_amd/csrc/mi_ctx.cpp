@@ -40,6 +40,7 @@ namespace mi_detail
     SC_TOL = 2,
     SC_RES = 3,
     SC_BNORM = 4,
+    SC_INVERTED = 7, // set by the element kernels when a quadrature point has det F <= 0; travels with SC_NORM_RHS
     SC_NORM_RHS = 8,
     SC_NORM_UPD = 9,
     SC_TOT = 10 // [rr, rz, pq, bb] all-reduced totals of the distributed CG
@@ -146,6 +147,7 @@ namespace mi_detail
     p.variant = c->asm_variant;
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
+    p.inverted = c->d_sc + SC_INVERTED;
     return p;
   }
 
@@ -503,6 +505,7 @@ namespace mi_detail
   {
     // tangent_matrix = 0 (:1054) is implied: the first cell that touches a block stores instead of adding
     HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SYSTEM_RHS), 0, size_t(c->n) * sizeof(double), c->stream)); // :1055
+    HIPCHK(c, hipMemsetAsync(c->d_sc + SC_INVERTED, 0, sizeof(double), c->stream));
     mi::AsmParams p  = asm_params(c);
     p.residual_only  = residual_only ? 1 : 0;
     mi_ctx       *c0 = c->team->members[0];
@@ -618,20 +621,25 @@ namespace mi_detail
   }
 
   // l2 norm over the unconstrained owned dofs of vector `which`, summed over the team (:549-576)
-  int team_masked_norm(Team &T, int which, int slot, double *out)
+  // flag (optional): the scalar in the slot BEFORE `slot` travels with the norm (same all-reduce, same copy): the
+  // inverted-element flag of the assembly sits in front of the residual norm
+  int team_masked_norm(Team &T, int which, int slot, double *out, double *flag = nullptr)
   {
-    mi_ctx *c0 = T.members[0];
+    mi_ctx   *c0 = T.members[0];
+    const int ex = flag ? 1 : 0;
     for (mi_ctx *m : T.members)
       mi::launch_masked_norm(m->dim, m->vec(which) + m->own0, m->d_cmask + m->slab.own_begin, m->own_n, m->part(3),
                              m->grid_vec, m->d_sc + slot, m->stream);
-    int rc = team_allreduce(T, slot, 1);
+    int rc = team_allreduce(T, slot - ex, 1 + ex);
     if (rc)
       return rc;
     HIPCHK(c0, hipGetLastError());
-    HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc + slot, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+    HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc + slot - ex, (1 + ex) * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
     if ((rc = sync(c0)))
       return rc;
-    *out = std::sqrt(c0->h_pinned[0]);
+    if (flag)
+      *flag = c0->h_pinned[0];
+    *out = std::sqrt(c0->h_pinned[ex]);
     return MI_OK;
   }
 
@@ -1432,10 +1440,13 @@ static int assemble_impl(mi_ctx *c, bool residual_only, double *res_norm)
         return rc;
     }
   toc(c0, t);
-  double    nrm = 0;
-  const int rc  = team_masked_norm(T, MI_V_SYSTEM_RHS, SC_NORM_RHS, &nrm);
+  double    nrm = 0, inverted = 0;
+  const int rc  = team_masked_norm(T, MI_V_SYSTEM_RHS, SC_NORM_RHS, &nrm, &inverted);
   if (res_norm)
     *res_norm = nrm;
+  if (rc == MI_OK && inverted > 0.0) // the reference's debug build stops here too: Assert(det_F > 0) (:935)
+    return fail(c, MI_EINVAL, "inverted element: det F <= 0 at a quadrature point (the displacement has folded a cell; the "
+                              "reference asserts det F > 0, nonlinear_elasticity.cc:935)");
   return rc;
 }
 

@@ -26,6 +26,8 @@ namespace mi
     int32_t         variant; // kernel variant for A/B timing
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
     double         *qrec;   // optional (3D Q2): the quadrature-point records the tangent is made of, [cell][MF_NREC][64] (see mf_spmv)
+    double         *inverted; // set to 1.0 by any quadrature point with det F <= 0 (the reference asserts det F > 0 there,
+                              // nonlinear_elasticity.cc:935); sits next to the residual norm in the context's scalar block
     unsigned long long *stamps; // diagnostic (null in production): [cells of the launch][8] shader-clock stamps of one
                                 // tangent wave at the phase boundaries of assemble_q2sf (mi_bench_assemble, MI_ASM_STAMPS)
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored

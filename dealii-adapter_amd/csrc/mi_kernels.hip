@@ -392,6 +392,8 @@ namespace mi
                                                    0.0;
         double Finv[9], J, tau[6], tiso[6], cII, cS, Fq[9], Jmq, rJq;
         neo_hooke_qp<DIM>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS, Fq, Jmq, rJq);
+        if (!(J > 0.0)) // inverted element (nonlinear_elasticity.cc:935 asserts det F > 0)
+          *prm.inverted = 1.0;
         if (part == 0)
           {
             double *r = &s_qp[q * RQ];
@@ -870,6 +872,8 @@ namespace mi
             for (int j = 0; j < 3; ++j)
               gu[i * 3 + j] = gxi[i][0] * Ji[0 * 3 + j] + gxi[i][1] * Ji[1 * 3 + j] + gxi[i][2] * Ji[2 * 3 + j];
           neo_hooke_qp<3>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS, Fq, Jmq, rJq);
+          if (!(J > 0.0)) // inverted element (nonlinear_elasticity.cc:935 asserts det F > 0)
+            *prm.inverted = 1.0;
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll

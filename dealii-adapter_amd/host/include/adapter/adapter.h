@@ -12,6 +12,7 @@
 //   ParameterClass: participant_name, config_file, mesh_name, read_data_name, write_data_name
 #pragma once
 #include <iostream>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -31,7 +32,18 @@ namespace Adapter
       , mesh_name(parameters.mesh_name)
       , read_data_name(parameters.read_data_name)
       , write_data_name(parameters.write_data_name)
-    {}
+    {
+#ifdef MI_WITH_PRECICE
+      // With the real libprecice every process of tools/launch_elasticity.py would register as the ONE rank of the same
+      // participant (this_mpi_process = 0 of n_mpi_processes = 1, as in the reference, adapter.h:152-154, 217-220) and the
+      // coupling would see N copies of "Solid".  Until the ranks > 0 join as ranks of one participant with empty vertex
+      // sets, a multi-process run against libprecice is refused; MI_SLABS=N (one process) is not affected.
+      if (const char *w = std::getenv("MI_WORLD_SIZE"))
+        if (std::atoi(w) > 1)
+          throw std::runtime_error("MI_WORLD_SIZE > 1 is not supported in a -DMI_WITH_PRECICE build: every process would "
+                                   "register as the single rank of participant <" + parameters.participant_name + ">");
+#endif
+    }
 
     // adapter.h:229-342
     template <typename DoFSource>

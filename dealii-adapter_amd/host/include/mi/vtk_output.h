@@ -99,12 +99,17 @@ namespace mi
     }
   } // namespace vtk_detail
 
-  inline void write_vtk(const Device &dev, int dim, int p, const int reps[3], const std::string &path)
+  // EVERY rank of a decomposed run has to call this: mi_get_node_coords and mi_vec_get assemble global views through
+  // team collectives (ncclAllReduce under RCCL), which hang or pair up with the wrong collective when only one rank
+  // enters them.  write = false (ranks > 0): take part in the gathers, write nothing.
+  inline void write_vtk(const Device &dev, int dim, int p, const int reps[3], const std::string &path, bool write = true)
   {
     const int64_t       nn = mi_n_nodes(dev.ctx()), n = mi_n_dofs(dev.ctx());
     std::vector<double> xyz(size_t(nn) * dim), u(size_t(n), 0.0);
     dev.check(mi_get_node_coords(dev.ctx(), xyz.data()), "mi_get_node_coords");
     dev.check(mi_vec_get(dev.ctx(), MI_V_TOTAL_DISPLACEMENT, u.data(), n), "mi_vec_get");
+    if (!write)
+      return;
     std::ofstream out(path);
     if (!out)
       throw std::runtime_error("Cannot open output file <" + path + ">");

@@ -119,8 +119,8 @@ namespace Linear_Elasticity
     const unsigned int interval = parameters.output_interval > 0 ? parameters.output_interval : 1;
     std::ostringstream name;
     name << "solution-" << std::setw(3) << std::setfill('0') << time.get_timestep() / interval << ".vtk";
-    if (mi::host_rank() == 0)
-      mi::write_vtk(*device, dim, int(parameters.poly_degree), mesh_desc.reps, parameters.output_folder + "/" + name.str());
+    // all ranks: the global views behind the output are gathered by team collectives; rank 0 writes the file
+    mi::write_vtk(*device, dim, int(parameters.poly_degree), mesh_desc.reps, parameters.output_folder + "/" + name.str(), mi::host_rank() == 0);
     timer.leave_subsection("Output results");
   }
 

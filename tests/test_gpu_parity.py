@@ -539,3 +539,22 @@ def test_rejects_bad_arguments():
     buf = np.zeros(2)
     assert M.lib().mi_set_interface_traction(G.h, 1, M._dp(buf)) == M.MI_EINVAL
     assert b"interface nodes" in M.lib().mi_last_error(G.h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,p,reps", [(3, 2, (3, 3, 3)), (2, 3, (4, 3)), (3, 1, (3, 2, 2))])
+def test_inverted_element_is_reported(dim, p, reps):
+    """the reference asserts det F > 0 at every quadrature point (nonlinear_elasticity.cc:935, debug builds); the device
+    reports the same condition by name instead of iterating on a folded mesh"""
+    G = M.Context(dim=dim, degree=p, reps=reps)
+    G.set_interface_traction((0.0,) * dim)
+    G.update_acceleration()
+    assert np.isfinite(G.assemble())  # a regular state assembles
+    x = G.coords
+    u = np.zeros((G.nnodes, dim))
+    u[:, 0] = -2.5 * x[:, 0]  # F_xx = 1 - 2.5 < 0 everywhere
+    G.set(M.V_U, (u * (~G.constrained.reshape(-1, dim))).ravel())
+    with pytest.raises(M.MiError, match="inverted element"):
+        G.assemble()
+    G.set(M.V_U, np.zeros(G.n))  # the context survives
+    assert np.isfinite(G.assemble())

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Start the `elasticity` executable on N GPUs of one node: one process per GPU, the box cut into N z-slabs, ghost planes
 and reductions over RCCL (the reference is single-rank, adapter.h:152-154; this is the launcher DESIGN.md section 6
-describes).  Every process runs the same program on global views of the interface, so the preCICE side of the case is
-unchanged; rank 0 prints and writes the output files.
+describes).  Every process runs the same program on global views of the interface; with the replay participant (the
+default build) the coupling side of the case is therefore unchanged, and rank 0 prints and writes the output files.
+A -DMI_WITH_PRECICE build refuses MI_WORLD_SIZE > 1: N processes would each register as the single rank of the same
+preCICE participant (host/include/adapter/adapter.h).
 
   python tools/launch_elasticity.py -n 8 [--exe dealii-adapter_amd/host/elasticity3d] [parameters.prm]
 

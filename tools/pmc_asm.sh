@@ -1,5 +1,6 @@
 #!/bin/bash
 # Issue / LDS / wait counters of the default element kernel at the headline size: bash tools/pmc_asm.sh
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_asm; rm -rf $OUT; mkdir -p $OUT
 i=0

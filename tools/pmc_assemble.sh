@@ -1,6 +1,7 @@
 #!/bin/bash
 # Hardware counters of the element kernels (default and sum-factorised), one rocprofv3 --pmc pass per counter.
 #   bash tools/pmc_assemble.sh [cells]   -> gpurun_out/pmc_assemble_n<cells>.json
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 set -u
 N=${1:-59}
 OUT=gpurun_out/pmc_asm_n$N

@@ -1,5 +1,6 @@
 #!/bin/bash
 # LDS bank-conflict share of the default element kernel: bash tools/pmc_lds.sh
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_lds; rm -rf $OUT; mkdir -p $OUT
 for C in SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # Counters of the matrix-free fine-level product (mf_spmv) at the headline size: bash tools/pmc_mf.sh [kernel-substring]
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 K=${1:-mf_spmv}
 OUT=gpurun_out/pmc_mf; rm -rf $OUT; mkdir -p $OUT

@@ -2,6 +2,7 @@
 # HBM traffic of the SpMV kernel from hardware counters, one rocprofv3 --pmc pass per counter (MI355X guide:
 # separate passes, no tracing flags next to --pmc).  Run on the GPU box from the repo root:
 #   bash tools/pmc_spmv.sh [cells]      -> gpurun_out/pmc_spmv_n<cells>.json (+ raw counter averages)
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 set -u
 N=${1:-59}
 OUT=gpurun_out/pmc_n$N

@@ -2,6 +2,7 @@
 # The committed profile set of a round from ONE box, in one gpurun call: bash tools/profile_round.sh [outdir]
 # (rocprofv3 kernel trace of the bench command, the bench line of that process, PMC passes over the same command, the
 # plain default run with the CPU baseline, the A/B runs).  Copy what is wanted from <outdir> to profiles/<round>/.
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 set -u
 OUT=${1:-gpurun_out/round}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
