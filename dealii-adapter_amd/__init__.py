@@ -115,6 +115,8 @@ def lib():
         L.mi_comm_info.restype = C.c_int
         L.mi_cg_solve.argtypes = [vp, C.c_double, C.c_int64, C.POINTER(C.c_int), dp]
         L.mi_apply_newton_update.argtypes = [vp, dp]
+        L.mi_direct_solve.argtypes = [vp, dp]
+        L.mi_direct_solve.restype = C.c_int
         L.mi_newmark_step.argtypes = [vp, C.POINTER(SolverDesc), C.POINTER(StepInfo)]
         L.mi_vec_get.argtypes = [vp, C.c_int, dp, C.c_int64]
         L.mi_vec_set.argtypes = [vp, C.c_int, dp, C.c_int64]
@@ -322,6 +324,14 @@ class Context:
         if rc not in (MI_OK, MI_ENOCONV_LIN):
             self._chk(rc)
         return rc, its.value, res.value
+
+    def direct_solve(self):
+        """banded Cholesky of the current tangent + substitution (mi_direct_solve); returns the status code"""
+        r = C.c_double(0)
+        rc = lib().mi_direct_solve(self.h, C.byref(r))
+        if rc not in (MI_OK, MI_EINVAL, MI_ENOCONV_LIN):
+            self._chk(rc)
+        return rc
 
     def apply_newton_update(self):
         r = C.c_double(0)

@@ -227,6 +227,59 @@ namespace mi_detail
     c->vals32_stale = false;
   }
 
+  // ---- direct solver (banded Cholesky in one workgroup) for the sizes of the reference's own geometries
+  int direct_prepare(mi_ctx *c)
+  {
+    if (c->team->size != 1)
+      return fail(c, MI_EINVAL, "the direct solver runs on an undecomposed mesh only");
+    if (c->d_band)
+      return MI_OK;
+    std::vector<int32_t> perm;
+    const int            hbw = c->mesh.band_perm(perm);
+    const double         flops = double(c->n) * double(hbw) * double(hbw);
+    if (hbw >= mi::BAND_MAXH || flops > DIRECT_MAX_FLOPS)
+      return fail(c, MI_EINVAL, "system too large for the device direct solver (%lld dofs, half bandwidth %d): use the CG",
+                  (long long)c->n, hbw);
+    c->band_hbw = hbw;
+    int rc      = upload(c, &c->d_band_perm, perm);
+    if (rc)
+      return rc;
+    HIPCHK(c, hipMalloc((void **)&c->d_band, size_t(c->n) * size_t(hbw + 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc((void **)&c->d_band_work, size_t(c->n) * sizeof(double)));
+    return MI_OK;
+  }
+
+  int direct_factor_solve(mi_ctx *c, const double *vals, const double *b, double *x, bool factor, bool solve)
+  {
+    int rc = direct_prepare(c);
+    if (rc)
+      return rc;
+    int32_t *flag = c->d_flags + 3;
+    if (factor)
+      {
+        HIPCHK(c, hipMemsetAsync(flag, 0, sizeof(int32_t), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_band, 0, size_t(c->n) * size_t(c->band_hbw + 1) * sizeof(double), c->stream));
+        mi::SellParams sp = sell_params(c, nullptr, nullptr, nullptr, nullptr, nullptr);
+        sp.vals           = vals;
+        mi::launch_band_extract(c->dim, sp, c->d_band_perm, c->d_band, c->band_hbw, c->stream);
+      }
+    if (mi::launch_band_cholesky_solve(c->dim, c->d_band, int(c->n), c->band_hbw, c->d_band_perm, int(c->mesh.nnodes), b, x,
+                                       c->d_band_work, flag, factor, solve, c->stream))
+      return fail(c, MI_EINVAL, "band too wide for the device direct solver");
+    HIPCHK(c, hipGetLastError());
+    if (factor)
+      {
+        int32_t *h = reinterpret_cast<int32_t *>(c->h_pinned + 8);
+        HIPCHK(c, hipMemcpyAsync(h, flag, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        if ((rc = sync(c)))
+          return rc;
+        if (h[0])
+          return fail(c, MI_ENOCONV_LIN, "direct solver: the matrix is not positive definite (non-positive pivot in the "
+                                         "Cholesky factorisation)");
+      }
+    return MI_OK;
+  }
+
   // which unassembled form of the current tangent the element products use: 2 quadrature-point records (mf_spmv),
   // 1 element tangents (ebe_spmv), 0 none
   int element_form(const mi_ctx *c)
@@ -894,7 +947,7 @@ namespace mi_detail
     void *ptrs[] = {c->d_conn,      c->d_rowptr,    c->d_col,         c->d_diagpos,     c->d_iface_nodes, c->d_faces,
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
-                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx,
+                    c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
                     c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base};
     for (void *p : ptrs)
       if (p)
@@ -1537,6 +1590,26 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   return rc;
 }
 
+// SparseDirectUMFPACK of the reference (nonlinear_elasticity.cc:1192-1200): factorise the current tangent and solve
+int mi_direct_solve(mi_ctx *c, double *res)
+{
+  HIPCHK(c, hipSetDevice(c->device));
+  for (mi_ctx *m : c->team->members)
+    {
+      m->active_sell_vals = nullptr;
+      m->active_dinv      = nullptr;
+    }
+  c->newton_update_is_zero = false;
+  int rc = direct_factor_solve(c, c->d_vals, c->vec(MI_V_SYSTEM_RHS), c->vec(MI_V_NEWTON_UPDATE), true, true);
+  if (rc)
+    return rc;
+  mi::launch_zero_constrained(c->dim, c->vec(MI_V_NEWTON_UPDATE), c->d_cmask, c->n, c->stream); // :1208
+  HIPCHK(c, hipGetLastError());
+  if (res)
+    *res = 0.0; // lin_res = 0 (:1199)
+  return sync(c);
+}
+
 int mi_apply_newton_update(mi_ctx *c, double *upd_norm)
 {
   HIPCHK(c, hipSetDevice(c->device));
@@ -1615,7 +1688,16 @@ int mi_newmark_step(mi_ctx *c, const mi_solver_desc *s, mi_step_info *info)
         return rc;
       int    its = 0;
       double res = 0;
-      rc = mi_cg_solve(c, s->tol_lin, int64_t(double(mi_n_dofs(c)) * s->max_iterations_lin), &its, &res); // :472
+      if (c->solver_direct) // "Solver type = Direct" (:1192-1200); too large for the device factorisation: CG at 1e-12
+        {
+          its = 1;
+          rc  = mi_direct_solve(c, &res);
+          if (rc == MI_EINVAL)
+            rc = mi_cg_solve(c, std::min(s->tol_lin, 1e-12), int64_t(double(mi_n_dofs(c)) * std::max(10.0, s->max_iterations_lin)),
+                             &its, &res);
+        }
+      else
+        rc = mi_cg_solve(c, s->tol_lin, int64_t(double(mi_n_dofs(c)) * s->max_iterations_lin), &its, &res); // :472
       if (info->newton_iterations < 16)
         {
           info->lin_its[info->newton_iterations] = its;
@@ -1841,6 +1923,11 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
   const std::string k(key ? key : "");
   for (mi_ctx *m : c->team->members)
     {
+      if (k == "solver_type" && (value == 0 || value == 1))
+        {
+          m->solver_direct = value;
+          continue;
+        }
       if (k == "spmv_variant" && (value == 1 || value == 3 || value == 4 || (value >= 11 && value <= 14)))
         m->spmv_variant = value;
       else if (k == "smoother_operator" && value >= 0 && value <= 2)

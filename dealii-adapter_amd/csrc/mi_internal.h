@@ -34,6 +34,7 @@ namespace mi_detail
     const int32_t *done;
   };
   constexpr int64_t SMALL_CG_MAX_MATRIX_BYTES = 1 << 20;
+  constexpr double  DIRECT_MAX_FLOPS = 3.0e8; // n * hbw^2 of the banded Cholesky one workgroup is asked to do (a few ms)
   // Chebyshev-Jacobi step fused into the product (multigrid smoother): see mi::SellParams
   struct ChebFusion
   {
@@ -118,6 +119,11 @@ struct mi_ctx
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
   int       precond_storage = 64;
   int       small_cg = 1; // matrices up to SMALL_CG_MAX_MATRIX_BYTES on one slab: whole Jacobi-PCG in one launch
+  // banded Cholesky factor of a small tangent ("Solver type = Direct"), allocated on first use
+  double   *d_band = nullptr, *d_band_work = nullptr;
+  int32_t  *d_band_perm = nullptr;
+  int       band_hbw = 0;
+  int       solver_direct = 0; // tuning "solver_type" 1: mi_newmark_step / mi_linear_step solve with the banded Cholesky
   uint16_t *d_off   = nullptr;
   uint8_t  *d_cmask = nullptr;
   double   *h_pinned = nullptr; // pinned host scratch (scalars, flags, interface buffer)
@@ -174,6 +180,10 @@ namespace mi_detail
   int  tic(mi_ctx *c, int cls, bool ext = false);
   void toc(mi_ctx *c, int id);
   int  sync(mi_ctx *c);
+  // banded Cholesky on the device (small undecomposed problems): factor the matrix `vals` (tangent layout) and/or solve
+  // x = K^-1 b; MI_EINVAL when the problem is too large for it (the caller then iterates)
+  int            direct_prepare(mi_ctx *c);
+  int            direct_factor_solve(mi_ctx *c, const double *vals, const double *b, double *x, bool factor, bool solve);
   void           refresh_vals32(mi_ctx *c); // fp32-rounded copy of the current tangent (opt-in smoother storage), if stale
   int            element_form(const mi_ctx *c); // 2 quadrature-point records, 1 element tangents, 0 none (current tangent)
   bool           mf_gather_fusable(const mi_ctx *c); // the smoother's product is the single-launch matrix-free form

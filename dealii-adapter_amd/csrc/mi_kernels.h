@@ -182,6 +182,11 @@ namespace mi
   // coarsest multigrid level: dense inverse of the level's sliced-ELL matrix (n <= 96, -1 otherwise) and its application
   int  launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s);
   void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s);
+  // banded Cholesky of a small tangent (direct solver): see band_cholesky_solve in mi_kernels.hip
+  constexpr int BAND_NB = 16, BAND_MAXH = 512; // block-column width; the half bandwidth (in dofs) stays below BAND_MAXH
+  void launch_band_extract(int dim, const SellParams &p, const int32_t *bperm, double *band, int hbw, hipStream_t s);
+  int  launch_band_cholesky_solve(int dim, double *band, int n, int hbw, const int32_t *bperm, int nnodes, const double *b,
+                                  double *x, double *work, int32_t *flag, bool factor, bool solve, hipStream_t s); // -1: band too wide
   constexpr int SELL_WPB = 3;   // wavefronts (= slices in flight) per workgroup of sell_spmv: launch grids and dot partials count in these
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_vals_to_f32(const double *vals, float *vals32, int64_t n, hipStream_t s); // the smoother's fp32-rounded copy (opt-in)

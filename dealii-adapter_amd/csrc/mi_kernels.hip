@@ -2835,6 +2835,255 @@ namespace mi
     x[i] = s;
   }
 
+  // ------------------------------------------------------------------ banded Cholesky (direct solver for small systems)
+  // "Solver type = Direct" (the reference's shipped default, parameters.prm:43: SparseDirectUMFPACK re-factorised in every
+  // Newton iteration, nonlinear_elasticity.cc:1192-1200) for the sizes the reference's own geometries have: the tangent
+  // is symmetric positive definite (constrained rows carry their diagonal only), so K = L L^T in a band.  The nodes are
+  // renumbered with the SHORTEST lattice direction running fastest (HostMesh::band_perm): the FSI3 flap with 18 x 3 Q3
+  // cells has a half bandwidth of 67 dofs instead of 337.  Storage: lower band, column c at band[c*(hbw+1) + (r - c)],
+  // c <= r <= c + hbw.  band_extract fills it from the assembled rows; band_cholesky_solve is ONE workgroup of 1024
+  // threads that factorises in block columns of 16 (diagonal block by one wavefront in LDS, panel = one triangular
+  // solve per row, trailing update from the panel in LDS) and then substitutes forward and backward.  Latency bound by
+  // construction (three barriers per block column): 0.3-1 ms for 1-3 k dofs against 9 ms for the 2,300 Jacobi-PCG
+  // iterations the same solve took at 1e-12.
+  template <int D>
+  __global__ __launch_bounds__(256) void band_extract(SellParams prm, const int32_t *__restrict__ bperm, double *band, int hbw)
+  {
+    constexpr int DD = D * D;
+    const int     sl = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (sl >= prm.nslices)
+      return;
+    const int node = prm.perm[int64_t(sl) * 64 + lane];
+    if (node < 0)
+      return;
+    const int     len = prm.len[sl], wx = prm.wx[sl], ld = hbw + 1;
+    const int64_t off = prm.off[sl];
+    const int     pr  = bperm[node];
+    for (int k = 0; k < len; ++k)
+      {
+        const int     pc = bperm[prm.col[(off + k) * 64 + lane]];
+        const double *v  = prm.vals + (off * 64 + int64_t(k / wx) * (64 * wx) + lane * wx + k % wx) * DD;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < D; ++j)
+            {
+              const int r = pr * D + i, c = pc * D + j;
+              if (r >= c)
+                band[int64_t(c) * ld + (r - c)] = v[i * D + j];
+            }
+      }
+  }
+
+  // x = K^-1 b with K in `band` (overwritten by its factor).  b, x: vectors in the library's dof order (dof = D node + c);
+  // bperm: node -> band position; work: n doubles.  flag[0] = 1 when a pivot is not positive (K not positive definite).
+  // factor_only / solve_only split the two halves (the linear model factorises its constant matrix once).
+  template <int D>
+  __global__ __launch_bounds__(1024) void band_cholesky_solve(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
+                                                             int nnodes, const double *__restrict__ b, double *x, double *work,
+                                                             int32_t *flag, int do_factor, int do_solve)
+  {
+    constexpr int NB = BAND_NB;
+    __shared__ double sL[NB][NB + 1];
+    __shared__ double sP[BAND_MAXH][NB + 1];
+    __shared__ double sy[NB];
+    const int tid = threadIdx.x, ld = hbw + 1;
+    auto      A   = [&](int r, int c) -> double & { return band[int64_t(c) * ld + (r - c)]; }; // c <= r <= c + hbw
+    if (do_factor)
+      for (int j0 = 0; j0 < n; j0 += NB)
+        {
+          const int nb = min(NB, n - j0);
+          // (a) diagonal block -> LDS, factorised by the lanes of wave 0 (lane = row)
+          if (tid < NB * NB)
+            {
+              const int r = tid / NB, c = tid % NB;
+              sL[r][c]    = (r < nb && c <= r && r - c <= hbw) ? A(j0 + r, j0 + c) : 0.0; // outside the band: zero
+            }
+          __syncthreads();
+          if (tid < 64)
+            {
+              // lane r holds row r of the block in registers; the entry of another row comes by a lane read (the loops are
+              // fully unrolled: static register indices, 136 lane reads instead of 16 x 15 dependent LDS round trips)
+              double row[NB];
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                row[c] = sL[tid < NB ? tid : 0][c];
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                {
+                  const double d = __shfl(row[c], c, 64);
+                  if (c < nb && !(d > 0.0) && tid == 0)
+                    flag[0] = 1;
+                  const double rd = (c < nb) ? 1.0 / sqrt(d) : 1.0;
+                  if (tid >= c)
+                    row[c] *= rd; // column c of L (the diagonal becomes sqrt(d))
+#pragma unroll
+                  for (int c2 = c + 1; c2 < NB; ++c2)
+                    {
+                      const double l2 = __shfl(row[c], c2, 64); // L[c2][c]
+                      if (tid >= c2)
+                        row[c2] -= row[c] * l2;
+                    }
+                }
+              if (tid < NB)
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                  sL[tid][c] = (tid < nb && c <= tid) ? row[c] : (tid == c ? 1.0 : 0.0);
+            }
+          __syncthreads();
+          if (tid < NB * NB)
+            {
+              const int r = tid / NB, c = tid % NB;
+              if (r < nb && c <= r && r - c <= hbw)
+                A(j0 + r, j0 + c) = sL[r][c];
+            }
+          // (b) panel: the rows below the block that reach into its columns, one triangular solve per row
+          const int r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+          if (tid < m)
+            {
+              const int r = r0 + tid;
+              double    xr[NB];
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                {
+                  double a = (c < nb && r - (j0 + c) <= hbw) ? A(r, j0 + c) : 0.0;
+                  for (int q = 0; q < c; ++q)
+                    a -= xr[q] * sL[c][q];
+                  xr[c] = c < nb ? a / sL[c][c] : 0.0;
+                }
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                {
+                  if (c < nb && r - (j0 + c) <= hbw)
+                    A(r, j0 + c) = xr[c];
+                  sP[tid][c] = xr[c];
+                }
+            }
+          __syncthreads();
+          // (c) trailing update of the window below / right of the block: A[s][t] -= sum_c P[s][c] P[t][c], t <= s
+          // s fastest: consecutive threads touch consecutive entries of a band column; eight entries per thread in
+          // flight (the old values of a batch are requested before any of it is stored).  (4 x 4 register tiles would
+          // quarter the LDS reads but need 128+ VGPRs at 1024 threads per workgroup: measured 2.5-4x slower, spilled.)
+          for (int p0 = tid; p0 < m * m; p0 += 1024 * 8)
+            {
+              double  upd[8];
+              double *ptr[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                {
+                  const int p = p0 + u * 1024, t = p / m, s = p - t * m;
+                  ptr[u]      = (p < m * m && t <= s) ? &A(r0 + s, r0 + t) : nullptr;
+                  double acc  = 0.0;
+                  if (ptr[u])
+                    {
+#pragma unroll
+                      for (int c = 0; c < NB; ++c)
+                        acc += sP[s][c] * sP[t][c];
+                      acc = *ptr[u] - acc;
+                    }
+                  upd[u] = acc;
+                }
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (ptr[u])
+                  *ptr[u] = upd[u];
+            }
+          __syncthreads();
+        }
+    if (!do_solve)
+      return;
+    // ---- right-hand side into band order
+    for (int i = tid; i < n; i += 1024)
+      {
+        const int node = i / D, c = i - node * D;
+        work[bperm[node] * D + c] = b[i];
+      }
+    __syncthreads();
+    // ---- forward substitution L y = b, block columns of NB
+    for (int j0 = 0; j0 < n; j0 += NB)
+      {
+        const int nb = min(NB, n - j0);
+        if (tid < NB * NB) // the diagonal block of L in LDS: the serial part below runs on LDS latency, not on L2 latency
+          {
+            const int r = tid / NB, c = tid % NB;
+            sL[r][c]    = (r < nb && c <= r && r - c <= hbw) ? A(j0 + r, j0 + c) : 0.0; // outside the band: zero
+          }
+        __syncthreads();
+        if (tid < 64) // lane r = row r of the block: column sweeps, the finished y_c broadcast from lane c
+          {
+            double w = tid < nb ? work[j0 + tid] : 0.0;
+            for (int c = 0; c < nb; ++c)
+              {
+                const double yc = __shfl(w, c, 64) / sL[c][c];
+                if (tid == c)
+                  w = yc;
+                else if (tid > c && tid < nb)
+                  w -= sL[tid][c] * yc;
+              }
+            if (tid < nb)
+              {
+                sy[tid]        = w;
+                work[j0 + tid] = w;
+              }
+          }
+        __syncthreads();
+        const int r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        if (tid < m)
+          {
+            const int r = r0 + tid;
+            double    v = work[r];
+            for (int c = 0; c < nb; ++c)
+              if (r - (j0 + c) <= hbw)
+                v -= A(r, j0 + c) * sy[c];
+            work[r] = v;
+          }
+        __syncthreads();
+      }
+    // ---- backward substitution L^T x = y
+    for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB)
+      {
+        const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        // contributions of the rows below the block: s_c = sum_r L[r][c] x[r]; 64 threads per column, then a wave sum
+        {
+          const int c = tid >> 6, l = tid & 63;
+          double    s = 0.0;
+          if (c < nb)
+            for (int t = l; t < m; t += 64)
+              if (r0 + t - (j0 + c) <= hbw)
+                s += A(r0 + t, j0 + c) * work[r0 + t];
+          s = wave_sum(s);
+          if (l == 0 && c < NB)
+            sy[c] = s;
+          if (tid < NB * NB)
+            {
+              const int r = tid / NB, cc = tid % NB;
+              sL[r][cc]   = (r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
+            }
+        }
+        __syncthreads();
+        if (tid < 64) // lane c = column c of the block, swept from the last row upwards
+          {
+            double w = tid < nb ? work[j0 + tid] - sy[tid] : 0.0;
+            for (int q = nb - 1; q >= 0; --q)
+              {
+                const double xq = __shfl(w, q, 64) / sL[q][q];
+                if (tid == q)
+                  w = xq;
+                else if (tid < q)
+                  w -= sL[q][tid] * xq;
+              }
+            if (tid < nb)
+              work[j0 + tid] = w;
+          }
+        __syncthreads();
+      }
+    for (int i = tid; i < n; i += 1024)
+      {
+        const int node = i / D, c = i - node * D;
+        x[i]           = work[bperm[node] * D + c];
+      }
+  }
+
   // ------------------------------------------------------------------ small vector kernels
   // dinv = 1 / diag(K); constraints.distribute afterwards keeps constrained entries of x at 0
   template <int D>
@@ -3353,6 +3602,27 @@ namespace mi
       hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, q, cell_begin);
   }
 
+  void launch_band_extract(int dim, const SellParams &p, const int32_t *bperm, double *band, int hbw, hipStream_t s)
+  {
+    const int grid = (p.nslices + 3) / 4;
+    if (dim == 3)
+      hipLaunchKernelGGL((band_extract<3>), dim3(grid), dim3(256), 0, s, p, bperm, band, hbw);
+    else
+      hipLaunchKernelGGL((band_extract<2>), dim3(grid), dim3(256), 0, s, p, bperm, band, hbw);
+  }
+  int launch_band_cholesky_solve(int dim, double *band, int n, int hbw, const int32_t *bperm, int nnodes, const double *b,
+                                 double *x, double *work, int32_t *flag, bool factor, bool solve, hipStream_t s)
+  {
+    if (hbw >= BAND_MAXH)
+      return -1;
+    if (dim == 3)
+      hipLaunchKernelGGL((band_cholesky_solve<3>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
+                         int(factor), int(solve));
+    else
+      hipLaunchKernelGGL((band_cholesky_solve<2>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
+                         int(factor), int(solve));
+    return 0;
+  }
   int launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s)
   {
     if (n > DENSE_MAX)

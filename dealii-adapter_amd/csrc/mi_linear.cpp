@@ -18,6 +18,7 @@ namespace mi_detail
     double  theta = 0.5;
     double *d_K = nullptr, *d_M = nullptr, *d_A = nullptr, *d_dinvA = nullptr, *d_body = nullptr;
     bool    body_force_enabled = false;
+    bool    factored = false; // the banded Cholesky factor of the (constant) system matrix is in the context's band
     // consistent-load operator on the interface nodes (scalar CSR over interface slots), :458-521
     std::vector<int32_t> B_rowptr, B_col;
     std::vector<double>  B_val;
@@ -433,7 +434,21 @@ int mi_linear_step(mi_ctx *c, int data_consistent, double abs_tol, int64_t max_i
       m->active_sell_vals = m->linear->d_A;
       m->active_dinv      = m->linear->d_dinvA;
     }
-  if (!rc)
+  bool direct = false;
+  if (!rc && c0->solver_direct && T.size == 1 && direct_prepare(c0) == MI_OK)
+    {
+      // "Solver type = Direct" (:553-559): the system matrix is constant, so it is factorised ONCE and a step is one
+      // forward and one backward substitution
+      direct          = true;
+      LinearModel &Lm = *c0->linear;
+      rc = direct_factor_solve(c0, Lm.d_A, c0->vec(MI_L_SYSTEM_RHS), c0->vec(MI_L_VELOCITY), !Lm.factored, true);
+      Lm.factored = Lm.factored || rc == MI_OK;
+      if (its)
+        *its = 1;
+      if (res)
+        *res = 0.0;
+    }
+  if (!rc && !direct)
     rc = cg_run(c0, MI_L_VELOCITY, MI_L_SYSTEM_RHS, -abs_tol, max_it, its, res);
   for (mi_ctx *m : T.members)
     {

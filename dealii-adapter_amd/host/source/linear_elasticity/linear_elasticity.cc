@@ -155,7 +155,14 @@ namespace Linear_Elasticity
         double    lin_res = 0.0;
         const bool direct = parameters.type_lin == "Direct";
         std::cout << (direct ? "\t Direct solver: " : "\t CG solver: ") << std::endl;
-        // "Direct" (UMFPACK, :553-559) is served by the device PCG at a tolerance four orders tighter
+        // "Direct" (UMFPACK, :553-559): the constant system matrix is factorised once on the device (banded Cholesky,
+        // tuning "solver_type" 1) and a step is two substitutions; where the system is too large for that, the device
+        // PCG at a tolerance four orders tighter serves it (the library falls back by itself)
+        if (direct && !solver_type_set)
+          {
+            device->check(mi_set_tuning(device->ctx(), "solver_type", 1), "mi_set_tuning");
+            solver_type_set = true;
+          }
         device->check(mi_linear_step(device->ctx(), parameters.data_consistent ? 1 : 0, direct ? 1e-14 : 1e-10,
                                      static_cast<int64_t>(double(mi_n_dofs(device->ctx())) *
                                                           std::max(1.0, parameters.max_iterations_lin)),

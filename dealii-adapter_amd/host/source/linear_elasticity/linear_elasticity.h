@@ -47,6 +47,7 @@ namespace Linear_Elasticity
 
     mi_mesh_desc                mesh_desc{};
     std::unique_ptr<mi::Device> device;
+    bool                        solver_type_set = false; // "Solver type = Direct" passed on to the library
     mi::Vector                  old_velocity, velocity, old_displacement, displacement, old_stress, stress;
     std::vector<mi::Vector *>   state_variables;
 

@@ -227,8 +227,8 @@ namespace Nonlinear_Elasticity
 
     print_conv_header();
 
-    // "Direct" (UMFPACK, :1192-1200) has no device counterpart: it is served by the same PCG run to a tolerance
-    // at which the answer is solver independent
+    // "Direct" (UMFPACK, :1192-1200): banded Cholesky on the device (mi_direct_solve) for the sizes of the reference's
+    // geometries; beyond them (MI_EINVAL) the PCG runs to a tolerance at which the answer is solver independent
     const bool   direct  = parameters.type_lin == "Direct";
     const double tol_lin = direct ? 1e-12 : parameters.tol_lin;
     const double it_mult = direct ? std::max(10.0, parameters.max_iterations_lin) : parameters.max_iterations_lin;
@@ -279,7 +279,16 @@ namespace Nonlinear_Elasticity
         std::cout << " SLV " << std::flush;
         int       lin_it  = 0;
         double    lin_res = 0.0;
-        const int rc = mi_cg_solve(ctx, tol_lin, static_cast<int64_t>(double(mi_n_dofs(ctx)) * it_mult), &lin_it, &lin_res);
+        int rc = MI_EINVAL;
+        if (direct && use_device_direct)
+          {
+            lin_it = 1; // :1198-1199
+            rc     = mi_direct_solve(ctx, &lin_res);
+            if (rc == MI_EINVAL)
+              use_device_direct = false; // too large for the device factorisation: iterate from now on
+          }
+        if (rc == MI_EINVAL)
+          rc = mi_cg_solve(ctx, tol_lin, static_cast<int64_t>(double(mi_n_dofs(ctx)) * it_mult), &lin_it, &lin_res);
         timer.leave_subsection();
         device->check(rc, "mi_cg_solve"); // SolverControl::NoConvergence
         ++last_newton_iterations;

@@ -75,6 +75,7 @@ namespace Nonlinear_Elasticity
 
     // machine-readable companion of the Newton table: one JSON line per solved step in <Output folder>/steps.jsonl
     unsigned int last_newton_iterations = 0, last_lin_iterations = 0;
+    bool         use_device_direct = true; // "Solver type = Direct": mi_direct_solve until it reports "too large"
     void         log_step_json() const;
   };
 } // namespace Nonlinear_Elasticity

@@ -152,6 +152,14 @@ int mi_assemble(mi_ctx *ctx, double *res_norm);     /* :446 -> :1044-1087 incl. 
 int mi_assemble_residual(mi_ctx *ctx, double *res_norm);
 int mi_cg_solve(mi_ctx *ctx, double rel_tol, int64_t max_it, int *its, double *res);
                                                     /* :472 -> :1153-1191 (Jacobi-PCG, warm start) + :1208 */
+/* "Solver type = Direct" (SparseDirectUMFPACK re-factorised in every Newton iteration, :1192-1200; the reference's shipped
+ * default, parameters.prm:43): banded Cholesky factorisation of the current tangent + substitution on the device (one
+ * workgroup; nodes renumbered with the shortest lattice direction fastest), then :1208.  *res = 0 as in :1199.  Meant for
+ * the sizes of the reference's own geometries: MI_EINVAL ("too large ...") beyond ~3e8 flops of factorisation or on a
+ * decomposed mesh -- callers then use mi_cg_solve at a tolerance of 1e-12.  MI_ENOCONV_LIN: non-positive pivot.
+ * mi_set_tuning("solver_type", 1) makes mi_newmark_step and mi_linear_step solve this way (with that fallback); the
+ * linear model factorises its constant matrix once (linear_elasticity.cc:553-559). */
+int mi_direct_solve(mi_ctx *ctx, double *res);
 int mi_apply_newton_update(mi_ctx *ctx, double *upd_norm); /* get_error_update :564-576; delta += update :487; then
                                                        the consumed update is cleared, so that the next solve of the
                                                        step starts from zero -- unless mi_set_tuning("cg_warm_start", 1)
@@ -252,7 +260,7 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * matrix), 1: with stored symmetric element tangents, 0: with the assembled matrix; "spmv_variant" 4 +
  * "element_tangents" 2 | 1: mi_spmv through that form whatever the mesh size (tests); "cg_operator" 0 (default) | 1: the
  * CG's own product on the assembled matrix | in the smoother's unassembled form (A/B); "asm_variant" 0 (default): 3D Q2
- * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
+ * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update; "solver_type" 0 (default) | 1: see mi_direct_solve; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
  * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 /* read back: "smoother_operator_active" (2 / 1: the smoother's fine-level products are matrix-free / use the stored

@@ -558,3 +558,78 @@ def test_inverted_element_is_reported(dim, p, reps):
         G.assemble()
     G.set(M.V_U, np.zeros(G.n))  # the context survives
     assert np.isfinite(G.assemble())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# "Solver type = Direct": banded Cholesky on the device (mi_direct_solve) against the oracle's direct solve
+DIRECT_CASES = [("FSI3", 2, 1), ("FSI3", 2, 2), ("FSI3", 2, 3), ("PF", 2, 2), ("PF", 3, 2), ("FSI3", 3, 1)]
+
+
+def _scenario_pair(scenario, dim, p):
+    d = O.scenario_desc(scenario, dim, degree=p)
+    P = O.Problem(d)
+    G = M.Context(dim=dim, degree=p, reps=tuple(d.reps)[:dim], lo=tuple(d.lo)[:dim], hi=tuple(d.hi)[:dim],
+                  face_role=list(d.face_role))
+    return P, G
+
+
+@pytest.mark.parametrize("scenario,dim,p", DIRECT_CASES)
+def test_direct_solver_matches_the_oracle_direct_solve(scenario, dim, p):
+    """the reference's shipped default (parameters.prm:43, nonlinear_elasticity.cc:1192-1200) on its own geometries: one
+    factorisation + substitution on the device = the oracle's banded LU = scipy's sparse LU of the exported matrix"""
+    import scipy.sparse.linalg as spla
+    P, G = _scenario_pair(scenario, dim, p)
+    _randomise_state(P, G, seed=5 + p, amp_u=0.002)
+    P.update_acceleration()
+    P.assemble()
+    G.update_acceleration()
+    G.assemble()
+    P.vec(O.V_NEWTON)[:] = 0.0
+    rc_o, _, _ = P.solve_linear(O.SOLVER_DIRECT)
+    assert rc_o == 0
+    assert G.direct_solve() == 0
+    x = G.get(M.V_NEWTON)
+    assert _relmax(x, P.vec(O.V_NEWTON)) < 1e-10
+    K, b = G.csr(), G.get(M.V_RHS)
+    assert _relmax(x, spla.spsolve(K.tocsc(), b)) < 1e-10
+    assert np.all(x[G.constrained] == 0.0)  # constraints.distribute (:1208)
+    x2 = None
+    for _ in range(2):  # bit-stable: the same factorisation twice
+        assert G.direct_solve() == 0
+        x2 = G.get(M.V_NEWTON) if x2 is None else x2
+        assert np.array_equal(G.get(M.V_NEWTON), x2)
+
+
+@pytest.mark.parametrize("scenario,dim,p", [("FSI3", 2, 3), ("PF", 3, 2)])
+def test_newmark_steps_with_the_direct_solver(scenario, dim, p):
+    """whole steps with solver_type = 1: Newton table and interface displacement as the oracle's direct steps"""
+    P, G = _scenario_pair(scenario, dim, p)
+    G.set_tuning("solver_type", 1)
+    ids = P.interface_nodes
+    for step in range(3):
+        t = np.zeros(dim)
+        t[1] = -50.0 * (step + 1)
+        P.set_interface_traction(t)
+        G.set_interface_traction(t)
+        rc_o, io = P.newmark_step(O.SOLVER_DIRECT)
+        rc, ig = G.newmark_step()
+        assert rc == 0 and rc_o == 0 and ig.converged == 1
+        assert (ig.newton_iterations, ig.assemblies) == (io.newton_iterations, io.assemblies)
+        assert ig.lin_its_total == ig.newton_iterations  # one "iteration" per direct solve (:1198)
+        u_o = P.vec(O.V_U).reshape(-1, dim)[ids]
+        assert _relmax(G.get_interface_displacement(), u_o) < 1e-10
+
+
+def test_direct_solver_refuses_what_it_cannot_factorise():
+    """beyond ~3e8 flops of factorisation the entry point says so and the step falls back to the PCG at 1e-12"""
+    P, G = _pair(3, 2, (12, 12, 12))
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    G.update_acceleration()
+    G.assemble()
+    assert G.direct_solve() == M.MI_EINVAL and b"too large" in M.lib().mi_last_error(G.h)
+    G.set_tuning("solver_type", 1)
+    P.set_interface_traction((0.0, -2e3, 0.0))
+    rc, info = G.newmark_step()
+    rc_o, io = P.newmark_step(O.SOLVER_CG_JACOBI, tol_lin=1e-12, max_it_mult=2.0)
+    assert rc == 0 and rc_o == 0 and info.converged == 1 and info.lin_its_total > info.newton_iterations
+    assert _relmax(G.get(M.V_U), P.vec(O.V_U)) < TOL_SOL
