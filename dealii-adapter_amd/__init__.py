@@ -38,7 +38,7 @@ class NewmarkDesc(C.Structure):
 
 
 class CommDesc(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("nccl_unique_id", C.c_void_p)]
+    _fields_ = [("rank", C.c_int32), ("size", C.c_int32), ("nccl_unique_id", C.c_void_p), ("cut_axis", C.c_int32)]
 
 
 class PartitionInfo(C.Structure):
@@ -206,9 +206,9 @@ class Context:
 
     def __init__(self, dim=3, degree=2, reps=(4, 4, 4), lo=(0, 0, 0), hi=(1, 1, 1), face_role=None, mu=0.5e6, nu=0.4,
                  rho=1000.0, body_force=(0, 0, 0), beta=0.25, gamma=0.5, delta_t=0.005, device=0, perturb=None,
-                 slabs=1, rank=None, world=1, unique_id=None):
-        """slabs > 1: that many z-slabs inside this process (test mode); rank/world/unique_id: one slab per process
-        over RCCL"""
+                 slabs=1, rank=None, world=1, unique_id=None, cut_axis=0):
+        """slabs > 1: that many slabs inside this process (test mode); rank/world/unique_id: one slab per process
+        over RCCL; cut_axis: 0 automatic (direction with most cell layers, ties: the last), 1 / 2 / 3 = x / y / z"""
         L = lib()
         md, mat, nm = MeshDesc(), MaterialDesc(), NewmarkDesc()
         md.dim, md.degree = dim, degree
@@ -230,10 +230,10 @@ class Context:
         self.h = C.c_void_p()
         comm = None
         if slabs > 1:
-            comm = CommDesc(-1, slabs, None)
+            comm = CommDesc(-1, slabs, None, cut_axis)
         elif world > 1 or unique_id is not None:
             self._uid = C.create_string_buffer(unique_id, 128)
-            comm = CommDesc(rank or 0, world, C.cast(self._uid, C.c_void_p))
+            comm = CommDesc(rank or 0, world, C.cast(self._uid, C.c_void_p), cut_axis)
         rc = L.mi_ctx_create(C.byref(md), C.byref(mat), C.byref(nm), device, C.byref(comm) if comm else None,
                              C.byref(self.h))
         if rc != MI_OK:

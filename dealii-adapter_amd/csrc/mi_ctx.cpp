@@ -148,6 +148,9 @@ namespace mi_detail
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
     p.inverted = c->d_sc + SC_INVERTED;
+    p.axmap    = 0;
+    for (int d = 0; d < 3; ++d)
+      p.axmap |= (c->team->amap.ext_axis[d] << (2 * d)) | ((c->team->amap.dir[d] < 0 ? 1 : 0) << (6 + d));
     return p;
   }
 
@@ -976,10 +979,11 @@ namespace mi_detail
         const mi::SlabPartition &s = c->slab;
         const double *perturb = md->vertex_perturbation ? md->vertex_perturbation + s.vertex_offset * md->dim : nullptr;
         if (T.size == 1)
-          c->mesh.build(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, perturb);
+          c->mesh.build(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, perturb, 0, 0, 0, -1,
+                        T.amap.identity ? nullptr : T.amap.ext_axis); // replicated multigrid levels of a rotated lattice
         else
           c->mesh.build(md->dim, md->degree, s.local_reps, md->lo, md->hi, s.local_face_role, perturb, s.z0,
-                        md->reps[md->dim - 1], s.own_begin, s.own_end);
+                        md->reps[md->dim - 1], s.own_begin, s.own_end, T.amap.identity ? nullptr : T.amap.ext_axis);
         c->tab.build(md->degree, md->degree + 2); // qf_cell(p+2), qf_face(p+2): nonlinear_elasticity.cc:74-75
       }
     catch (const std::exception &e)
@@ -1033,7 +1037,7 @@ namespace mi_detail
       std::vector<int32_t> own_nodes, own_slots;
       for (int32_t ln : m.iface_nodes)
         {
-          const int64_t g  = ln + c->slab.node_offset;
+          const int64_t g  = T.ext_node(ln + c->slab.node_offset); // the list is in the reference's node order
           const auto    it = std::lower_bound(T.iface_global.begin(), T.iface_global.end(), g);
           if (it == T.iface_global.end() || *it != g)
             return fail(c, MI_EINVAL, "internal error: interface node %lld missing from the global list", (long long)g);
@@ -1186,6 +1190,64 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   T->device   = device_id;
   T->dim      = md->dim;
   T->md       = *md;
+  const mi_mesh_desc *md_ext = md; // the box as the caller describes it (reference order: x fastest)
+  mi_mesh_desc        md_int = *md;
+  if (nranks > 1)
+    {
+      // which direction the slabs cut; any but the last: the lattice is laid over the box rotated (mi::AxisMap)
+      const int want = comm ? comm->cut_axis : 0;
+      if (want < 0 || want > md->dim)
+        {
+          g_create_error = "cut_axis must be 0 (automatic) or 1..dim";
+          delete T;
+          return MI_EINVAL;
+        }
+      try
+        {
+          T->amap = mi::make_axis_map(md->dim, md->reps, want - 1);
+        }
+      catch (const std::exception &e)
+        {
+          g_create_error = e.what();
+          delete T;
+          return MI_EINVAL;
+        }
+      if (!T->amap.identity)
+        {
+          mi::rotate_box(T->amap, md->dim, md->reps, md->lo, md->hi, md->face_role, md_int.reps, md_int.lo, md_int.hi,
+                         md_int.face_role);
+          int     nn_ext[3] = {1, 1, 1}, nv_ext[3] = {1, 1, 1};
+          int64_t nnodes = 1, nverts = 1;
+          for (int d = 0; d < md->dim; ++d)
+            {
+              nn_ext[d] = md->degree * md->reps[d] + 1;
+              nv_ext[d] = md->reps[d] + 1;
+              nnodes *= nn_ext[d];
+              nverts *= nv_ext[d];
+            }
+          T->e2i.resize(size_t(nnodes));
+          T->i2e.resize(size_t(nnodes));
+          for (int64_t g = 0; g < nnodes; ++g)
+            {
+              const int64_t gi     = mi::ext_to_int_point(T->amap, md->dim, nn_ext, g);
+              T->e2i[size_t(g)]    = gi;
+              T->i2e[size_t(gi)]   = g;
+            }
+          if (md->vertex_perturbation) // tests: the offsets in internal vertex order (components stay physical)
+            {
+              T->perturb_int.resize(size_t(nverts) * md->dim);
+              for (int64_t v = 0; v < nverts; ++v)
+                {
+                  const int64_t vi = mi::ext_to_int_point(T->amap, md->dim, nv_ext, v);
+                  for (int k = 0; k < md->dim; ++k)
+                    T->perturb_int[size_t(vi) * md->dim + k] = md->vertex_perturbation[size_t(v) * md->dim + k];
+                }
+              md_int.vertex_perturbation = T->perturb_int.data();
+            }
+          md    = &md_int;
+          T->md = md_int;
+        }
+    }
   T->md.vertex_perturbation = nullptr; // coarse levels use the unperturbed box
   auto bail   = [&](int code, const std::string &msg) {
     g_create_error = msg;
@@ -1201,7 +1263,8 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
       for (int d = 0; d < md->dim; ++d)
         if (md->reps[d] < 1)
           throw std::invalid_argument("repetitions must be >= 1");
-      T->iface_global = mi::global_interface_nodes(md->dim, md->degree, md->reps, md->face_role);
+      // the coupling interface in the reference's order: ascending node id of the box as the caller describes it
+      T->iface_global = mi::global_interface_nodes(md_ext->dim, md_ext->degree, md_ext->reps, md_ext->face_role);
       const mi::SlabPartition s0 =
         mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, 0, nranks);
       T->nnodes_global = s0.nnodes_global;
@@ -1373,7 +1436,7 @@ static int gather_global_host(mi_ctx *c, const std::function<double(mi_ctx *, in
   for (mi_ctx *m : T.members)
     for (int64_t ln = m->slab.own_begin; ln < m->slab.own_end; ++ln)
       for (int k = 0; k < m->dim; ++k)
-        out[(ln + m->slab.node_offset) * m->dim + k] = val(m, ln, k);
+        out[T.ext_node(ln + m->slab.node_offset) * m->dim + k] = val(m, ln, k);
   if (T.nccl)
     {
       int rc = ensure_gbuf(T);
@@ -1819,6 +1882,36 @@ int mi_snapshot_load(mi_ctx *c, const mi_snapshot *s, int which)
   return MI_OK;
 }
 
+// global dof vectors cross the C-ABI in the reference's node order (x fastest); inside a team whose lattice lies rotated
+// over the box (decomposition along a direction other than the last, mi::AxisMap) they are permuted on the way
+static int gbuf_to_host(mi_ctx *c, double *host)
+{
+  Team &T = *c->team;
+  if (T.e2i.empty())
+    {
+      HIPCHK(c, hipMemcpy(host, T.d_gbuf, size_t(T.n_global) * sizeof(double), hipMemcpyDeviceToHost));
+      return MI_OK;
+    }
+  std::vector<double> tmp(size_t(T.n_global));
+  HIPCHK(c, hipMemcpy(tmp.data(), T.d_gbuf, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  const int D = T.dim;
+  for (int64_t g = 0; g < T.nnodes_global; ++g)
+    for (int k = 0; k < D; ++k)
+      host[g * D + k] = tmp[size_t(T.e2i[size_t(g)]) * D + k];
+  return MI_OK;
+}
+static const double *to_internal_order(const Team &T, const double *host, std::vector<double> &buf)
+{
+  if (T.e2i.empty())
+    return host;
+  const int D = T.dim;
+  buf.resize(size_t(T.n_global));
+  for (int64_t g = 0; g < T.nnodes_global; ++g)
+    for (int k = 0; k < D; ++k)
+      buf[size_t(T.e2i[size_t(g)]) * D + k] = host[g * D + k];
+  return buf.data();
+}
+
 int mi_vec_get(mi_ctx *c, int which, double *host, int64_t n)
 {
   Team &T = *c->team;
@@ -1841,8 +1934,7 @@ int mi_vec_get(mi_ctx *c, int which, double *host, int64_t n)
   if ((rc = team_allreduce_buffer(T, T.d_gbuf, size_t(n))))
     return rc;
   HIPCHK(c, hipStreamSynchronize(T.stream));
-  HIPCHK(c, hipMemcpy(host, T.d_gbuf, size_t(n) * sizeof(double), hipMemcpyDeviceToHost));
-  return MI_OK;
+  return gbuf_to_host(c, host);
 }
 int mi_vec_set(mi_ctx *c, int which, const double *host, int64_t n)
 {
@@ -1853,6 +1945,8 @@ int mi_vec_set(mi_ctx *c, int which, const double *host, int64_t n)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (which == MI_V_NEWTON_UPDATE)
     T.members[0]->newton_update_is_zero = false;
+  std::vector<double> rot;
+  host = to_internal_order(T, host, rot);
   for (mi_ctx *m : T.members) // every slab takes its local range (ghost planes included) from the global array
     HIPCHK(m, hipMemcpy(m->vec(which), host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
                         hipMemcpyHostToDevice));
@@ -1892,6 +1986,8 @@ int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
   Team &T = *c->team;
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<double> rot;
+  x_host = to_internal_order(T, x_host, rot);
   for (mi_ctx *m : T.members)
     HIPCHK(m, hipMemcpy(m->work(W_P), x_host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
                         hipMemcpyHostToDevice));
@@ -1914,8 +2010,7 @@ int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
   if ((rc = team_allreduce_buffer(T, T.d_gbuf, size_t(T.n_global))))
     return rc;
   HIPCHK(c, hipStreamSynchronize(T.stream));
-  HIPCHK(c, hipMemcpy(y_host, T.d_gbuf, size_t(T.n_global) * sizeof(double), hipMemcpyDeviceToHost));
-  return MI_OK;
+  return gbuf_to_host(c, y_host);
 }
 
 int mi_set_tuning(mi_ctx *c, const char *key, int value)

@@ -68,7 +68,14 @@ namespace mi_detail
     double               *d_gbuf  = nullptr; // global-vector scratch (n_global doubles), on demand
     double               *d_ifbuf = nullptr; // global interface scratch (n_if * dim doubles)
     double              **d_sc_ptrs = nullptr; // emulated all-reduce: the members' scalar blocks
-    mi_mesh_desc          md{};                // the undecomposed mesh (coarse multigrid levels are global)
+    mi_mesh_desc          md{};                // the undecomposed mesh AS THE LATTICE SEES IT (coarse multigrid levels are global)
+    // decomposition along a direction other than the last: the lattice lies rotated over the box (mi::AxisMap).  e2i /
+    // i2e: node of the reference's order (x fastest; what the C-ABI speaks) <-> node of the internal lattice; empty when
+    // the two agree.  coord_of_axis goes to HostMesh::build of every context of the team (levels included).
+    mi::AxisMap           amap;
+    std::vector<int64_t>  e2i, i2e;
+    std::vector<double>   perturb_int;         // vertex perturbation in internal vertex order (tests)
+    int64_t ext_node(int64_t internal) const { return i2e.empty() ? internal : i2e[size_t(internal)]; }
   };
 } // namespace mi_detail
 

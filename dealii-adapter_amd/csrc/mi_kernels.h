@@ -26,6 +26,9 @@ namespace mi
     int32_t         variant; // kernel variant for A/B timing
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
     double         *qrec;   // optional (3D Q2): the quadrature-point records the tangent is made of, [cell][MF_NREC][64] (see mf_spmv)
+    int32_t         axmap;    // how the lattice lies over the box (mi::AxisMap): bits 2d..2d+1 the physical coordinate lattice
+                              // direction d runs along, bit 6+d set if backwards; 0x24 = aligned.  Only the Neumann term needs it
+                              // (the reference pairs face and cell quadrature points by their index in PHYSICAL order)
     double         *inverted; // set to 1.0 by any quadrature point with det F <= 0 (the reference asserts det F > 0 there,
                               // nonlinear_elasticity.cc:935); sits next to the residual norm in the context's scalar block
     unsigned long long *stamps; // diagnostic (null in production): [cells of the launch][8] shader-clock stamps of one

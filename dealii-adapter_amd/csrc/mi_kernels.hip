@@ -1322,26 +1322,49 @@ namespace mi
       }
     __syncthreads();
 
+    // The lattice may lie rotated over the box (decomposition along a direction other than the last, mi::AxisMap): lattice
+    // direction d of the cell runs along physical coordinate ext[d], backwards if rev[d].  The ORDER of the quadrature
+    // points matters here -- the reference pairs face point fq with CELL point fq (:825-827), both counted in physical
+    // directions, x fastest -- so points are counted physically and translated to the cell's own directions.
+    int ext[3] = {0, 1, 2}, rev[3] = {0, 0, 0}, loc[3] = {0, 1, 2};
+    for (int d = 0; d < DIM; ++d)
+      {
+        ext[d]      = (prm.axmap >> (2 * d)) & 3;
+        rev[d]      = (prm.axmap >> (6 + d)) & 1;
+        loc[ext[d]] = d;
+      }
+    auto q1d = [&](int d, int q) { return rev[d] ? NQ1 - 1 - q : q; }; // 1D point q of a physical direction, on lattice direction d
     for (int f = 0; f < 2 * DIM; ++f)
       {
     if (!((fmask >> f) & 1))
       continue;
     const int nd = f >> 1, side = f & 1;
-    // face-local axes [DEAL.II, recalled]: x-normal (y,z); y-normal (z,x) in 3D, (x) in 2D; z-normal (x,y)
-    int ax0, ax1;
+    // face-local axes [DEAL.II, recalled], in PHYSICAL directions: x-normal (y,z); y-normal (z,x) in 3D, (x) in 2D;
+    // z-normal (x,y); ax0 / ax1 are the lattice directions they correspond to
+    const int nde = ext[nd];
+    int       ax0, ax1;
     if (DIM == 2)
       {
-        ax0 = nd == 0 ? 1 : 0;
+        ax0 = loc[nde == 0 ? 1 : 0];
         ax1 = 2;
       }
     else
       {
-        ax0 = nd == 0 ? 1 : (nd == 1 ? 2 : 0);
-        ax1 = nd == 0 ? 2 : (nd == 1 ? 0 : 1);
+        ax0 = loc[nde == 0 ? 1 : (nde == 1 ? 2 : 0)];
+        ax1 = loc[nde == 0 ? 2 : (nde == 1 ? 0 : 1)];
       }
     for (int fq = tid; fq < NQF; fq += 64)
       {
-        const int f1 = fq % NQ1, f2 = fq / NQ1;
+        const int f1 = q1d(ax0, fq % NQ1), f2 = (DIM == 3) ? q1d(ax1, fq / NQ1) : 0; // face point, on the lattice directions
+        // the cell point with the same PHYSICAL index, as this cell counts it
+        int cq;
+        {
+          const int qe[3] = {fq % NQ1, (fq / NQ1) % NQ1, (DIM == 3) ? fq / (NQ1 * NQ1) : 0};
+          int       ql[3] = {0, 0, 0};
+          for (int d = 0; d < DIM; ++d)
+            ql[d] = q1d(d, qe[ext[d]]);
+          cq = ql[0] + NQ1 * (ql[1] + NQ1 * ql[2]);
+        }
         // (1) F at the CELL quadrature point with index fq  -- the reference's quirk (:825-827 vs :902-903)
         double gxi[9];
 #pragma unroll
@@ -1350,7 +1373,7 @@ namespace mi
         for (int a = 0; a < NPC; ++a)
           {
             double N, dN[3];
-            shape_at_qp<DIM, P>(s_N1, s_dN1, fq, a, N, dN);
+            shape_at_qp<DIM, P>(s_N1, s_dN1, cq, a, N, dN);
 #pragma unroll
             for (int i = 0; i < DIM; ++i)
 #pragma unroll
@@ -1359,7 +1382,7 @@ namespace mi
           }
         double xi[3] = {0, 0, 0};
         {
-          int qi[3] = {fq % NQ1, (fq / NQ1) % NQ1, (DIM == 3) ? fq / (NQ1 * NQ1) : 0};
+          int qi[3] = {cq % NQ1, (cq / NQ1) % NQ1, (DIM == 3) ? cq / (NQ1 * NQ1) : 0};
 #pragma unroll
           for (int d = 0; d < DIM; ++d)
             xi[d] = s_qx[qi[d]];
@@ -1445,7 +1468,7 @@ namespace mi
         double s = 0.0;
         for (int fq = 0; fq < NQF; ++fq)
           {
-            const int f1 = fq % NQ1, f2 = fq / NQ1;
+            const int f1 = q1d(ax0, fq % NQ1), f2 = (DIM == 3) ? q1d(ax1, fq / NQ1) : 0;
             double    N  = s_N1[f1 * NP1 + ai[ax0]];
             if (DIM == 3)
               N *= s_N1[f2 * NP1 + ai[ax1]];

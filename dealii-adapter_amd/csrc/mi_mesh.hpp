@@ -163,6 +163,86 @@ namespace mi
     }
   };
 
+  // ------------------------------------------------------------------ which direction a decomposition cuts (host only)
+  // Slabs are cut along the LAST lattice direction (the slowest in the node numbering: a slab then owns a contiguous
+  // range of node planes).  To cut a box along another direction -- the reference's flap is 18 x 3 x 1 cells
+  // (nonlinear_elasticity.cc:189-205): only x can be cut at all -- the lattice is laid over the box ROTATED: internal
+  // lattice direction d runs along physical coordinate ext_axis[d], forwards or backwards (dir[d]), with the wanted
+  // direction last.  3D: a cyclic shift of (x, y, z); 2D cut along x: (y, -x).  Both keep the cells right handed.  Inside
+  // the library nothing but the vertex coordinates knows about it (the element kernels work on general Q1 cells);
+  // at the C-ABI the global arrays are permuted back to the reference's node order (x fastest).
+  struct AxisMap
+  {
+    int  ext_axis[3] = {0, 1, 2};
+    int  dir[3]      = {1, 1, 1};
+    bool identity    = true;
+  };
+  // cut = 0, 1, 2: the physical direction to cut; -1: the one with most cell layers (ties: the last)
+  inline AxisMap make_axis_map(int dim, const int *reps, int cut)
+  {
+    AxisMap m;
+    if (cut < 0)
+      {
+        cut = dim - 1;
+        for (int d = dim - 2; d >= 0; --d)
+          if (reps[d] > reps[cut])
+            cut = d;
+      }
+    if (cut >= dim)
+      throw std::invalid_argument("cut direction outside the dimension of the mesh");
+    if (cut == dim - 1)
+      return m;
+    m.identity = false;
+    if (dim == 3)
+      for (int d = 0; d < 3; ++d)
+        m.ext_axis[d] = (cut + 1 + d) % 3; // (cut+1, cut+2, cut): cyclic, right handed
+    else
+      {
+        m.ext_axis[0] = 1;
+        m.ext_axis[1] = 0;
+        m.dir[1]      = -1; // (y, -x): right handed
+      }
+    return m;
+  }
+  // the box as the rotated lattice sees it
+  inline void rotate_box(const AxisMap &m, int dim, const int *reps, const double *lo, const double *hi, const int *face_role,
+                         int *reps_i, double *lo_i, double *hi_i, int *role_i)
+  {
+    for (int d = 0; d < 3; ++d)
+      {
+        reps_i[d] = 1;
+        lo_i[d] = hi_i[d] = 0.0;
+        role_i[2 * d] = role_i[2 * d + 1] = 0;
+      }
+    for (int d = 0; d < dim; ++d)
+      {
+        const int e = m.ext_axis[d];
+        reps_i[d]   = reps[e];
+        lo_i[d]     = m.dir[d] > 0 ? lo[e] : hi[e];
+        hi_i[d]     = m.dir[d] > 0 ? hi[e] : lo[e];
+        for (int side = 0; side < 2; ++side)
+          role_i[2 * d + side] = face_role[2 * e + (m.dir[d] > 0 ? side : 1 - side)];
+      }
+  }
+  // external (reference order: x fastest) lattice point -> internal lattice point, for lattices with n_ext[] points
+  inline int64_t ext_to_int_point(const AxisMap &m, int dim, const int *n_ext, int64_t id)
+  {
+    int e[3] = {0, 0, 0};
+    for (int d = 0; d < dim; ++d)
+      {
+        e[d] = int(id % n_ext[d]);
+        id /= n_ext[d];
+      }
+    int64_t out = 0, stride = 1;
+    for (int d = 0; d < dim; ++d)
+      {
+        const int a = m.ext_axis[d], idx = m.dir[d] > 0 ? e[a] : n_ext[a] - 1 - e[a];
+        out += stride * idx;
+        stride *= n_ext[a];
+      }
+    return out;
+  }
+
   // ------------------------------------------------------------------ slab decomposition (host only)
   // The last lattice direction (z in 3D, y in 2D) is the slowest in the node numbering, so a slab of cell layers
   // owns a contiguous range of node planes.  Rank r works on the box of its own layers [z0, z1) plus one ghost
@@ -357,8 +437,12 @@ namespace mi
 
     // zoff / zreps_global / own range: slab of a decomposed box (see SlabPartition): `reps_` are the LOCAL
     // repetitions, lo/hi the GLOBAL box, the last direction starts at global cell layer zoff
+    // coord_of_axis (optional): lattice direction d runs along physical coordinate coord_of_axis[d] (see AxisMap; lo / hi
+    // are given per LATTICE direction, hi < lo for a direction that runs backwards); perturb: offsets of the local
+    // vertices, physical components
     void build(int dim_, int p_, const int *reps_, const double *lo, const double *hi, const int *face_role,
-               const double *perturb, int zoff = 0, int zreps_global = 0, int64_t own_begin = 0, int64_t own_end = -1)
+               const double *perturb, int zoff = 0, int zreps_global = 0, int64_t own_begin = 0, int64_t own_end = -1,
+               const int *coord_of_axis = nullptr)
     {
       dim = dim_;
       p   = p_;
@@ -394,8 +478,9 @@ namespace mi
           for (int d = 0; d < dim; ++d)
             {
               const bool cut = (d == dim - 1) && zreps_global > 0;
-              vx[size_t(v) * dim + d] = lo[d] + (hi[d] - lo[d]) * (vi[d] + (cut ? zoff : 0)) / (cut ? zreps_global : reps[d]) +
-                                        (perturb ? perturb[size_t(v) * dim + d] : 0.0);
+              const int  c   = coord_of_axis ? coord_of_axis[d] : d;
+              vx[size_t(v) * dim + c] = lo[d] + (hi[d] - lo[d]) * (vi[d] + (cut ? zoff : 0)) / (cut ? zreps_global : reps[d]) +
+                                        (perturb ? perturb[size_t(v) * dim + c] : 0.0);
             }
         }
 

@@ -465,6 +465,8 @@ namespace mi_detail
         T->stream       = c->stream;
         T->owns_stream  = false;
         T->md           = md;
+        T->amap         = c->team->amap; // the levels' lattices lie over the box like the fine one (geometry only: their
+                                         // node ids never leave the library, so no permutation tables)
         T->iface_global = mi::global_interface_nodes(dim, p, md.reps, md.face_role);
         mi_ctx   *lc    = nullptr;
         const int rc    = create_member(*T, &md, &c->mat, &c->nm, slab_level ? c->slab.rank : 0, &lc);

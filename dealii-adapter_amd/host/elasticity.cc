@@ -44,9 +44,9 @@ int main(int argc, char **argv)
       std::cout << "--     . adapter revision " << adapter_info << std::endl;
       std::cout << "--     . device " << device_info << " (DIM=" << DIM << ")" << std::endl;
       if (mi::host_world_size() > 1)
-        std::cout << "--     . " << mi::host_world_size() << " processes, one z-slab and one GPU each (RCCL)" << std::endl;
+        std::cout << "--     . " << mi::host_world_size() << " processes, one slab and one GPU each (RCCL; cut along the direction with most cell layers)" << std::endl;
       else if (std::getenv("MI_SLABS") && std::atoi(std::getenv("MI_SLABS")) > 1)
-        std::cout << "--     . " << std::atoi(std::getenv("MI_SLABS")) << " z-slabs emulated on one GPU" << std::endl;
+        std::cout << "--     . " << std::atoi(std::getenv("MI_SLABS")) << " slabs emulated on one GPU (cut along the direction with most cell layers)" << std::endl;
       std::cout << "-----------------------------------------------------------------------------" << std::endl
                 << std::endl;
 

@@ -19,7 +19,7 @@
 namespace mi
 {
   // Decomposition of the executables, taken from the environment (the reference is single-rank, adapter.h:152-154):
-  //   MI_SLABS=N                                   N z-slabs inside this process on one GPU (emulation; tests)
+  //   MI_SLABS=N                                   N slabs inside this process on one GPU (emulation; tests)
   //   MI_WORLD_SIZE=N MI_RANK=r MI_UID_FILE=path   one process per GPU over RCCL (tools/launch_elasticity.py sets them
   //   [MI_LOCAL_RANK=d]                            and starts the N processes); rank 0 creates the RCCL id and leaves
   //                                                it in the file, the others wait for it; device = local rank

@@ -61,7 +61,7 @@ typedef struct
   double beta, gamma, delta_t;
 } mi_newmark_desc;
 
-/* domain decomposition into `size` z-slabs (last lattice direction), one slab per process/GPU with ghost planes
+/* domain decomposition into `size` slabs along one box direction (`cut_axis`), one slab per process/GPU with ghost planes
  * exchanged by ncclSend/ncclRecv and scalars by ncclAllReduce (RCCL over xGMI).  size==1 (or a NULL descriptor):
  * single GPU.  rank == -1: all `size` slabs are created inside this process on one device and advance in
  * lockstep (test mode: lets the decomposition be checked on a single-GPU box).  All entry points keep speaking
@@ -70,6 +70,9 @@ typedef struct
 {
   int32_t     rank, size;
   const void *nccl_unique_id; /* 128-byte ncclUniqueId from mi_comm_unique_id(), the same on all ranks */
+  int32_t     cut_axis;       /* direction the slabs are cut along: 0 = automatic (the one with most cell layers; ties: the
+                                 last, i.e. z-slabs of a cube), 1 / 2 / 3 = x / y / z.  The reference's flap is 18 x 3 (x 1)
+                                 cells (nonlinear_elasticity.cc:189-205): only x can be cut into more than 3 parts */
 } mi_comm_desc;
 
 /* host-only description of one slab (no device needed; used by the multi-process CPU tests) */

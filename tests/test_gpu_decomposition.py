@@ -292,3 +292,66 @@ def test_multigrid_smoother_on_element_tangents_is_slab_invariant(slabs):
     for op in (1, 2):
         assert abs(res[0][0] - res[op][0]) <= 1 and 0 < res[op][0] < 60
         assert _relmax(res[op][1], res[0][1]) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# decomposition along a chosen direction (round 3): the lattice lies rotated over the box, the C-ABI keeps speaking the
+# reference's node order.  The reference's flap is 18 x 3 (x 1) cells (nonlinear_elasticity.cc:189-205): only x can be
+# cut into more than three parts.
+@pytest.mark.parametrize("dim,p,reps,slabs,axis", [(3, 2, (5, 2, 3), 2, 1), (3, 2, (6, 2, 2), 3, 1), (3, 1, (3, 7, 4), 4, 2),
+                                                   (3, 2, (2, 5, 2), 2, 2), (3, 2, (2, 2, 5), 2, 3), (2, 2, (6, 5), 3, 1),
+                                                   (2, 3, (4, 4), 2, 1), (2, 1, (7, 3), 4, 0), (3, 3, (4, 1, 2), 2, 0)])
+def test_team_cut_along_any_axis_assembly_spmv_and_global_views(dim, p, reps, slabs, axis):
+    """axis 1 / 2 / 3 = x / y / z, 0 = automatic (most cell layers).  Distorted cells, clamp, z-clamp and interface faces
+    (the Neumann term pairs face and cell quadrature points by their PHYSICAL index, nonlinear_elasticity.cc:825-827)"""
+    P, G = _setup(dim, p, reps, slabs, seed=slabs + axis, cut_axis=axis)
+    assert G.comm_info()[0] == slabs
+    assert (G.n, G.nnz, G.ncells) == (P.n, P.nnz, P.ncells)
+    assert np.allclose(G.coords, P.coords, rtol=0, atol=1e-15)
+    assert np.array_equal(G.constrained, P.constrained)
+    ids, xyz = G.interface()
+    assert np.array_equal(ids, P.interface_nodes) and np.allclose(xyz, P.coords[ids], atol=1e-15)
+    _randomise(P, G, seed=20 + slabs)
+    v = np.random.default_rng(3).standard_normal(P.n)
+    G.set(M.V_V, v)
+    assert np.array_equal(G.get(M.V_V), v)  # global views round trip in the reference's node order
+    P.update_acceleration()
+    P.assemble()
+    G.update_acceleration()
+    rn = G.assemble()
+    assert _relmax(G.get(M.V_RHS), P.vec(O.V_RHS)) < 1e-12
+    assert abs(rn - P.residual_norm()) / P.residual_norm() < 1e-12
+    x = np.random.default_rng(4321).standard_normal(P.n)
+    assert _relmax(G.spmv(x), P.csr() @ x) < 1e-13
+
+
+@pytest.mark.parametrize("dim,slabs,axis,precond", [(3, 2, 1, 1), (3, 4, 1, 0), (3, 8, 0, 1), (2, 6, 1, 0), (2, 3, 0, 1)])
+def test_fsi3_flap_cut_along_x_matches_the_undecomposed_run(dim, slabs, axis, precond):
+    """BASELINE configuration 5's geometry (18 x 3 (x 1) cells) on 2 .. 8 parts: Newmark steps with interface tractions against
+    the oracle; axis 0 picks x by itself"""
+    p = 2
+    d = O.scenario_desc("FSI3", dim, degree=p)
+    P = O.Problem(d)
+    G = M.Context(dim=dim, degree=p, reps=tuple(d.reps)[:dim], lo=tuple(d.lo)[:dim], hi=tuple(d.hi)[:dim],
+                  face_role=list(d.face_role), slabs=slabs, cut_axis=axis)
+    assert G.comm_info()[0] == slabs
+    G.set_tuning("precond", precond)
+    ids, _ = G.interface()
+    for step in range(1, 4):
+        t = np.zeros(dim)
+        t[1] = -40.0 * step
+        P.set_interface_traction(t)
+        G.set_interface_traction(t)
+        rc_o, info_o = P.newmark_step(O.SOLVER_DIRECT)
+        rc, info = G.newmark_step(tol_lin=1e-12, max_it_mult=10.0)
+        assert rc_o == 0 and rc == 0 and info.converged == 1
+        assert info.newton_iterations == info_o.newton_iterations
+        u_o = P.vec(O.V_U).reshape(-1, dim)[ids]
+        assert np.abs(G.get_interface_displacement() - u_o).max() / np.abs(u_o).max() < 1e-8
+    for k in (M.V_U, M.V_V, M.V_A):
+        assert _relmax(G.get(k), P.vec(k)) < 1e-6
+
+
+def test_more_parts_than_layers_is_refused_with_the_axis_named():
+    with pytest.raises(M.MiError, match="more ranks than cell layers"):
+        M.Context(dim=3, degree=1, reps=(3, 2, 2), slabs=4, cut_axis=2)

@@ -28,7 +28,10 @@ def fake_lib():
                                                           (4, 3, 1, "4,3,9", 1, 0), (2, 3, 2, "3,2,5", 0, 0),
                                                           (3, 2, 3, "4,9", 1, 0), (8, 3, 2, "3,3,17", 1, 0),
                                                           (3, 3, 2, "3,3,7", 1, 1), (3, 3, 2, "3,3,7", 1, 2),
-                                                          (2, 3, 2, "4,3,6", 0, 2)])
+                                                          (2, 3, 2, "4,3,6", 0, 2),
+                                                          # most cell layers along x / y: the lattice lies rotated over the box
+                                                          (3, 3, 2, "7,2,3", 1, 0), (4, 3, 1, "3,9,2", 1, 0),
+                                                          (3, 2, 2, "9,4", 1, 0), (4, 3, 2, "9,2,2", 0, 2)])
 def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, overlap, ebe):
     """ebe = 1 / 2: the multigrid smoother on the stored element tangents / matrix-free, as on big meshes"""
     out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap),

@@ -210,13 +210,27 @@ def test_executable_on_emulated_slabs(tmp_path):
     (tmp_path / "two").mkdir()
     out1, rows1 = _run_case("block_neo_3d_q2", "elasticity3d", tmp_path / "one")
     out2, rows2 = _run_case("block_neo_3d_q2", "elasticity3d", tmp_path / "two", env={"MI_SLABS": "2"})
-    assert "2 z-slabs emulated on one GPU" in out2 and "z-slabs" not in out1
+    assert "2 slabs emulated on one GPU" in out2 and "slabs emulated" not in out1
     assert len(rows1) == len(rows2) > 0
     for a, b in zip(rows1, rows2):
         assert a[0] == b[0] and np.abs(a[1:] - b[1:]).max() <= 1e-9 * np.abs(a[1:]).max()
     v1 = open(tmp_path / "one" / "out" / "solution-001.vtk").read().split()
     v2 = open(tmp_path / "two" / "out" / "solution-001.vtk").read().split()
     assert len(v1) == len(v2)
+
+
+def test_executable_cuts_the_flap_along_x(tmp_path):
+    """BASELINE configuration 5's geometry in 3D: the FSI3 flap has 18 x 3 x 1 cells (nonlinear_elasticity.cc:189-205), so
+    until round 3 it could not be decomposed at all (slabs were cut along z only).  Four parts along x, chosen by the
+    library itself, against the undecomposed run: same displacement log to the linear tolerance."""
+    (tmp_path / "one").mkdir()
+    (tmp_path / "four").mkdir()
+    out1, rows1 = _run_case("fsi3_neo_3d_q3", "elasticity3d", tmp_path / "one")
+    out4, rows4 = _run_case("fsi3_neo_3d_q3", "elasticity3d", tmp_path / "four", env={"MI_SLABS": "4"})
+    assert "4 slabs emulated on one GPU" in out4
+    assert len(rows1) == len(rows4) > 0
+    for a, b in zip(rows1, rows4):
+        assert a[0] == b[0] and np.abs(a[1:] - b[1:]).max() <= 1e-8 * np.abs(a[1:]).max()
 
 
 def test_launcher_rank_environment_is_validated(tmp_path):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Start the `elasticity` executable on N GPUs of one node: one process per GPU, the box cut into N z-slabs, ghost planes
+"""Start the `elasticity` executable on N GPUs of one node: one process per GPU, the box cut into N slabs (along the direction with most cell layers), ghost planes
 and reductions over RCCL (the reference is single-rank, adapter.h:152-154; this is the launcher DESIGN.md section 6
 describes).  Every process runs the same program on global views of the interface; with the replay participant (the
 default build) the coupling side of the case is therefore unchanged, and rank 0 prints and writes the output files.
