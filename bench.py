@@ -354,7 +354,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         lin_its_last = [int(info.lin_its[i]) for i in range(min(info.newton_iterations, 16))]
-        r = {"G": G, "elapsed": elapsed, "lin_its_last": lin_its_last, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
+        cnt = {k: G.get_tuning("count_" + k) for k in ("scalar_allreduce", "vector_allreduce", "halo_exchange", "cg_host_sync",
+                                                        "cg_iterations", "cg_solves")}
+        r = {"G": G, "elapsed": elapsed, "lin_its_last": lin_its_last, "counts": cnt, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
              "tm": G.timings(), "comm": G.comm_info()}
         return r
 
@@ -405,6 +407,14 @@ def main():
                 "cg_start": "zero for every solve (the reference starts the 2nd, 3rd ... solve of a step from the previous Newton "
                             "update: same stopping rule, more iterations; --cg-start previous-update)"
                 if args.cg_start == "zero" else "previous Newton update, as in the reference (nonlinear_elasticity.cc:419,472)",
+                # latency-bound events of the linear solves per CG iteration / per solve.  Complete for a decomposed run
+                # (N ranks or --slabs N); on ONE slab the scalar all-reduce sites are still counted (they are no-ops there)
+                # while halo exchanges and the V-cycle's vector all-reduce are skipped before their counters
+                "collectives_per_iteration": {
+                    "scalar_allreduce": R["counts"]["scalar_allreduce"] / max(R["counts"]["cg_iterations"], 1),
+                    "vector_allreduce": R["counts"]["vector_allreduce"] / max(R["counts"]["cg_iterations"], 1),
+                    "halo_exchange": R["counts"]["halo_exchange"] / max(R["counts"]["cg_iterations"], 1)},
+                "host_syncs_per_solve": R["counts"]["cg_host_sync"] / max(R["counts"]["cg_solves"], 1),
                 "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
                 "ms_cg_per_step": tm["cg_total"][0] / args.steps,
                 "ms_sell_copy_per_step": tm["sell_copy"][0] / args.steps,

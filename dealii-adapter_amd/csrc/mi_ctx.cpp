@@ -445,6 +445,7 @@ namespace mi_detail
   // sum over all slabs of d_sc[off .. off+cnt) in place
   int team_allreduce(Team &T, int off, int cnt)
   {
+    ++T.n_scalar_allreduce;
     if (T.size == 1)
       return MI_OK;
     mi_ctx *c0 = T.members[0];
@@ -462,6 +463,7 @@ namespace mi_detail
   int team_halo_begin(Team &T, const std::function<double *(mi_ctx *)> &vec,
                       const std::function<mi_ctx *(mi_ctx *)> &ctx_of)
   {
+    ++T.n_halo;
     if (T.size == 1)
       return MI_OK;
     const int D = T.dim;
@@ -523,6 +525,7 @@ namespace mi_detail
   // sum over all slabs of a replicated vector (every slab holds all n entries): coarse multigrid residuals
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n)
   {
+    ++T.n_vector_allreduce;
     if (T.size == 1)
       return MI_OK;
     if (T.nccl)
@@ -834,6 +837,7 @@ namespace mi_detail
       HIPCHK(c0, hipMemcpyAsync(h_flags, c0->d_flags, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, c0->stream));
       HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc, 8 * sizeof(double), hipMemcpyDeviceToHost, c0->stream));
       HIPCHK(c0, hipStreamSynchronize(c0->stream));
+      ++T.n_cg_sync;
       done = h_flags[0] != 0;
       return MI_OK;
     };
@@ -909,6 +913,8 @@ namespace mi_detail
       return rc;
     if (its)
       *its = h_flags[1];
+    ++T.n_cg_solves;
+    T.n_cg_its += h_flags[1];
     if (res)
       *res = c0->h_pinned[SC_RES];
     c0->cg_breakdown = h_flags[0] == 2;
@@ -2141,6 +2147,18 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = m->precond;
   else if (k == "spmv_variant")
     *value = m->spmv_variant;
+  else if (k == "count_scalar_allreduce")
+    *value = int(c->team->n_scalar_allreduce);
+  else if (k == "count_vector_allreduce")
+    *value = int(c->team->n_vector_allreduce);
+  else if (k == "count_halo_exchange")
+    *value = int(c->team->n_halo);
+  else if (k == "count_cg_host_sync")
+    *value = int(c->team->n_cg_sync);
+  else if (k == "count_cg_iterations")
+    *value = int(c->team->n_cg_its);
+  else if (k == "count_cg_solves")
+    *value = int(c->team->n_cg_solves);
   else
     return fail(c, MI_EINVAL, "unknown tuning key '%s'", k.c_str());
   return MI_OK;
@@ -2154,6 +2172,8 @@ int mi_set_profiling(mi_ctx *c, int enable)
 int mi_reset_timings(mi_ctx *c)
 {
   int rc = sync(c);
+  Team &T = *c->team;
+  T.n_scalar_allreduce = T.n_vector_allreduce = T.n_halo = T.n_cg_sync = T.n_cg_its = T.n_cg_solves = 0;
   std::memset(&c->team->members[0]->timings, 0, sizeof(mi_timings));
   return rc;
 }

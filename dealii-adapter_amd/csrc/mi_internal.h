@@ -76,6 +76,10 @@ namespace mi_detail
     std::vector<int64_t>  e2i, i2e;
     std::vector<double>   perturb_int;         // vertex perturbation in internal vertex order (tests)
     int64_t ext_node(int64_t internal) const { return i2e.empty() ? internal : i2e[size_t(internal)]; }
+    // what a solve costs in latency-bound events since the last mi_reset_timings: scalar all-reduces, vector all-reduces,
+    // halo exchanges (complete for a decomposed team; a single slab skips the last two before their counters), host
+    // synchronisations and iterations inside cg_run
+    int64_t n_scalar_allreduce = 0, n_vector_allreduce = 0, n_halo = 0, n_cg_sync = 0, n_cg_its = 0, n_cg_solves = 0;
   };
 } // namespace mi_detail
 

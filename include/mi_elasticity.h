@@ -266,6 +266,9 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update; "solver_type" 0 (default) | 1: see mi_direct_solve; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
  * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
+/* counters since the last mi_reset_timings (what a solve costs in latency-bound events; counted on one slab as well,
+ * where the collectives themselves are no-ops): "count_scalar_allreduce", "count_vector_allreduce",
+ * "count_halo_exchange", "count_cg_host_sync", "count_cg_iterations", "count_cg_solves" */
 /* read back: "smoother_operator_active" (2 / 1: the smoother's fine-level products are matrix-free / use the stored
  * element tangents, 0: the assembled matrix), "precond",
  * "spmv_variant" */
