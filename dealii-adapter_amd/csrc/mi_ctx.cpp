@@ -396,6 +396,7 @@ namespace mi_detail
             p.slice0  = 0;
             p.nslices = nin;
             p.part0   = 0;
+            p.split   = c->split_int;
             mi::launch_sell_spmv(c->dim, p, c->grid_spmv_int, c->stream, c->sell_unroll);
           }
         if (part != 1 && nbd > 0)
@@ -403,6 +404,7 @@ namespace mi_detail
             p.slice0  = nin;
             p.nslices = nbd;
             p.part0   = nin > 0 ? c->grid_spmv_int : 0;
+            p.split   = c->split_bnd;
             mi::launch_sell_spmv(c->dim, p, c->grid_spmv_bnd, c->stream, c->sell_unroll);
           }
       }
@@ -1091,9 +1093,13 @@ namespace mi_detail
     c->grid_vec  = int(std::max<int64_t>(1, std::min<int64_t>(1024, (c->own_n + 255) / 256)));
     {
       const int64_t nin = m.sell_nslices_interior, nbd = m.sell_nslices - nin;
-      constexpr int64_t W = mi::SELL_WPB; // one wavefront per slice, W wavefronts per workgroup
-      c->grid_spmv_bnd  = int(std::min<int64_t>(MAX_PART / 4, (nbd + W - 1) / W));
-      c->grid_spmv_int  = int(std::min<int64_t>(MAX_PART - c->grid_spmv_bnd, (nin + W - 1) / W));
+      constexpr int64_t W = mi::SELL_WPB; // one wavefront per slice, W wavefronts per workgroup ...
+      // ... unless the launch is small: then one WORKGROUP per slice (sell_spmv_split), decided by the slice count alone
+      const bool use_split = !(getenv("MI_SELL_SPLIT") && atoi(getenv("MI_SELL_SPLIT")) == 0);
+      c->split_int      = use_split && nin > 0 && nin <= mi::SELL_SPLIT_MAX_SLICES;
+      c->split_bnd      = use_split && nbd > 0 && nbd <= mi::SELL_SPLIT_MAX_SLICES;
+      c->grid_spmv_bnd  = c->split_bnd ? int(nbd) : int(std::min<int64_t>(MAX_PART / 4, (nbd + W - 1) / W));
+      c->grid_spmv_int  = c->split_int ? int(nin) : int(std::min<int64_t>(MAX_PART - c->grid_spmv_bnd, (nin + W - 1) / W));
       c->grid_spmv      = std::max(1, c->grid_spmv_int + c->grid_spmv_bnd);
       if (nin == 0 && nbd == 0)
         c->grid_spmv_int = 1;
@@ -2075,6 +2081,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->sell_unroll = value;
       else if (k == "spmv_grid" && value >= 1 && value + m->grid_spmv_bnd <= MAX_PART)
         {
+          m->split_int = m->split_bnd = false; // an explicit grid means the one-wavefront-per-slice kernel
           if (m->mesh.sell_nslices_interior > 0)
             m->grid_spmv_int = value;
           else

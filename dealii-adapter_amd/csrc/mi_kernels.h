@@ -118,6 +118,8 @@ namespace mi
     int32_t        part0;              // first slot of `partials` this launch writes (one per workgroup)
     int32_t        own_begin, own_end; // rows (nodes) that contribute to the fused dot product
     int32_t        xcd_remap; // 1: workgroups of one XCD take a contiguous eighth of the slices (measured slower)
+    int32_t        split;     // 1: small launch -- one workgroup of SELL_SPLIT_W wavefronts per slice (sell_spmv_split; the
+                              // dot partials then count one per SLICE); set from the launch's slice count alone
   };
 
   struct CgParams
@@ -190,6 +192,7 @@ namespace mi
   void launch_band_extract(int dim, const SellParams &p, const int32_t *bperm, double *band, int hbw, hipStream_t s);
   int  launch_band_cholesky_solve(int dim, double *band, int n, int hbw, const int32_t *bperm, int nnodes, const double *b,
                                   double *x, double *work, int32_t *flag, bool factor, bool solve, hipStream_t s); // -1: band too wide
+  constexpr int SELL_SPLIT_MAX_SLICES = 160; // launches up to this many slices take the k-split kernel (sell_spmv_split)
   constexpr int SELL_WPB = 3;   // wavefronts (= slices in flight) per workgroup of sell_spmv: launch grids and dot partials count in these
   constexpr int EBE_NBLK = 378; // 27 * 28 / 2 node-pair blocks of a 3D Q2 cell
   void launch_vals_to_f32(const double *vals, float *vals32, int64_t n, hipStream_t s); // the smoother's fp32-rounded copy (opt-in)

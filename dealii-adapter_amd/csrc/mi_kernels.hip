@@ -1558,6 +1558,137 @@ namespace mi
   // CHEB: Chebyshev-Jacobi update fused into the epilogue (see SellParams), y is not written
   // ICOL: column indices generated from the row's column box (SellParams::rowbox) instead of read from memory
   // NTL: matrix values loaded with the non-temporal hint
+  // what a row does with its finished product (acc = (K x)_row): plain store, fused dot partial, or the fused
+  // Chebyshev-Jacobi step / residual of the multigrid smoother (see SellParams)
+  template <int D, bool DOT, bool CHEB>
+  __device__ __forceinline__ void sell_row_epilogue(const SellParams &prm, const int node, const double *acc, double &dsum)
+  {
+    constexpr int DD = D * D;
+    if (node < 0)
+      return;
+    double res[D];
+    if constexpr (CHEB)
+      {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          res[i] = prm.cheb_b[int64_t(node) * D + i] - acc[i];
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      {
+        const int64_t idx = int64_t(node) * D + i;
+        if constexpr (CHEB)
+          {
+            if (prm.cheb_d)
+              {
+                double s = prm.cheb_dinv[idx] * res[i];
+                if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
+                  {
+                    s = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j)
+                      s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
+                  }
+                // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a
+                // solve that broke down)
+                const double dn    = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * prm.cheb_d[idx] : 0.0) + prm.cheb_c2 * s;
+                prm.cheb_d[idx]    = dn;
+                prm.cheb_xout[idx] = prm.x[idx] + dn;
+              }
+            else
+              prm.y[idx] = res[i]; // residual mode: y = b - K x
+          }
+        else
+          prm.y[idx] = acc[i];
+        if (DOT && node >= prm.own_begin && node < prm.own_end)
+          dsum += acc[i] * prm.dotv[idx];
+      }
+  }
+
+  // ------------------------------------------------------------------ the same product for SMALL launches (k-split)
+  // A launch with a few dozen slices (coarse multigrid levels, the boundary rows of a slab, mid-size problems) cannot
+  // fill the chip with one wavefront per slice, and that wavefront walks through its 9-25 x-lines one memory round trip
+  // at a time: 14-21 us per product whatever the level (round 2 trace).  Here one WORKGROUP of SELL_SPLIT_W wavefronts
+  // owns a slice: wave w takes the x-lines g = w, w + W, ... (every lane loads its own wx blocks straight from memory --
+  // the matrix of such a level sits in the L2 / Infinity Cache), the partial sums of the waves meet in LDS and wave 0
+  // adds them in wave order (deterministic) and runs the row epilogue.  The summation order differs from sell_spmv's
+  // (x-lines interleaved over the waves), so which of the two kernels a launch takes depends on the launch's slice count
+  // alone (SELL_SPLIT_MAX_SLICES), never on timing.
+  constexpr int SELL_SPLIT_W = 8;
+  template <int D, bool DOT, bool F32, bool CHEB, bool ICOL>
+  __global__ __launch_bounds__(SELL_SPLIT_W * 64) void sell_spmv_split(SellParams prm)
+  {
+    if (prm.done && *prm.done)
+      return;
+    constexpr int DD = D * D, W = SELL_SPLIT_W;
+    using VT         = typename std::conditional<F32, float, double>::type;
+    __shared__ double s_part[W][D][64];
+    __shared__ double s_red[W];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl   = prm.slice0 + blockIdx.x;
+    double    dsum = 0.0;
+    const int     wx  = prm.wx[sl];
+    const int     len = prm.len[sl], ng = len / wx;
+    const int64_t off = prm.off[sl];
+    const int     node = prm.perm[int64_t(sl) * 64 + lane];
+    const VT *__restrict__ vbase =
+      (F32 ? reinterpret_cast<const VT *>(prm.vals32) : reinterpret_cast<const VT *>(prm.vals)) + (off * 64 + int64_t(lane) * wx) * DD;
+    const int32_t *__restrict__ cp = prm.col + off * 64 + lane;
+    int32_t b0 = 0, wy = 1;
+    if constexpr (ICOL)
+      {
+        b0 = prm.rowbox[(int64_t(sl) * 64 + lane) * 2];
+        wy = (prm.rowbox[(int64_t(sl) * 64 + lane) * 2 + 1] >> 8) & 255;
+      }
+    double acc[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      acc[i] = 0.0;
+    for (int g = wave; g < ng; g += W)
+      {
+        const VT *__restrict__ vp = vbase + int64_t(g) * (64 * wx) * DD;
+        const int32_t c0 = ICOL ? b0 + (g % wy) * prm.nn0 + (g / wy) * prm.nn0 * prm.nn1 : 0;
+        for (int kx = 0; kx < wx; ++kx)
+          {
+            const int32_t c = ICOL ? c0 + kx : cp[int64_t(g * wx + kx) * 64];
+            double        v[DD], xx[D];
+#pragma unroll
+            for (int e = 0; e < DD; ++e)
+              v[e] = double(vp[kx * DD + e]);
+#pragma unroll
+            for (int j = 0; j < D; ++j)
+              xx[j] = prm.x[int64_t(c) * D + j];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                acc[i] += v[i * D + j] * xx[j];
+          }
+      }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+      s_part[wave][i][lane] = acc[i];
+    __syncthreads();
+    if (wave == 0)
+      {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          {
+            double t = s_part[0][i][lane];
+            for (int w = 1; w < W; ++w)
+              t += s_part[w][i][lane];
+            acc[i] = t;
+          }
+        sell_row_epilogue<D, DOT, CHEB>(prm, node, acc, dsum);
+      }
+    if (DOT)
+      {
+        const double tot = block_sum<W * 64>(dsum, s_red);
+        if (threadIdx.x == 0)
+          prm.partials[prm.part0 + blockIdx.x] = tot;
+      }
+  }
+
   constexpr int SELL_STAGE_BYTES = 23040; // 64 rows x 5 blocks x 72 bytes: the largest chunk of 3D Q2
   template <int D, int WXT, bool NTL, bool DOT, bool F32, bool CHEB, bool ICOL>
   __device__ __forceinline__ void sell_slice(const SellParams &prm, const int sl, const int wx_rt, const int lane, char *stage,
@@ -1656,46 +1787,7 @@ namespace mi
             MI_WAVE_SYNC(); // the buffer is free again
           }
       }
-    if (node >= 0)
-      {
-        double res[D];
-        if constexpr (CHEB)
-          {
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-              res[i] = prm.cheb_b[int64_t(node) * D + i] - acc[i];
-          }
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-          {
-            const int64_t idx = int64_t(node) * D + i;
-            if constexpr (CHEB)
-              {
-                if (prm.cheb_d)
-                  {
-                    double s = prm.cheb_dinv[idx] * res[i];
-                    if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
-                      {
-                        s = 0.0;
-#pragma unroll
-                        for (int j = 0; j < D; ++j)
-                          s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
-                      }
-                    // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a
-                    // solve that broke down)
-                    const double dn    = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * prm.cheb_d[idx] : 0.0) + prm.cheb_c2 * s;
-                    prm.cheb_d[idx]    = dn;
-                    prm.cheb_xout[idx] = prm.x[idx] + dn;
-                  }
-                else
-                  prm.y[idx] = res[i]; // residual mode: y = b - K x
-              }
-            else
-              prm.y[idx] = acc[i];
-            if (DOT && node >= prm.own_begin && node < prm.own_end)
-              dsum += acc[i] * prm.dotv[idx];
-          }
-      }
+    sell_row_epilogue<D, DOT, CHEB>(prm, node, acc, dsum);
   }
 
   template <int D, bool NTL = true, bool DOT = false, bool F32 = false, bool CHEB = false, bool ICOL = false>
@@ -3568,10 +3660,34 @@ namespace mi
     else
       hipLaunchKernelGGL((sell_spmv<D, NTL, DOT, F32, CHEB, ICOL>), dim3(grid), dim3(SELL_WPB * 64), 0, s, p);
   }
+  template <int D, bool DOT, bool F32, bool CHEB, bool ICOL>
+  static void sell_launch_split(const SellParams &p, hipStream_t s)
+  {
+    const hipEvent_t a = g_ev_start, b = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    if (a && b)
+      hipExtLaunchKernelGGL((sell_spmv_split<D, DOT, F32, CHEB, ICOL>), dim3(p.nslices), dim3(SELL_SPLIT_W * 64), 0, s, a, b, 0, p);
+    else
+      hipLaunchKernelGGL((sell_spmv_split<D, DOT, F32, CHEB, ICOL>), dim3(p.nslices), dim3(SELL_SPLIT_W * 64), 0, s, p);
+  }
   template <int D, bool NTL, bool ICOL>
   static void sell_dispatch(const SellParams &p, int grid, hipStream_t s)
   {
     const bool dot = p.dotv && p.partials, cheb = (p.cheb_d || p.cheb_b) && !dot, f32 = p.vals32 && !dot;
+    if (p.split) // small launch: one workgroup per slice (the caller decides from the slice count, see SellParams::split)
+      {
+        if (dot)
+          sell_launch_split<D, true, false, false, ICOL>(p, s);
+        else if (cheb && f32)
+          sell_launch_split<D, false, true, true, ICOL>(p, s);
+        else if (cheb)
+          sell_launch_split<D, false, false, true, ICOL>(p, s);
+        else if (f32)
+          sell_launch_split<D, false, true, false, ICOL>(p, s);
+        else
+          sell_launch_split<D, false, false, false, ICOL>(p, s);
+        return;
+      }
     if (dot)
       sell_launch<D, NTL, true, false, false, ICOL>(p, grid, s);
     else if (cheb && f32)
