@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector (non-MFMA) peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 MF_FLOPS_PER_LANE = 1060.0  # FP64 flop per lane of a cell's wavefront in mf_spmv (counter pass of profiles/r03, see roofline.fp64)
-CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")
+CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")  # unit counts of a whole CPU step (deterministic)
 
 
 def _pkg():
@@ -263,6 +263,10 @@ def main():
     ap.add_argument("--cpu-cells", type=int, default=34,
                     help="cells per side of the CPU-baseline sample (34 = BASELINE configuration 3; 0: skip)")
     ap.add_argument("--cpu-its", type=str, default="8,30", help="CG iterations timed by the CPU sample: SSOR,Jacobi")
+    ap.add_argument("--cpu-config4", action="store_true",
+                    help="also run the CPU leg on the metric's own mesh (BASELINE configuration 4, 59^3 cells): ONE Newton iteration = "
+                         "one assembly + CG+SSOR and CG+Jacobi solves, ~6 minutes on a 64-core socket; reproduces the constants "
+                         "committed in profiles/r02/cpu_baseline_config4_one_newton_iteration.json inside a driver run")
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -492,7 +496,7 @@ def main():
                 "kernel": ("mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
                            "point numbers per cell the tangent is linearised at (sum factorisation, no stored K_e; 4.8x fewer bytes "
                            "than the element tangents it replaced, which takes the product off the HBM roofline: VALU, LDS and HBM "
-                           "are each half to three quarters busy, profiles/r02/pmc_counters_mf_spmv_n59.json); "
+                           "are each half to three quarters busy, profiles/r03/pmc_counters_mf_spmv_n59.json); "
                            if form == 2 else
                            "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
                            "tangents (378 lower-triangle 3x3 blocks per cell); ") +
@@ -539,25 +543,32 @@ def main():
             G.set_tuning("spmv_variant", 3)
             out["roofline"]["calibration_stream_read"] = {"ms": ms_cal, "GB": 8 * G.nnz / 1e9,
                                                           "GB_per_s": 8 * G.nnz / ms_cal / 1e6}
-        pmc_file = os.path.join(ROOT, "profiles", "r02", "pmc_bench_n59.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r03", "pmc_bench_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
-            # per-launch HBM traffic of this very command under `rocprofv3 --pmc` (tools/pmc_bench.sh), as committed
+            # NOT a measurement of this run: per-launch HBM traffic of the same command under `rocprofv3 --pmc`
+            # (tools/pmc_bench.sh), as committed with the round's profiles; `roofline.traffic` itself stays null because
+            # PMC counters cannot be collected from inside this process
             pmc = json.load(open(pmc_file))
             how = ("rocprofv3 --pmc over `python3 bench.py --steps 1 --warmup 0 --cpu-cells 0`, one counter per pass: "
                    "TCC_EA0_RDREQ x 128 B - TCC_EA0_RDREQ_32B x 96 B + WRITE_SIZE x 1 KiB (tools/pmc_bench.sh)")
-            dot = [v for k, v in pmc.items() if k.startswith("mi::sell_spmv<3, 2, 0, 1, true")]
-            cgobj = out["roofline"].get("cg_product", out["roofline"])
+            ref = {"note": "committed counter passes of another process of the same command, not of this run", "how": how,
+                   "source": os.path.relpath(pmc_file, ROOT)}
+            dot = [v for k, v in pmc.items() if k.startswith("mi::sell_spmv<3, true, true")]
             if dot:
-                cgobj["traffic_from_committed_profile"] = {
-                    "GB_per_launch": dot[0]["traffic_GB_per_launch"], "source": os.path.relpath(pmc_file, ROOT),
-                    "ratio_to_algorithmic": dot[0]["traffic_GB_per_launch"] / (bytes_bsr / 1e9), "how": how}
+                ref["cg_product"] = {"GB_per_launch": dot[0]["traffic_GB_per_launch"],
+                                     "ratio_to_algorithmic": dot[0]["traffic_GB_per_launch"] / (bytes_bsr / 1e9)}
             eb = [v for k, v in pmc.items() if k.startswith("mi::mf_spmv" if form == 2 else "mi::ebe_spmv")
                   and (not single or v["traffic_GB_per_launch"] > 1.0)]
             if eb and "cg_product" in out["roofline"]:
                 tot = sum(v["traffic_GB_per_launch"] * v["launches"] for v in eb) / sum(v["launches"] for v in eb)
-                out["roofline"]["traffic_from_committed_profile"] = {
-                    "GB_per_launch": tot, "source": os.path.relpath(pmc_file, ROOT),
-                    "ratio_to_algorithmic": tot / out["roofline"]["algorithmic_GB_per_launch"], "how": how}
+                ref["dominant_kernel"] = {"GB_per_launch": tot,
+                                          "ratio_to_algorithmic": tot / out["roofline"]["algorithmic_GB_per_launch"]}
+            asm = [v for k, v in pmc.items() if k.startswith("mi::assemble_q2sf<false>")]
+            if asm:
+                ref["assemble_q2sf_per_tangent_assembly"] = {
+                    "GB": sum(v["traffic_GB_per_launch"] * v["launches"] for v in asm) / (sum(v["launches"] for v in asm) / 8.0),
+                    "note": "eight colour launches per assembly (launch-weighted mean per launch x 8)"}
+            out["roofline"]["reference_profiles"] = ref
     del G, R
     # ---- second field for N > 1: weak scaling (one cells^3 block per GPU)
     if world > 1 and not replicas and not args.no_weak and args.scaling == "strong":
@@ -600,6 +611,12 @@ def main():
             gpu_same = {"value": out["value"], "ms_per_step": out["ms_per_step"], "n_dofs": out["config"]["n_dofs"]}
         out["cpu_baseline"] = cpu_baseline(args.cpu_cells, its_a, its_b)
         out["cpu_baseline"]["gpu_same_config"] = gpu_same
+        if args.cpu_config4:
+            p4 = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "59,0,0,2"], capture_output=True,
+                                text=True, timeout=3000)
+            l4 = [l for l in p4.stdout.splitlines() if l.startswith("{")]
+            out["cpu_baseline"]["config4_one_newton_iteration_live"] = json.loads(l4[-1]) if (p4.returncode == 0 and l4) else {
+                "error": (p4.stderr or p4.stdout)[-300:]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -7,7 +7,8 @@ OUT=gpurun_out/pmc_mf; rm -rf $OUT; mkdir -p $OUT
 i=0
 for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_LDS_UNALIGNED_STALL" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" \
-         "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LEVEL_WAVES GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_32B_sum" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+         "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LEVEL_WAVES GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_32B_sum" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+         "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64"; do
   i=$((i+1))
   rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 tools/time_element_products.py 59 2 > $OUT/p$i.log 2>&1 || echo "pass $i ($C) failed"
 done
