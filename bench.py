@@ -27,7 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector (non-MFMA) peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-MF_FLOPS_PER_LANE = 1060.0  # FP64 flop per lane of a cell's wavefront in mf_spmv (counter pass of profiles/r03, see roofline.fp64)
+MF_FLOPS_PER_LANE = 734.0  # FP64 flop per lane of a cell's wavefront in mf_spmv: (2 x 63.67 M FMA + 20.95 M MUL + 2.46 M ADD +
+# 0.21 M TRANS wave instructions) x 64 lanes / (205,379 cells x 64 lanes), profiles/r03/pmc_counters_mf_spmv_n59.json
 CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")  # unit counts of a whole CPU step (deterministic)
 
 
