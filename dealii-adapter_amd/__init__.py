@@ -12,7 +12,7 @@ import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "libmi_elasticity.so")
+LIB_PATH = os.environ.get("MI_LIB") or os.path.join(PKG_DIR, "libmi_elasticity.so")  # MI_LIB: A/B of two builds in one job (tools)
 HEADER = os.path.join(ROOT, "include", "mi_elasticity.h")
 
 MI_OK, MI_EINVAL, MI_EHIP, MI_ENOCONV_LIN, MI_ENOCONV_NR, MI_ECOMM = 0, -1, -2, -3, -4, -5
