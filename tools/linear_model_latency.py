@@ -19,9 +19,11 @@ def main():
     cases = [("block 3D Q1 40^3 (config 2)", 3, 1, (40, 40, 40), (0, 0, 0), (1, 1, 1)),
              ("beam 3D Q1 80x8x8 [0,10]x[0,1]^2", 3, 1, (80, 8, 8), (0, 0, 0), (10, 1, 1)),
              ("FSI3 2D p=3 (shipped)", 2, 3, (18, 3), (0.24899, 0.19), (0.6, 0.21))]
-    for name, dim, p, reps, lo, hi in cases:
+    for name, dim, p, reps, lo, hi in cases + [(c[0] + ", Solver type = Direct",) + c[1:] for c in cases[2:]]:
         t0 = time.perf_counter()
         G = M.Context(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=[1, 7, 7, 7, 8, 8])
+        if name.endswith("Direct"):  # banded Cholesky of the constant system matrix, factorised once
+            G.set_tuning("solver_type", 1)
         assert L.mi_linear_setup(G.h, 0.5) == 0, L.mi_last_error(G.h)
         t_setup = time.perf_counter() - t0
         tr = (0.0, -200.0, 0.0)[:dim]
