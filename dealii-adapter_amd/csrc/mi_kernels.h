@@ -71,6 +71,24 @@ namespace mi
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
   };
 
+  // constant operators of the linear model (linear_elasticity.cc:248-374), one launch per colour
+  struct LinAsmParams
+  {
+    const int32_t  *conn;    // [ncells][npc] colour-sorted
+    const double   *cverts;  // [ncells][2^dim][dim]
+    const uint16_t *off;     // as AsmParams::off
+    const int2     *rowinfo; // as AsmParams::rowinfo
+    const uint8_t  *cmask;   // [nnodes]
+    const double   *tab;     // N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1] of the LINEAR model's rule (nq1 = p + 1, :61)
+    int32_t         np1, nq1;
+    double          lambda, mu, rho, ctheta; // Lame parameters, density, theta^2 dt^2
+    double          body[3];
+    double         *K, *M, *A; // block values in the tangent's layout, zeroed by the caller
+    double         *bodyvec;   // [ndofs] rho b integrated against the shape functions (:358-373), or null
+    int64_t         cell_begin;
+    int32_t         cell_count;
+  };
+
   // row-per-wave cross-check product (tests) and the streaming calibration kernels
   struct SpmvParams
   {
@@ -225,6 +243,7 @@ namespace mi
   // whole Jacobi-PCG in one single-workgroup launch (small problems, one slab)
   void launch_cg_small(int dim, const SellParams &p, const CgParams &c, const double *b, double rel_tol, int max_it,
                        hipStream_t s);
+  void launch_assemble_linear(int dim, const LinAsmParams &p, hipStream_t s);
   void launch_extract_dinv(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
                            hipStream_t s);
   void launch_masked_norm(int dim, const double *v, const uint8_t *cmask, int64_t n, double *part, int grid,

@@ -1278,6 +1278,146 @@ namespace mi
       }
   }
 
+  // ------------------------------------------------------------------ linear model: K, M, stepping matrix, body force
+  // linear_elasticity.cc:248-374.  The operators are constant: assembled once per set-up, so this kernel is written for
+  // generality (any dim / degree the mesh tables allow, runtime loops), not for speed.  One workgroup per cell of the
+  // colour; the points' inverse Jacobians and weights go to LDS, then every thread walks over node pairs (a,b):
+  //   K_ab[ci][cj] = sum_q (lambda g_a[ci] g_b[cj] + mu g_a[cj] g_b[ci] + delta_cicj mu g_a.g_b) JxW      (:301-320)
+  //   M_ab         = sum_q rho N_a N_b JxW  (on the diagonal of the block)                                  (:341-345)
+  //   A_ab         = M_ab + theta^2 dt^2 K_ab with zero boundary values applied cell by cell: entries of constrained
+  //                  rows / columns dropped, the diagonal kept -- on the summed matrix that is
+  //                  MatrixTools::apply_boundary_values (:348-353, :426-451)
+  // and added to the blocks of the three operators (colouring: no other cell of the launch holds the same block).
+  template <int DIM>
+  __global__ __launch_bounds__(256) void assemble_linear_cells(LinAsmParams prm)
+  {
+    constexpr int MAXQ = 125, DD = DIM * DIM;
+    __shared__ double s_ji[MAXQ * 9], s_w[MAXQ], s_verts[8 * 3];
+    const int     tid = threadIdx.x, np1 = prm.np1, nq1 = prm.nq1;
+    const int     npc = (DIM == 2) ? np1 * np1 : np1 * np1 * np1, nq = (DIM == 2) ? nq1 * nq1 : nq1 * nq1 * nq1;
+    const int64_t cell = prm.cell_begin + blockIdx.x;
+    const double *__restrict__ N1 = prm.tab, *__restrict__ dN1 = prm.tab + nq1 * np1, *__restrict__ qw = prm.tab + 2 * nq1 * np1,
+                               *__restrict__ qx = qw + nq1;
+    if (tid < (1 << DIM) * DIM)
+      s_verts[tid] = prm.cverts[cell * ((1 << DIM) * DIM) + tid];
+    __syncthreads();
+    if (tid < nq)
+      {
+        const int qi[3] = {tid % nq1, (tid / nq1) % nq1, DIM == 3 ? tid / (nq1 * nq1) : 0};
+        double    xi[3] = {0.0, 0.0, 0.0}, w = 1.0, Jm[9], Ji[9];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d)
+          {
+            xi[d] = qx[qi[d]];
+            w *= qw[qi[d]];
+          }
+        q1_jacobian<DIM>(s_verts, xi, Jm);
+        const double detJ = det3x3(Jm);
+        inv3x3(Jm, detJ, Ji);
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          s_ji[tid * 9 + k] = Ji[k];
+        s_w[tid] = detJ * w;
+      }
+    __syncthreads();
+    // value and real-space gradient of shape function (ai) at point (qi)
+    auto shape = [&](const int *qi, const int *ai, const double *Ji, double &n, double *g) {
+      double v[3], d[3];
+#pragma unroll
+      for (int k = 0; k < DIM; ++k)
+        {
+          v[k] = N1[qi[k] * np1 + ai[k]];
+          d[k] = dN1[qi[k] * np1 + ai[k]];
+        }
+      double dn[3];
+      if constexpr (DIM == 2)
+        {
+          n     = v[0] * v[1];
+          dn[0] = d[0] * v[1];
+          dn[1] = v[0] * d[1];
+          dn[2] = 0.0;
+        }
+      else
+        {
+          n     = v[0] * v[1] * v[2];
+          dn[0] = d[0] * v[1] * v[2];
+          dn[1] = v[0] * d[1] * v[2];
+          dn[2] = v[0] * v[1] * d[2];
+        }
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+        g[i] = dn[0] * Ji[0 * 3 + i] + dn[1] * Ji[1 * 3 + i] + (DIM == 3 ? dn[2] * Ji[2 * 3 + i] : 0.0);
+    };
+    for (int pair = tid; pair < npc * npc; pair += 256)
+      {
+        const int a = pair / npc, b = pair - a * npc;
+        const int ai[3] = {a % np1, (a / np1) % np1, DIM == 3 ? a / (np1 * np1) : 0};
+        const int bi[3] = {b % np1, (b / np1) % np1, DIM == 3 ? b / (np1 * np1) : 0};
+        double    Kb[DD], Mb = 0.0;
+#pragma unroll
+        for (int k = 0; k < DD; ++k)
+          Kb[k] = 0.0;
+        for (int q = 0; q < nq; ++q)
+          {
+            const int     qi[3] = {q % nq1, (q / nq1) % nq1, DIM == 3 ? q / (nq1 * nq1) : 0};
+            const double *Ji    = &s_ji[q * 9];
+            double        na, nb, ga[3], gb[3];
+            shape(qi, ai, Ji, na, ga);
+            shape(qi, bi, Ji, nb, gb);
+            const double w  = s_w[q];
+            double       gg = 0.0;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k)
+              gg += ga[k] * gb[k];
+#pragma unroll
+            for (int ci = 0; ci < DIM; ++ci)
+#pragma unroll
+              for (int cj = 0; cj < DIM; ++cj)
+                Kb[ci * DIM + cj] += (ga[ci] * gb[cj] * prm.lambda + ga[cj] * gb[ci] * prm.mu + (ci == cj ? gg * prm.mu : 0.0)) * w;
+            Mb += prm.rho * na * nb * w;
+          }
+        const int32_t A  = prm.conn[cell * npc + a], B = prm.conn[cell * npc + b];
+        const int2    ia = prm.rowinfo[A];
+        if (ia.x < 0) // ghost row of a slab
+          continue;
+        const uint32_t o   = prm.off[(cell * npc + a) * npc + b];
+        const int64_t  pos = (int64_t(ia.x) + int64_t((o >> 4) & 0x7ff) * ia.y + (o & 15)) * DD;
+        const int      cma = prm.cmask[A], cmb = prm.cmask[B];
+#pragma unroll
+        for (int ci = 0; ci < DIM; ++ci)
+#pragma unroll
+          for (int cj = 0; cj < DIM; ++cj)
+            {
+              const double kv = Kb[ci * DIM + cj], mv = (ci == cj) ? Mb : 0.0;
+              prm.K[pos + ci * DIM + cj] += kv;
+              if (ci == cj)
+                prm.M[pos + ci * DIM + cj] += mv;
+              const bool drop = (((cma >> ci) | (cmb >> cj)) & 1) && !(a == b && ci == cj);
+              if (!drop)
+                prm.A[pos + ci * DIM + cj] += kv * prm.ctheta + mv;
+            }
+      }
+    if (prm.bodyvec && tid < npc) // create_right_hand_side with rho b (:358-373)
+      {
+        const int a     = tid;
+        const int ai[3] = {a % np1, (a / np1) % np1, DIM == 3 ? a / (np1 * np1) : 0};
+        double    s     = 0.0;
+        for (int q = 0; q < nq; ++q)
+          {
+            const int qi[3] = {q % nq1, (q / nq1) % nq1, DIM == 3 ? q / (nq1 * nq1) : 0};
+            double    n     = 1.0;
+#pragma unroll
+            for (int k = 0; k < DIM; ++k)
+              n *= N1[qi[k] * np1 + ai[k]];
+            s += n * s_w[q];
+          }
+        const int64_t g = int64_t(prm.conn[cell * npc + a]) * DIM;
+#pragma unroll
+        for (int ci = 0; ci < DIM; ++ci)
+          prm.bodyvec[g + ci] += prm.rho * prm.body[ci] * s;
+      }
+  }
+
   // ------------------------------------------------------------------ Neumann faces (:791-859)
   // one 64-thread workgroup per cell of the current colour that owns interface faces; the cell's faces are
   // processed one after the other (faces of one cell share edge/corner nodes, cells of one colour do not)
@@ -3924,6 +4064,15 @@ namespace mi
   void launch_cg_final_check(const CgParams &c, int it, hipStream_t s)
   {
     hipLaunchKernelGGL(cg_final_check, dim3(1), dim3(256), 0, s, c, it);
+  }
+  void launch_assemble_linear(int dim, const LinAsmParams &p, hipStream_t s)
+  {
+    if (p.cell_count <= 0)
+      return;
+    if (dim == 3)
+      hipLaunchKernelGGL(assemble_linear_cells<3>, dim3(p.cell_count), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL(assemble_linear_cells<2>, dim3(p.cell_count), dim3(256), 0, s, p);
   }
   void launch_extract_dinv(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
                            hipStream_t s)

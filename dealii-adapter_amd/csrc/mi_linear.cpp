@@ -1,9 +1,10 @@
 // mi_linear.cpp -- the linear elastodynamics model (ElastoDynamics, source/linear_elasticity/linear_elasticity.cc)
 // on the device context.
 //
-// Stiffness K and mass M are constant: they are assembled ONCE on the host (linear_elasticity.cc:248-374, the
-// reference does the same on the CPU) into the block pattern and uploaded in the device layout of the tangent
-// (slice-interleaved block rows, mi_mesh.hpp).  The per-step path (assemble_rhs :378-454, solve :525-575, update_displacement :579-586) runs on the
+// Stiffness K, mass M and the stepping matrix are constant: they are assembled ONCE, on the device
+// (assemble_linear_cells, colour by colour like the tangent; linear_elasticity.cc:248-374) straight into the device
+// layout of the tangent (x-line-interleaved block rows, mi_mesh.hpp); only the consistent-load operator of the interface
+// (interface-sized) is put together on the host.  The per-step path (assemble_rhs :378-454, solve :525-575, update_displacement :579-586) runs on the
 // device: fused vector kernels, 2 SpMVs (M v - K (theta(1-theta)dt^2 v + dt d)) and the warm-started PCG.
 #include <cmath>
 #include <cstring>
@@ -22,7 +23,6 @@ namespace mi_detail
     // consistent-load operator on the interface nodes (scalar CSR over interface slots), :458-521
     std::vector<int32_t> B_rowptr, B_col;
     std::vector<double>  B_val;
-    std::vector<double>  hK, hM, hA; // host block-CSR copies (parity tests)
   };
 
   void linear_destroy(mi_ctx *c)
@@ -38,13 +38,6 @@ namespace mi_detail
 
   namespace
   {
-    struct CellGeom
-    {
-      std::vector<double> G;   // [nq][npc][dim] real-space gradients
-      std::vector<double> N;   // [nq][npc]
-      std::vector<double> JxW; // [nq]
-    };
-
     // Jm[i][j] = dX_i/dxi_j of the d-linear cell map
     void jacobian(int dim, const double *verts, const double *xi, double Jm[3][3])
     {
@@ -62,89 +55,6 @@ namespace mi_detail
               Jm[i][j] += verts[v * dim + i] * g;
           }
     }
-    double det3(const double A[3][3])
-    {
-      return A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
-             A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-    }
-    void inv3(const double A[3][3], double B[3][3])
-    {
-      const double r = 1.0 / det3(A);
-      B[0][0]        = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) * r;
-      B[0][1]        = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) * r;
-      B[0][2]        = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) * r;
-      B[1][0]        = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) * r;
-      B[1][1]        = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) * r;
-      B[1][2]        = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) * r;
-      B[2][0]        = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) * r;
-      B[2][1]        = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) * r;
-      B[2][2]        = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) * r;
-    }
-
-    void cell_geometry(const mi::Tables1D &t, int dim, const double *verts, CellGeom &g)
-    {
-      const int np1 = t.np1, nq1 = t.nq1;
-      int       npc = 1, nq = 1;
-      for (int d = 0; d < dim; ++d)
-        {
-          npc *= np1;
-          nq *= nq1;
-        }
-      g.G.assign(size_t(nq) * npc * dim, 0.0);
-      g.N.assign(size_t(nq) * npc, 0.0);
-      g.JxW.assign(nq, 0.0);
-      for (int q = 0; q < nq; ++q)
-        {
-          const int qi[3] = {q % nq1, (q / nq1) % nq1, dim == 3 ? q / (nq1 * nq1) : 0};
-          double    xi[3] = {0, 0, 0}, w = 1.0;
-          for (int d = 0; d < dim; ++d)
-            {
-              xi[d] = t.qx[qi[d]];
-              w *= t.qw[qi[d]];
-            }
-          double Jm[3][3], Ji[3][3];
-          jacobian(dim, verts, xi, Jm);
-          inv3(Jm, Ji);
-          g.JxW[q] = det3(Jm) * w;
-          for (int a = 0; a < npc; ++a)
-            {
-              const int ai[3] = {a % np1, (a / np1) % np1, dim == 3 ? a / (np1 * np1) : 0};
-              double    n = 1.0, dn[3] = {0, 0, 0};
-              for (int d = 0; d < dim; ++d)
-                n *= t.N[size_t(qi[d]) * np1 + ai[d]];
-              for (int k = 0; k < dim; ++k)
-                {
-                  double v = 1.0;
-                  for (int d = 0; d < dim; ++d)
-                    v *= (d == k) ? t.dN[size_t(qi[d]) * np1 + ai[d]] : t.N[size_t(qi[d]) * np1 + ai[d]];
-                  dn[k] = v;
-                }
-              g.N[size_t(q) * npc + a] = n;
-              for (int i = 0; i < dim; ++i)
-                {
-                  double s = 0;
-                  for (int j = 0; j < dim; ++j)
-                    s += dn[j] * Ji[j][i];
-                  g.G[(size_t(q) * npc + a) * dim + i] = s;
-                }
-            }
-        }
-    }
-
-    // host block-CSR values -> the device layout of the tangent (slice-interleaved block rows, owned rows only)
-    int to_device_sell(mi_ctx *c, const std::vector<double> &bsr, double **d_sell)
-    {
-      const mi::HostMesh &m  = c->mesh;
-      const size_t        dd = size_t(c->dim) * c->dim;
-      std::vector<double> v(std::max<size_t>(1, size_t(m.nvalblocks()) * dd), 0.0);
-      for (int64_t nd = 0; nd < m.nnodes; ++nd)
-        if (m.rowinfo[2 * size_t(nd)] >= 0)
-          for (int32_t b = m.rowptr[size_t(nd)]; b < m.rowptr[size_t(nd) + 1]; ++b)
-            std::memcpy(&v[size_t(m.valpos(nd, int(b - m.rowptr[size_t(nd)]))) * dd], &bsr[size_t(b) * dd], dd * sizeof(double));
-      HIPCHK(c, hipMalloc((void **)d_sell, v.size() * sizeof(double)));
-      HIPCHK(c, hipMemcpy(*d_sell, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice));
-      return MI_OK;
-    }
   } // namespace
 } // namespace mi_detail
 
@@ -152,8 +62,8 @@ using namespace mi_detail;
 
 extern "C" {
 
-// K, M, stepping matrix, load operator and body force of ONE slab: the host loops run over the slab's local cells
-// (ghost layer included), which completes every owned row exactly as the device assembly does
+// K, M, stepping matrix, load operator and body force of ONE slab: the launches run over the slab's local cells
+// (ghost layer included), which completes every owned row exactly as the tangent's assembly does
 static int linear_setup_member(mi_ctx *c, double theta)
 {
   linear_destroy(c);
@@ -162,90 +72,70 @@ static int linear_setup_member(mi_ctx *c, double theta)
   L.theta        = theta;
 
   const mi::HostMesh &m   = c->mesh;
-  const int           dim = c->dim, npc = m.npc, dpc = npc * dim, DD = dim * dim;
+  const int           dim = c->dim, npc = m.npc, DD = dim * dim;
   const double        mu = c->mat.mu, nu = c->mat.nu, rho = c->mat.rho;
   const double        lambda = 2 * mu * nu / (1 - 2 * nu); // parameters.cc:189
   const double        dt     = c->nm.delta_t;
 
   mi::Tables1D t;
   t.build(c->degree, c->degree + 1); // quad_order = p+1 (linear_elasticity.cc:61)
-  int nq = 1, nqf = 1;
-  for (int d = 0; d < dim; ++d)
-    {
-      nq *= t.nq1;
-      if (d < dim - 1)
-        nqf *= t.nq1;
-    }
+  int nqf = 1;
+  for (int d = 0; d < dim - 1; ++d)
+    nqf *= t.nq1;
 
   double bn = 0;
   for (int d = 0; d < 3; ++d)
     bn += c->mat.body_force[d] * c->mat.body_force[d];
   L.body_force_enabled = std::sqrt(bn) > 1e-15; // :62
 
-  L.hK.assign(size_t(m.nnzb) * DD, 0.0);
-  L.hM.assign(size_t(m.nnzb) * DD, 0.0);
-  std::vector<double> body(size_t(c->n), 0.0);
-  CellGeom            g;
-  std::vector<double> Ke(size_t(dpc) * dpc), Me(size_t(npc) * npc);
-  for (int64_t cell = 0; cell < m.ncells; ++cell)
+  // K, M, A = M + theta^2 dt^2 K with zero boundary values applied, and the body-force vector: on the device
+  const size_t nval = std::max<size_t>(1, size_t(m.nvalblocks()) * DD);
+  double      *d_tab = nullptr;
+  {
+    const std::vector<double> tab = t.packed();
+    HIPCHK(c, hipMalloc((void **)&d_tab, tab.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  for (double **pp : {&L.d_K, &L.d_M, &L.d_A})
     {
-      cell_geometry(t, dim, &m.cverts[size_t(cell) * m.nv * dim], g);
-      std::fill(Ke.begin(), Ke.end(), 0.0);
-      std::fill(Me.begin(), Me.end(), 0.0);
-      for (int q = 0; q < nq; ++q)
-        for (int a = 0; a < npc; ++a)
-          {
-            const double *ga = &g.G[(size_t(q) * npc + a) * dim];
-            for (int b = 0; b < npc; ++b)
-              {
-                const double *gb = &g.G[(size_t(q) * npc + b) * dim];
-                double        gg = 0;
-                for (int k = 0; k < dim; ++k)
-                  gg += ga[k] * gb[k];
-                // :301-320  lambda d_ci N_i d_cj N_j + mu d_cj N_i d_ci N_j + delta mu grad N_i . grad N_j
-                for (int ci = 0; ci < dim; ++ci)
-                  for (int cj = 0; cj < dim; ++cj)
-                    Ke[size_t(a * dim + ci) * dpc + b * dim + cj] +=
-                      (ga[ci] * gb[cj] * lambda + ga[cj] * gb[ci] * mu + (ci == cj ? gg * mu : 0.0)) * g.JxW[q];
-                // create_mass_matrix with coefficient rho (:341-345)
-                Me[size_t(a) * npc + b] += rho * g.N[size_t(q) * npc + a] * g.N[size_t(q) * npc + b] * g.JxW[q];
-              }
-            if (L.body_force_enabled) // create_right_hand_side with rho*b (:358-373)
-              for (int ci = 0; ci < dim; ++ci)
-                body[size_t(m.conn[size_t(cell) * npc + a]) * dim + ci] +=
-                  rho * c->mat.body_force[ci] * g.N[size_t(q) * npc + a] * g.JxW[q];
-          }
-      const uint16_t *off = &m.off[size_t(cell) * npc * npc];
-      for (int a = 0; a < npc; ++a)
-        {
-          const int32_t A = m.conn[size_t(cell) * npc + a];
-          for (int b = 0; b < npc; ++b)
-            {
-              // off = g << 4 | kx (bit 15: first-touch flag): slot k = g * wx + kx of the block row of A (mi_mesh.hpp)
-              const size_t blk = size_t(m.rowptr[size_t(A)]) + ((off[a * npc + b] >> 4) & 0x7ff) * m.rowwx[size_t(A)] + (off[a * npc + b] & 15);
-              for (int ci = 0; ci < dim; ++ci)
-                {
-                  for (int cj = 0; cj < dim; ++cj)
-                    L.hK[blk * DD + ci * dim + cj] += Ke[size_t(a * dim + ci) * dpc + b * dim + cj];
-                  L.hM[blk * DD + ci * dim + ci] += Me[size_t(a) * npc + b];
-                }
-            }
-        }
+      HIPCHK(c, hipMalloc((void **)pp, nval * sizeof(double)));
+      HIPCHK(c, hipMemsetAsync(*pp, 0, nval * sizeof(double), c->stream));
     }
-  // stepping matrix M + theta^2 dt^2 K (:348-353) with zero boundary values applied (:426-451,
-  // MatrixTools::apply_boundary_values: row and column eliminated, diagonal kept)
-  L.hA.resize(L.hK.size());
-  for (size_t k = 0; k < L.hA.size(); ++k)
-    L.hA[k] = L.hK[k] * (dt * dt * theta * theta) + L.hM[k];
-  for (int64_t A = 0; A < m.nnodes; ++A)
-    for (int32_t blk = m.rowptr[size_t(A)]; blk < m.rowptr[size_t(A) + 1]; ++blk)
+  if (L.body_force_enabled)
+    {
+      HIPCHK(c, hipMalloc((void **)&L.d_body, size_t(c->n) * sizeof(double)));
+      HIPCHK(c, hipMemsetAsync(L.d_body, 0, size_t(c->n) * sizeof(double), c->stream));
+    }
+  {
+    mi::LinAsmParams p{};
+    p.conn    = c->d_conn;
+    p.cverts  = c->d_cverts;
+    p.off     = c->d_off;
+    p.rowinfo = reinterpret_cast<const int2 *>(c->d_rowinfo);
+    p.cmask   = c->d_cmask;
+    p.tab     = d_tab;
+    p.np1     = t.np1;
+    p.nq1     = t.nq1;
+    p.lambda  = lambda;
+    p.mu      = mu;
+    p.rho     = rho;
+    p.ctheta  = dt * dt * theta * theta;
+    for (int d = 0; d < 3; ++d)
+      p.body[d] = c->mat.body_force[d];
+    p.K       = L.d_K;
+    p.M       = L.d_M;
+    p.A       = L.d_A;
+    p.bodyvec = L.d_body;
+    for (int col = 0; col < m.ncolours; ++col)
       {
-        const int32_t B = m.colidx[size_t(blk)];
-        for (int i = 0; i < dim; ++i)
-          for (int j = 0; j < dim; ++j)
-            if ((((m.cmask[size_t(A)] >> i) | (m.cmask[size_t(B)] >> j)) & 1) && !(A == B && i == j))
-              L.hA[size_t(blk) * DD + i * dim + j] = 0.0;
+        p.cell_begin = m.colour_begin[size_t(col)];
+        p.cell_count = int32_t(m.colour_begin[size_t(col) + 1] - m.colour_begin[size_t(col)]);
+        mi::launch_assemble_linear(dim, p, c->stream);
       }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_tab);
+  }
 
   // consistent-load operator B_ab = int_interface N_a N_b dA (assemble_consistent_loading :458-521, no pull-back)
   {
@@ -318,19 +208,10 @@ static int linear_setup_member(mi_ctx *c, double theta)
       }
   }
 
-  // device copies: sliced-ELL K, M, A; Jacobi diagonal of A; body-force vector
-  int rc;
-  if ((rc = to_device_sell(c, L.hK, &L.d_K)) || (rc = to_device_sell(c, L.hM, &L.d_M)) ||
-      (rc = to_device_sell(c, L.hA, &L.d_A)))
-    return rc;
+  // Jacobi diagonal of A
   HIPCHK(c, hipMalloc((void **)&L.d_dinvA, size_t(c->n) * sizeof(double)));
   mi::launch_extract_dinv(c->dim, L.d_A, c->d_diagpos, L.d_dinvA, m.nnodes, c->stream);
   HIPCHK(c, hipGetLastError());
-  if (L.body_force_enabled)
-    {
-      HIPCHK(c, hipMalloc((void **)&L.d_body, size_t(c->n) * sizeof(double)));
-      HIPCHK(c, hipMemcpy(L.d_body, body.data(), body.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
   HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double), c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return MI_OK;
@@ -469,10 +350,14 @@ int mi_linear_matrix_get_csr(mi_ctx *c, int which, int64_t *rowptr, int32_t *col
     return fail(c, MI_EINVAL, "linear model not set up or bad matrix id");
   if (team_size(c) != 1)
     return fail(c, MI_EINVAL, "matrix export is only available on an undecomposed mesh");
-  const std::vector<double> &bv = which == 0 ? c->linear->hK : which == 1 ? c->linear->hM : c->linear->hA;
-  const int                  D = c->dim, DD = D * D;
-  const mi::HostMesh        &m = c->mesh;
-  int64_t                    k = 0;
+  const int           D = c->dim, DD = D * D;
+  const mi::HostMesh &m = c->mesh;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<double> bv(size_t(m.nvalblocks()) * DD);
+  HIPCHK(c, hipMemcpy(bv.data(), which == 0 ? c->linear->d_K : which == 1 ? c->linear->d_M : c->linear->d_A,
+                      bv.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int64_t k = 0;
   for (int64_t nd = 0; nd < m.nnodes; ++nd)
     for (int i = 0; i < D; ++i)
       {
@@ -481,7 +366,7 @@ int mi_linear_matrix_get_csr(mi_ctx *c, int which, int64_t *rowptr, int32_t *col
           for (int j = 0; j < D; ++j)
             {
               col[k] = m.colidx[size_t(b)] * D + j;
-              val[k] = bv[size_t(b) * DD + i * D + j];
+              val[k] = bv[size_t(m.valpos(nd, int(b - m.rowptr[size_t(nd)]))) * DD + i * D + j];
               ++k;
             }
       }
