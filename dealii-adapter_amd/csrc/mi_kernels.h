@@ -173,6 +173,7 @@ namespace mi
     const int32_t *rstart[3]; // restrict: per coarse index, range into ri/rw
     const int32_t *ri[3];
     const double  *rw[3];
+    int32_t        rmax;      // restrict: longest list of any coarse index in any direction (<= 4: the unrolled kernel)
   };
 
   struct LinearParams

@@ -1706,43 +1706,85 @@ namespace mi
     constexpr int DD = D * D;
     if (node < 0)
       return;
-    double res[D];
     if constexpr (CHEB)
       {
+        // every operand first, then the arithmetic, then the stores: interleaved with the stores (d, x' may alias the
+        // operands as far as the compiler knows) the loads of component i+1 waited for the stores of component i --
+        // three memory round trips instead of one on levels where a launch is nothing but round trips
+        double res[D], dinv[DD], dold[D], xold[D];
 #pragma unroll
         for (int i = 0; i < D; ++i)
-          res[i] = prm.cheb_b[int64_t(node) * D + i] - acc[i];
-      }
+          res[i] = prm.cheb_b[int64_t(node) * D + i];
+        if (prm.cheb_d)
+          {
+            if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
+              {
 #pragma unroll
-    for (int i = 0; i < D; ++i)
-      {
-        const int64_t idx = int64_t(node) * D + i;
-        if constexpr (CHEB)
+                for (int k = 0; k < DD; ++k)
+                  dinv[k] = prm.cheb_dinv[int64_t(node) * DD + k];
+              }
+            else
+              {
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+                  dinv[i] = prm.cheb_dinv[int64_t(node) * D + i];
+              }
+            // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a solve that
+            // broke down)
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+              {
+                dold[i] = prm.cheb_c1 != 0.0 ? prm.cheb_d[int64_t(node) * D + i] : 0.0;
+                xold[i] = prm.x[int64_t(node) * D + i];
+              }
+          }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          res[i] -= acc[i];
+        double out0[D], out1[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
           {
             if (prm.cheb_d)
               {
-                double s = prm.cheb_dinv[idx] * res[i];
-                if (prm.cheb_blk) // block-Jacobi: D^-1 is a DxD block per node
+                double s = dinv[i] * res[i];
+                if (prm.cheb_blk)
                   {
                     s = 0.0;
 #pragma unroll
                     for (int j = 0; j < D; ++j)
-                      s += prm.cheb_dinv[int64_t(node) * DD + i * D + j] * res[j];
+                      s += dinv[i * D + j] * res[j];
                   }
-                // c1 == 0 on the first step: the old d is not read (it may hold anything, e.g. the NaNs of a
-                // solve that broke down)
-                const double dn    = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * prm.cheb_d[idx] : 0.0) + prm.cheb_c2 * s;
-                prm.cheb_d[idx]    = dn;
-                prm.cheb_xout[idx] = prm.x[idx] + dn;
+                const double dn = (prm.cheb_c1 != 0.0 ? prm.cheb_c1 * dold[i] : 0.0) + prm.cheb_c2 * s;
+                out0[i]         = dn;
+                out1[i]         = xold[i] + dn;
               }
             else
-              prm.y[idx] = res[i]; // residual mode: y = b - K x
+              out0[i] = res[i]; // residual mode: y = b - K x
           }
-        else
-          prm.y[idx] = acc[i];
-        if (DOT && node >= prm.own_begin && node < prm.own_end)
-          dsum += acc[i] * prm.dotv[idx];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          {
+            const int64_t idx = int64_t(node) * D + i;
+            if (prm.cheb_d)
+              {
+                prm.cheb_d[idx]    = out0[i];
+                prm.cheb_xout[idx] = out1[i];
+              }
+            else
+              prm.y[idx] = out0[i];
+          }
       }
+    else
+      {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+          prm.y[int64_t(node) * D + i] = acc[i];
+      }
+    if (DOT && node >= prm.own_begin && node < prm.own_end)
+#pragma unroll
+      for (int i = 0; i < D; ++i)
+        dsum += acc[i] * prm.dotv[int64_t(node) * D + i];
   }
 
   // ------------------------------------------------------------------ the same product for SMALL launches (k-split)
@@ -2789,6 +2831,61 @@ namespace mi
 #pragma unroll
     for (int c = 0; c < D; ++c)
       coarse[I * D + c] = ((m >> c) & 1) ? 0.0 : acc[c];
+  }
+
+  // the same sums (same order, same bits) with the lists in registers first: one thread per DOF, every list at most
+  // MAXR long (factor-2 coarsening: 3, 4 where the lattices are not nested), so the table entries are loaded once and
+  // the up to MAXR^D fine values are independent loads -- three memory round trips deep instead of one per term
+  // (the small levels of a V-cycle are latency, not bandwidth: 20 -> 6 us on the 31^3 level)
+  template <int D, int MAXR>
+  __global__ __launch_bounds__(256) void lattice_restrict_unrolled(LatticeParams p, double *coarse, const double *__restrict__ fine,
+                                                                   const uint8_t *__restrict__ cmask_coarse)
+  {
+    const int64_t g = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (g >= p.n_tgt * D)
+      return;
+    const int64_t I = g / D;
+    const int     c = int(g - I * D);
+    const int     ci[3] = {int(I % p.nt[0]), int((I / p.nt[0]) % p.nt[1]), int(I / (int64_t(p.nt[0]) * p.nt[1]))};
+    int           cnt[3] = {1, 1, 1}, fi[3][MAXR];
+    double        fw[3][MAXR];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int k = 0; k < MAXR; ++k)
+        {
+          fi[d][k] = 0;
+          fw[d][k] = (d >= D && k == 0) ? 1.0 : 0.0;
+        }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      {
+        const int b = p.rstart[d][ci[d]];
+        cnt[d]      = p.rstart[d][ci[d] + 1] - b;
+#pragma unroll
+        for (int k = 0; k < MAXR; ++k)
+          if (k < cnt[d])
+            {
+              fi[d][k] = p.ri[d][b + k];
+              fw[d][k] = p.rw[d][b + k];
+            }
+      }
+    double acc = 0.0;
+#pragma unroll
+    for (int kz = 0; kz < (D == 3 ? MAXR : 1); ++kz)
+#pragma unroll
+      for (int ky = 0; ky < MAXR; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < MAXR; ++kx)
+          if (kx < cnt[0] && ky < cnt[1] && kz < cnt[2])
+            {
+              const double  wz = (D == 3) ? fw[2][kz] : 1.0;
+              const double  wt = fw[0][kx] * (fw[1][ky] * wz);
+              const int64_t f  = fi[0][kx] + int64_t(p.ns[0]) * (fi[1][ky] + int64_t(p.ns[1]) * (D == 3 ? fi[2][kz] : 0));
+              acc += wt * fine[f * D + c];
+            }
+    const int m = cmask_coarse ? cmask_coarse[I] : 0;
+    coarse[g]   = ((m >> c) & 1) ? 0.0 : acc;
   }
 
   // r = b - q (q = A x0), partials of ||r||^2, r.dinv.r and ||b||^2
@@ -4031,7 +4128,15 @@ namespace mi
                                const uint8_t *cmask_coarse, hipStream_t s)
   {
     const int grid = int((p.n_tgt + 255) / 256);
-    if (dim == 3)
+    if (p.rmax >= 1 && p.rmax <= 4 && p.n_tgt <= 100000) // (above, the loop form is the faster one: 26 against 30 us at 216 k nodes)
+      {
+        const int gu = int((p.n_tgt * dim + 255) / 256);
+        if (dim == 3)
+          hipLaunchKernelGGL((lattice_restrict_unrolled<3, 4>), dim3(gu), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
+        else
+          hipLaunchKernelGGL((lattice_restrict_unrolled<2, 4>), dim3(gu), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
+      }
+    else if (dim == 3)
       hipLaunchKernelGGL((lattice_restrict<3>), dim3(grid), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
     else
       hipLaunchKernelGGL((lattice_restrict<2>), dim3(grid), dim3(256), 0, s, p, coarse, fine, cmask_coarse);

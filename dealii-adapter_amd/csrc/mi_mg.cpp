@@ -41,9 +41,14 @@ namespace mi_detail
     double  lmax = 0.0;     // estimate of the largest eigenvalue of D^-1 A
     double *dense_inv = nullptr; // coarsest level, n <= 96: the inverse of the level matrix (exact coarse solve in one launch)
     MgTransfer to_coarse;   // to level l+1
-    double *b() const { return ws; }
-    double *x() const { return ws + (x_swapped ? 6 : 1) * ctx->n; }
-    double *x_other() const { return ws + (x_swapped ? 1 : 6) * ctx->n; }
+    // level 0 works on the CG's own vectors: its right-hand side IS the residual W_R (only owned entries are ever read)
+    // and its first x buffer IS W_Z, so a V-cycle neither copies its input nor (unless an odd number of fused steps
+    // left the result in the second buffer) its output
+    double *b_ext = nullptr, *x_ext = nullptr;
+    double *x_first() const { return x_ext ? x_ext : ws + ctx->n; }
+    double *b() const { return b_ext ? b_ext : ws; }
+    double *x() const { return x_swapped ? ws + 6 * ctx->n : x_first(); }
+    double *x_other() const { return x_swapped ? x_first() : ws + 6 * ctx->n; }
     double *d() const { return ws + 2 * ctx->n; }
     double *q() const { return ws + 3 * ctx->n; }
     double *ev() const { return ws + 4 * ctx->n; }
@@ -181,6 +186,7 @@ namespace mi_detail
           std::vector<double>  rw;
           for (const auto &l : lists)
             {
+              t.restrict_.rmax = std::max(t.restrict_.rmax, int32_t(l.size()));
               for (const auto &e : l)
                 {
                   ri.push_back(e.first);
@@ -820,14 +826,16 @@ namespace mi_detail
     for (mi_ctx *m : T.members)
       {
         MgLevel &L0 = m->mg->levels[0];
-        mi::launch_copy_owned(L0.b(), m->work(W_R), m->n, m->own0, m->own_n, m->stream);
+        L0.b_ext    = m->work(W_R);
+        L0.x_ext    = m->work(W_Z);
       }
     int rc = vcycle(T, 0);
     if (rc)
       return rc;
     for (mi_ctx *m : T.members)
-      HIPCHK(m, hipMemcpyAsync(m->work(W_Z), m->mg->levels[0].x(), size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
-                               m->stream));
+      if (m->mg->levels[0].x() != m->work(W_Z))
+        HIPCHK(m, hipMemcpyAsync(m->work(W_Z), m->mg->levels[0].x(), size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
+                                 m->stream));
     HIPCHK(T.members[0], hipGetLastError());
     return MI_OK;
   }
