@@ -360,7 +360,8 @@ def main():
             elapsed = float(t.item())
         lin_its_last = [int(info.lin_its[i]) for i in range(min(info.newton_iterations, 16))]
         cnt = {k: G.get_tuning("count_" + k) for k in ("scalar_allreduce", "vector_allreduce", "halo_exchange", "cg_host_sync",
-                                                        "cg_iterations", "cg_solves")}
+                                                        "cg_iterations", "cg_solves", "mg_refresh")}
+        cnt["mg_refresh_every"] = G.get_tuning("mg_refresh_every")
         r = {"G": G, "elapsed": elapsed, "lin_its_last": lin_its_last, "counts": cnt, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
              "tm": G.timings(), "comm": G.comm_info()}
         return r
@@ -420,6 +421,10 @@ def main():
                     "vector_allreduce": R["counts"]["vector_allreduce"] / max(R["counts"]["cg_iterations"], 1),
                     "halo_exchange": R["counts"]["halo_exchange"] / max(R["counts"]["cg_iterations"], 1)},
                 "host_syncs_per_solve": R["counts"]["cg_host_sync"] / max(R["counts"]["cg_solves"], 1),
+                # the multigrid preconditioner's coarse operators (levels >= 1) are kept over time steps: rebuilt at every
+                # k-th step, or earlier when a solve needs a quarter more iterations than the first one after a rebuild
+                "coarse_operator_refresh": {"every_steps": R["counts"]["mg_refresh_every"],
+                                            "refreshes_in_timed_steps": R["counts"]["mg_refresh"]},
                 "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
                 "ms_cg_per_step": tm["cg_total"][0] / args.steps,
                 "ms_sell_copy_per_step": tm["sell_copy"][0] / args.steps,

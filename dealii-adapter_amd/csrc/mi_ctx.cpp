@@ -749,7 +749,12 @@ namespace mi_detail
             if ((rc = mg_update(T)))
               return rc;
             for (mi_ctx *m : T.members)
-              m->mg_force = false;
+              {
+                m->mg_force                = false;
+                m->mg_steps_since_refresh = 0;
+                m->mg_its_ref             = 0;
+              }
+            ++c0->n_mg_refresh;
           }
         for (size_t k = 0; k < R; ++k)
           cgs[k].z = T.members[k]->work(W_Z) + T.members[k]->own0;
@@ -1326,6 +1331,8 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     for (mi_ctx *m : T->members)
       {
         m->precond = precond;
+        if (const char *e = getenv("MI_MG_REFRESH_EVERY"))
+          m->mg_refresh_every = std::max(1, atoi(e));
         if (precond == 1)
           {
             const int rc = mg_setup(m);
@@ -1537,7 +1544,11 @@ int mi_newton_begin_step(mi_ctx *c)
     {
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_SOLUTION_DELTA), 0, size_t(m->n) * sizeof(double), m->stream));
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
-      m->mg_force = true; // new time step: refresh the coarse operators at its first solve
+      // new time step: refresh the coarse operators at its first solve ("mg_refresh_every" k: at every k-th step)
+      if (m->mg_steps_since_refresh + 1 >= m->mg_refresh_every)
+        m->mg_force = true;
+      else
+        ++m->mg_steps_since_refresh;
     }
   c->team->members[0]->newton_update_is_zero = true;
   return MI_OK;
@@ -1633,6 +1644,16 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   // a breakdown (NaN state, indefinite tangent) is final, as with deal.II's SolverControl: no second attempt from a
   // poisoned iterate
   bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
+  if (mg && rc == MI_OK)
+    {
+      // coarse operators kept over several time steps ("mg_refresh_every"): the first solve after a refresh sets the
+      // mark, a later solve that needs a quarter (at least 2) more iterations asks for a refresh before the next one
+      if (c0->mg_its_ref == 0)
+        c0->mg_its_ref = my_its;
+      else if (my_its > c0->mg_its_ref + std::max(2, c0->mg_its_ref / 4))
+        for (mi_ctx *m : c->team->members)
+          m->mg_force = true;
+    }
   if (rc == MI_ENOCONV_LIN && mg && !broke && my_its < max_it)
     {
       // first suspect: a smoother interval that ends below lambda_max (its modes are amplified).  Estimate the
@@ -2096,6 +2117,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         c->team->overlap = value;
       else if (k == "asm_variant" && value >= 0 && value <= 9)
         m->asm_variant = value;
+      else if (k == "mg_refresh_every" && value >= 1 && value <= 1000)
+        m->mg_refresh_every = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
         m->mg_lag = value;
       else if (k == "cg_fused_dot" && (value == 0 || value == 1))
@@ -2164,6 +2187,10 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = int(c->team->n_cg_sync);
   else if (k == "count_cg_iterations")
     *value = int(c->team->n_cg_its);
+  else if (k == "count_mg_refresh")
+    *value = int(c->team->members[0]->n_mg_refresh);
+  else if (k == "mg_refresh_every")
+    *value = c->mg_refresh_every;
   else if (k == "count_cg_solves")
     *value = int(c->team->n_cg_solves);
   else
@@ -2181,6 +2208,7 @@ int mi_reset_timings(mi_ctx *c)
   int rc = sync(c);
   Team &T = *c->team;
   T.n_scalar_allreduce = T.n_vector_allreduce = T.n_halo = T.n_cg_sync = T.n_cg_its = T.n_cg_solves = 0;
+  T.members[0]->n_mg_refresh = 0;
   std::memset(&c->team->members[0]->timings, 0, sizeof(mi_timings));
   return rc;
 }

@@ -180,6 +180,10 @@ struct mi_ctx
   bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
   int                   asm_variant = 0;
   int                   mg_lag   = 1;    // 1: keep the coarse operators over the Newton iterations of one step
+  // ... and over time steps: refreshed at the first solve of every k-th step, or before the next solve when one
+  // needed a quarter (at least 2) more iterations than the first solve after the last refresh (mg_its_ref)
+  int                   mg_refresh_every = 8, mg_steps_since_refresh = 0, mg_its_ref = 0;
+  int64_t               n_mg_refresh = 0;
 
   double *vec(int which) { return d_vecs + size_t(which) * size_t(n); }
   double *work(int which) { return d_work + size_t(which) * size_t(n); }

@@ -252,7 +252,10 @@ typedef struct
 int mi_set_profiling(mi_ctx *ctx, int enable);
 /* run-time switches (A/B timing, tests): "spmv_variant" 3 sliced-ELL (default), 1 block-CSR; "spmv_grid" workgroups;
  * "sell_unroll" 1..4; "xcd_remap" 0/1; "precond" 1 multigrid V-cycle (default), 0 Jacobi; "mg_lag" 1 coarse
- * operators kept over the Newton iterations of a step (default), 0 rebuilt after every assembly; "asm_variant"
+ * operators kept over the Newton iterations of a step (default), 0 rebuilt after every assembly; "mg_refresh_every" k
+ * (default 8, 1..1000): with "mg_lag" 1 the coarse operators (levels >= 1 of the preconditioner; the fine-level
+ * smoother always works on the current tangent) are rebuilt at the first solve of every k-th time step, or before
+ * the next solve when one needed a quarter (at least 2) more iterations than the first solve after the last rebuild; "asm_variant"
  * element-kernel ablations; "halo_overlap" 1 ghost-plane exchange on the communication stream next to the interior
  * rows of the SpMV (default), 0 in line on the compute stream; "precond_storage" 64 (default) | 32: the multigrid
  * smoother multiplies with an fp32-rounded copy of the level matrices (arithmetic, the CG's own product and its
@@ -268,7 +271,8 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 /* counters since the last mi_reset_timings (what a solve costs in latency-bound events; counted on one slab as well,
  * where the collectives themselves are no-ops): "count_scalar_allreduce", "count_vector_allreduce",
- * "count_halo_exchange", "count_cg_host_sync", "count_cg_iterations", "count_cg_solves" */
+ * "count_halo_exchange", "count_cg_host_sync", "count_cg_iterations", "count_cg_solves", "count_mg_refresh" (rebuilds of
+ * the multigrid preconditioner's coarse operators) */
 /* read back: "smoother_operator_active" (2 / 1: the smoother's fine-level products are matrix-free / use the stored
  * element tangents, 0: the assembled matrix), "precond",
  * "spmv_variant" */

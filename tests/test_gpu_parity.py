@@ -293,6 +293,41 @@ def test_stalled_multigrid_solve_heals_itself():
     assert rc == 0 and abs(its - its_ok) <= 2
 
 
+def test_coarse_operators_are_kept_over_time_steps_and_refreshed_on_demand():
+    """"mg_refresh_every": the preconditioner's coarse operators (levels >= 1) are rebuilt at every k-th time step --
+    same solutions at a tight tolerance whatever k -- and earlier when a solve needs a quarter more iterations than
+    the first solve after the last rebuild (here: after the eigenvalue estimates were spoiled)"""
+    def run(every, spoil_at=None):
+        G = M.Context(dim=3, degree=2, reps=(16, 16, 16))  # 107,811 dofs: multigrid is the default
+        assert G.get_tuning("precond") == 1 and G.get_tuning("mg_refresh_every") == 8
+        G.set_tuning("mg_refresh_every", every)
+        G.reset_timings()
+        its, refreshes = [], []
+        for k in range(4):
+            if k == spoil_at:
+                G.set_tuning("mg_scale_lmax_percent", 60)
+            G.set_interface_traction((0.0, -2e3 * (k + 1), 0.0))
+            rc, info = G.newmark_step(tol_lin=1e-10, max_it_mult=1.0)
+            assert rc == 0 and info.converged == 1
+            its.append([int(info.lin_its[i]) for i in range(info.newton_iterations)])
+            refreshes.append(G.get_tuning("count_mg_refresh"))
+        u = G.get(M.V_U)
+        G.close()
+        return its, refreshes, u
+
+    its1, r1, u1 = run(1)
+    assert r1 == [1, 2, 3, 4]
+    its2, r2, u2 = run(2)
+    assert r2 == [1, 1, 2, 2] and _relmax(u2, u1) < 1e-8
+    itsn, rn, un = run(1000)
+    assert rn == [1, 1, 1, 1] and _relmax(un, u1) < 1e-8
+    assert max(max(s) for s in itsn) <= max(max(s) for s in its1) + 2  # (the lagged operators precondition as well)
+    itss, rs, us = run(1000, spoil_at=2)
+    assert rs[1] == 1 and rs[2] == 2, (rs, itss)  # the slow solve of step 3 asked for the rebuild, in that step
+    assert max(itss[2]) > max(itsn[2]) + 2 and max(itss[3]) <= max(itsn[3]) + 2, (itss, itsn)
+    assert _relmax(us, u1) < 1e-8
+
+
 def test_smoother_operator_choice_only_changes_the_preconditioner():
     """multigrid-PCG with the smoother on the element tangents vs on the assembled matrix: the same operator up to
     rounding, so the same iteration counts and the same converged solution"""
