@@ -249,10 +249,12 @@ def main():
     ap.add_argument("--cg-operator", choices=["assembled", "element"], default="assembled",
                     help="A/B: the CG's own product on the assembled sliced-ELL matrix (default; the kernel the north star names) or "
                          "on the unassembled element tangents like the smoother's (then no sliced-ELL copy is made)")
-    ap.add_argument("--cg-start", choices=["zero", "previous-update"], default="zero",
-                    help="start vector of the 2nd, 3rd ... linear solve of a step: zero (default) or the previous Newton update, "
-                         "as the reference's loop has it (nonlinear_elasticity.cc:419,472: costs 6 more CG iterations per step); "
-                         "the N = 1 line reports the other choice as a second measurement")
+    ap.add_argument("--cg-start", choices=["zero", "previous-update", "previous-step", "extrapolated"], default="previous-step",
+                    help="start vector of the linear solves: previous-step (default, what the executable sets: the j-th solve of "
+                         "a step starts from the solution of the j-th solve of the previous step), extrapolated (the same over "
+                         "two steps), zero, or previous-update as the reference's loop has it (nonlinear_elasticity.cc:419,472: "
+                         "the previous Newton update of the step); the stopping rule is the same; the N = 1 line reports the "
+                         "other choices as further measurements")
     ap.add_argument("--slabs", type=int, default=1, help="diagnostic: cut the mesh into this many slabs on ONE GPU")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="N GPUs: strong = the one cells^3 block (BASELINE configuration 4) is cut into N parts (default); "
@@ -326,7 +328,7 @@ def main():
                       rho=1000.0, beta=0.25, gamma=0.5, delta_t=0.005, device=device, rank=None if replicas else rank,
                       world=1 if replicas else world, unique_id=uid_, slabs=args.slabs if (world == 1 or replicas) else 1)
         G.set_tuning("smoother_operator", {"matrix-free": 2, "element": 1, "assembled": 0}[args.smoother_operator])
-        G.set_tuning("cg_warm_start", 1 if (cg_start or args.cg_start) == "previous-update" else 0)
+        G.set_tuning("cg_warm_start", {"zero": 0, "previous-update": 1, "previous-step": 2, "extrapolated": 3}[cg_start or args.cg_start])
         G.set_tuning("cg_operator", 1 if (cg_operator or args.cg_operator) == "element" else 0)
         if os.environ.get("MI_CG_FUSED_DOT"):
             G.set_tuning("cg_fused_dot", int(os.environ["MI_CG_FUSED_DOT"]))
@@ -410,9 +412,13 @@ def main():
                 "cg_iterations_per_step": R["cg_its"] / args.steps,
                 "assemblies_per_step": R["assemblies"] / args.steps,
                 "cg_iterations_last_step": R["lin_its_last"],
-                "cg_start": "zero for every solve (the reference starts the 2nd, 3rd ... solve of a step from the previous Newton "
-                            "update: same stopping rule, more iterations; --cg-start previous-update)"
-                if args.cg_start == "zero" else "previous Newton update, as in the reference (nonlinear_elasticity.cc:419,472)",
+                "cg_start": {"zero": "zero for every solve (the reference starts the 2nd, 3rd ... solve of a step from the previous "
+                                     "Newton update: same stopping rule, more iterations; --cg-start previous-update)",
+                             "previous-update": "previous Newton update, as in the reference (nonlinear_elasticity.cc:419,472)",
+                             "previous-step": "the j-th solve of a step starts from the solution of the j-th solve of the previous "
+                                              "step (what the executable sets; same stopping rule; with_cg_start_zero and "
+                                              "with_cg_start_previous_update are the runs with the other start vectors)",
+                             "extrapolated": "as previous-step, extrapolated linearly over two steps"}[args.cg_start],
                 # latency-bound events of the linear solves per CG iteration / per solve.  Complete for a decomposed run
                 # (N ranks or --slabs N); on ONE slab the scalar all-reduce sites are still counted (they are no-ops there)
                 # while halo exchanges and the V-cycle's vector all-reduce are skipped before their counters
@@ -591,12 +597,16 @@ def main():
         del W
     if world == 1 and args.slabs == 1:
         # the other start vector, measured beside the headline (3 steps)
-        other = "previous-update" if args.cg_start == "zero" else "zero"
-        S = measure(args.scaling, n, 3, 1, None, cg_start=other)
-        out["config"]["with_cg_start_" + other.replace("-", "_")] = {
-            "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"], "cg_iterations_per_step": S["cg_its"] / 3,
-            "cg_iterations_last_step": S["lin_its_last"], "steps": 3, "warmup": 1}
-        del S
+        # the other start vectors, measured beside the headline (3 steps each): zero for every solve, and the reference's
+        # (the previous Newton update, nonlinear_elasticity.cc:419,472)
+        for other in ("zero", "previous-update", "previous-step"):
+            if other == args.cg_start or (other == "previous-step" and args.cg_start == "extrapolated"):
+                continue
+            S = measure(args.scaling, n, 3, 1, None, cg_start=other)
+            out["config"]["with_cg_start_" + other.replace("-", "_")] = {
+                "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"], "cg_iterations_per_step": S["cg_its"] / 3,
+                "cg_iterations_last_step": S["lin_its_last"], "steps": 3, "warmup": 1}
+            del S
         if args.cg_operator == "assembled" and n >= 24:
             # opt-in A/B beside the headline: the CG's own product on the element tangents too (no sliced-ELL copy);
             # not the default because north_star names the product on the assembled matrix

@@ -964,7 +964,10 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base};
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base,
+                    c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
+                    c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
+                    c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};
     for (void *p : ptrs)
       if (p)
         hipFree(p);
@@ -1118,7 +1121,7 @@ namespace mi_detail
     if (const char *v = getenv("MI_SELL_ICOL"))
       c->sell_icol = atoi(v) != 0;
     if (const char *v = getenv("MI_CG_WARM_START"))
-      c->cg_warm_start = atoi(v) != 0;
+      c->cg_warm_start = std::min(3, std::max(0, atoi(v)));
     if (const char *v = getenv("MI_SMALL_CG"))
       c->small_cg = atoi(v) != 0;
     return MI_OK;
@@ -1551,6 +1554,7 @@ int mi_newton_begin_step(mi_ctx *c)
         ++m->mg_steps_since_refresh;
     }
   c->team->members[0]->newton_update_is_zero = true;
+  c->team->members[0]->solves_this_step      = 0;
   return MI_OK;
 }
 
@@ -1632,9 +1636,23 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
     }
   // SolverCG starts from the passed vector (:1184-1187): whatever MI_V_NEWTON_UPDATE holds (see mi_apply_newton_update);
   // when the library itself has just cleared it, r0 = b needs no product
-  mi_ctx    *c0     = c->team->members[0];
-  const bool x_zero = c0->newton_update_is_zero;
+  mi_ctx *c0     = c->team->members[0];
+  bool    x_zero = c0->newton_update_is_zero;
   c0->newton_update_is_zero = false;
+  // "cg_warm_start" 2 (default) / 3: when the library has just cleared the update, the j-th solve of a time step starts
+  // from the solution of the j-th solve of the previous step (3: extrapolated linearly over the last two) instead of
+  // zero -- the loads of a time-stepping run change little from step to step.  Same stopping rule (:1155-1156, a
+  // residual norm relative to |rhs|); costs one product for r0, saves about one iteration in seven on the headline run.
+  const int  pj   = c0->solves_this_step++;
+  const bool pred = c0->cg_warm_start >= 2 && pj < mi_ctx::NPRED;
+  if (pred && x_zero && c0->pred_count[pj] >= 1)
+    {
+      const bool two = c0->cg_warm_start == 3 && c0->pred_count[pj] >= 2;
+      for (mi_ctx *m : c->team->members)
+        mi::launch_vec_lincomb2(m->vec(MI_V_NEWTON_UPDATE), two ? 2.0 : 1.0, m->d_pred[pj][0], two ? -1.0 : 0.0, m->d_pred[pj][1],
+                                m->n, m->stream);
+      x_zero = false;
+    }
   // A multigrid-preconditioned solve needs 7-15 iterations; one that has not converged after 300 has stalled, and
   // iterating on to max_it (dofs x multiplier, i.e. millions) would be a hang in all but name.
   const bool    mg     = mg_active(c);
@@ -1683,6 +1701,19 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
       if (its)
         *its += done_its;
     }
+  if (pred && rc == MI_OK) // this solution predicts the same solve of the next step
+    {
+      for (mi_ctx *m : c->team->members)
+        {
+          for (int h = 0; h < 2; ++h)
+            if (!m->d_pred[pj][h])
+              HIPCHK(m, hipMalloc((void **)&m->d_pred[pj][h], size_t(m->n) * sizeof(double)));
+          std::swap(m->d_pred[pj][0], m->d_pred[pj][1]);
+          HIPCHK(m, hipMemcpyAsync(m->d_pred[pj][0], m->vec(MI_V_NEWTON_UPDATE), size_t(m->n) * sizeof(double),
+                                   hipMemcpyDeviceToDevice, m->stream));
+        }
+      ++c0->pred_count[pj];
+    }
   return rc;
 }
 
@@ -1722,10 +1753,10 @@ int mi_apply_newton_update(mi_ctx *c, double *upd_norm)
       // solve then has to reduce its residual by as much more: 10-11 instead of 7-8 iterations per solve at 5 M dofs
       // (28 instead of 22 per step).  Unless the reference's start vector is asked for ("cg_warm_start" 1), the
       // consumed update is cleared and the next solve starts from zero; the stopping rule is the same.
-      if (!m->cg_warm_start)
+      if (m->cg_warm_start != 1)
         HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
     }
-  T.members[0]->newton_update_is_zero = !T.members[0]->cg_warm_start;
+  T.members[0]->newton_update_is_zero = T.members[0]->cg_warm_start != 1;
   HIPCHK(c, hipGetLastError());
   if (upd_norm)
     *upd_norm = nrm;
@@ -1837,6 +1868,18 @@ int mi_state_save(mi_ctx *c)
       HIPCHK(m, hipMemcpyAsync(m->d_saved, m->d_vecs, size_t(6) * size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
                                m->stream));
       m->have_saved = true;
+      // the start-vector history of the linear solves belongs to the state: a restored run repeats the saved one
+      for (int j = 0; j < mi_ctx::NPRED; ++j)
+        for (int h = 0; h < 2; ++h)
+          if (m->d_pred[j][h])
+            {
+              if (!m->d_pred_saved[j][h])
+                HIPCHK(m, hipMalloc((void **)&m->d_pred_saved[j][h], size_t(m->n) * sizeof(double)));
+              HIPCHK(m, hipMemcpyAsync(m->d_pred_saved[j][h], m->d_pred[j][h], size_t(m->n) * sizeof(double),
+                                       hipMemcpyDeviceToDevice, m->stream));
+            }
+      for (int j = 0; j < mi_ctx::NPRED; ++j)
+        m->pred_count_saved[j] = c->team->members[0]->pred_count[j];
     }
   return MI_OK;
 }
@@ -1846,8 +1889,17 @@ int mi_state_restore(mi_ctx *c)
     return fail(c, MI_EINVAL, "state_variables are not the same as previously saved.");
   HIPCHK(c, hipSetDevice(c->device));
   for (mi_ctx *m : c->team->members)
-    HIPCHK(m, hipMemcpyAsync(m->d_vecs, m->d_saved, size_t(6) * size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
-                             m->stream));
+    {
+      HIPCHK(m, hipMemcpyAsync(m->d_vecs, m->d_saved, size_t(6) * size_t(m->n) * sizeof(double), hipMemcpyDeviceToDevice,
+                               m->stream));
+      for (int j = 0; j < mi_ctx::NPRED; ++j)
+        for (int h = 0; h < 2; ++h)
+          if (m->d_pred[j][h] && m->d_pred_saved[j][h])
+            HIPCHK(m, hipMemcpyAsync(m->d_pred[j][h], m->d_pred_saved[j][h], size_t(m->n) * sizeof(double),
+                                     hipMemcpyDeviceToDevice, m->stream));
+    }
+  for (int j = 0; j < mi_ctx::NPRED; ++j)
+    c->team->members[0]->pred_count[j] = c->team->members[0]->pred_count_saved[j];
   return MI_OK;
 }
 
@@ -2123,7 +2175,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->mg_lag = value;
       else if (k == "cg_fused_dot" && (value == 0 || value == 1))
         m->cg_fused_dot = value;
-      else if (k == "cg_warm_start" && (value == 0 || value == 1))
+      else if (k == "cg_warm_start" && value >= 0 && value <= 3)
         m->cg_warm_start = value;
       else if (k == "cg_operator" && (value == 0 || value == 1))
         m->cg_operator = value;

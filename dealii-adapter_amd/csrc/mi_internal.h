@@ -121,9 +121,15 @@ struct mi_ctx
   double   *d_cellbox = nullptr; // with d_qrec when every local cell is an axis-parallel box: [ncells][4] = 1/h, volume
   bool      ke_valid = false; // d_ke / d_qrec belong to the current tangent
   int64_t   ebe_products = 0; // element-tangent products so far (profiling samples every 6th)
+  // "cg_warm_start" 2 / 3: the start vector of the j-th linear solve of a time step is the solution of the j-th solve
+  // of the previous step (2) or its linear extrapolation over the last two steps (3); history per slab
+  static constexpr int NPRED = 4;
+  double   *d_pred[NPRED][2] = {}, *d_pred_saved[NPRED][2] = {}; // (saved: mi_state_save / mi_state_restore)
+  int       pred_count[NPRED] = {}, pred_count_saved[NPRED] = {}, solves_this_step = 0;
   int       cg_operator = 0;   // A/B: 1 = the CG's own product on the element tangents too (no sliced-ELL copy); default 0:
                                // the assembled matrix, the kernel north_star names
-  int       cg_warm_start = 0; // 1: later solves of a step start from the previous Newton update, as the reference's do
+  int       cg_warm_start = 0; // 0 (library default): every solve starts from zero, 1: later solves of a step start from the previous Newton
+                               // update, as the reference's do, 2 / 3: from the same solve of the previous time step(s)
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
   int       ebe = 2;          // tuning "smoother_operator": 2 matrix-free from the quadrature-point records, 1 element
                               // tangents (both where available), 0 assembled matrix

@@ -2717,6 +2717,14 @@ namespace mi
     if (i < n)
       res[i] = b[i] - q[i];
   }
+  // x = a h1 + b h2 (start vector of a linear solve predicted from the solutions of the previous time steps)
+  __global__ __launch_bounds__(256) void vec_lincomb2(double *x, double a, const double *__restrict__ h1, double b,
+                                                      const double *__restrict__ h2, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n)
+      x[i] = b != 0.0 ? a * h1[i] + b * h2[i] : a * h1[i];
+  }
   // y = mask(x): copy the dofs inside [own0, own0+own_n), zero elsewhere (right-hand side of the V-cycle)
   __global__ __launch_bounds__(256) void copy_owned(double *y, const double *__restrict__ x, int64_t n, int64_t own0,
                                                     int64_t own_n)
@@ -4100,6 +4108,10 @@ namespace mi
   void launch_vec_residual(double *res, const double *b, const double *q, int64_t n, hipStream_t s)
   {
     hipLaunchKernelGGL(vec_residual, dim3(int((n + 255) / 256)), dim3(256), 0, s, res, b, q, n);
+  }
+  void launch_vec_lincomb2(double *x, double a, const double *h1, double b, const double *h2, int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(vec_lincomb2, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, a, h1, b, h2, n);
   }
   void launch_copy_owned(double *y, const double *x, int64_t n, int64_t own0, int64_t own_n, hipStream_t s)
   {

@@ -189,6 +189,11 @@ namespace Nonlinear_Elasticity
     device = std::make_unique<mi::Device>(mesh_desc, mat, nm, dev_id);
     if (std::getenv("MI_PROFILE"))
       mi_set_profiling(device->ctx(), 1);
+    // a time-stepping run: the j-th linear solve of a step starts from the solution of the j-th solve of the previous
+    // step (the reference starts from its previous Newton update, :419 / :472 -- the same stopping rule either way,
+    // fewer iterations this way); MI_CG_WARM_START=0|1 selects zero / the reference's start vector instead
+    if (!std::getenv("MI_CG_WARM_START"))
+      device->check(mi_set_tuning(device->ctx(), "cg_warm_start", 2), "mi_set_tuning");
 
     std::cout << "Triangulation:"
               << "\n\t Number of active cells: " << mi_n_cells(device->ctx())

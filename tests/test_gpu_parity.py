@@ -541,6 +541,39 @@ def test_newton_table_values_follow_reference_logic():
     assert rc == M.MI_ENOCONV_NR
 
 
+def test_start_vector_from_the_previous_time_step():
+    """"cg_warm_start" 2 (what the executable and bench.py set): the j-th linear solve of a step starts from the solution
+    of the j-th solve of the previous step -- same stopping rule, same Newton table, same states as the zero start to
+    the solver tolerance, fewer iterations under a smoothly changing load; 3: extrapolated over two steps.  The history
+    is part of mi_state_save / mi_state_restore: a restored run repeats the saved one bit by bit"""
+    runs = {}
+    for mode in (0, 2, 3):
+        _, G = _pair(3, 2, (4, 3, 2))
+        G.set_tuning("precond", 0)
+        G.set_tuning("cg_warm_start", mode)
+        its, table = [], []
+        for k in range(6):
+            G.set_interface_traction((0.0, -300.0 * (k + 1), 0.0))
+            rc, info = G.newmark_step(tol_lin=1e-10)
+            assert rc == 0 and info.converged == 1
+            its.append(info.lin_its_total)
+            table.append((info.newton_iterations, info.assemblies))
+        runs[mode] = (its, table, G.get(M.V_U), G.get(M.V_A), G)
+    for mode in (2, 3):
+        assert runs[mode][1] == runs[0][1]
+        assert runs[mode][0][0] == runs[0][0][0]  # no history in the first step
+        assert sum(runs[mode][0][1:]) < sum(runs[0][0][1:]), (runs[mode][0], runs[0][0])
+        assert _relmax(runs[mode][2], runs[0][2]) < 1e-8 and _relmax(runs[mode][3], runs[0][3]) < 1e-6
+    G = runs[2][4]
+    G.state_save()
+    G.set_interface_traction((0.0, -2500.0, 0.0))
+    G.newmark_step(tol_lin=1e-10)
+    first = G.get(M.V_U)
+    G.state_restore()
+    G.newmark_step(tol_lin=1e-10)
+    assert np.array_equal(G.get(M.V_U), first)
+
+
 def test_state_checkpoint_roundtrip():
     """implicit-coupling checkpoint (adapter.h:447-489): save, advance, restore, advance again -> same result"""
     _, G = _pair(2, 2, (6, 2))
