@@ -596,7 +596,6 @@ def main():
                                    "cg_iterations_per_step": W["cg_its"] / args.steps}
         del W
     if world == 1 and args.slabs == 1:
-        # the other start vector, measured beside the headline (3 steps)
         # the other start vectors, measured beside the headline (3 steps each): zero for every solve, and the reference's
         # (the previous Newton update, nonlinear_elasticity.cc:419,472)
         for other in ("zero", "previous-update", "previous-step"):

@@ -89,12 +89,14 @@ def test_team_cg_matches_undecomposed(dim, p, reps, slabs):
     assert np.all(G.get(M.V_NEWTON)[P.constrained] == 0)
 
 
-@pytest.mark.parametrize("slabs,precond", [(2, 1), (3, 0), (5, 1)])
-def test_team_newmark_steps_interface_displacement(slabs, precond):
-    """interface displacements for 1 vs N slabs equal to CG tolerance; here against the oracle"""
+@pytest.mark.parametrize("slabs,precond,start", [(2, 1, 2), (3, 0, 0), (5, 1, 0), (3, 0, 2)])
+def test_team_newmark_steps_interface_displacement(slabs, precond, start):
+    """interface displacements for 1 vs N slabs equal to CG tolerance; here against the oracle.
+    start = 2: the solves start from the same solve of the previous step (what the executable sets), history per slab"""
     dim, p, reps = 3, 2, (3, 2, 5)
     P, G = _setup(dim, p, reps, slabs, perturb_amp=0.0)
     G.set_tuning("precond", precond)  # the default at this size is Jacobi
+    G.set_tuning("cg_warm_start", start)
     ids, _ = G.interface()
     for step in range(1, 4):
         t = (0.0, -2e3 * step / 3.0, 0.0)
