@@ -352,7 +352,10 @@ namespace mi_detail
             const int t = sample ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
             mi::launch_mf_spmv(f, 0, int32_t(c->mesh.ncells), c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
                                t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
-            if (cheb) // the smoother's update / residual on the owned nodes, straight from the slots
+            if (cheb && cheb->xnext) // the smoother's step on the owned nodes, straight from the slots (three-term form)
+              mi::launch_mf_gather_cheb3(f, cheb->b, cheb->dinv6, cheb->xprev, x, cheb->xnext, cheb->c1, cheb->c2, c->own0 / 3,
+                                         c->own_n / 3, c->stream);
+            else if (cheb) // ... with the update vector d, in place / the residual
               mi::launch_mf_gather_cheb(f, cheb->b, cheb->dinv, cheb->d, const_cast<double *>(x), y, cheb->c1, cheb->c2,
                                         c->own0 / 3, c->own_n / 3, c->stream);
             else
@@ -595,7 +598,9 @@ namespace mi_detail
       {
         if (!c->d_dinv_blk)
           HIPCHK(c, hipMalloc((void **)&c->d_dinv_blk, size_t(c->mesh.nnodes) * c->dim * c->dim * sizeof(double)));
-        mi::launch_extract_dinv_blk(c->dim, c->d_vals, c->d_diagpos, c->d_dinv_blk, c->mesh.nnodes, c->stream);
+        if (!c->d_dinv_sym6 && c->dim == 3)
+          HIPCHK(c, hipMalloc((void **)&c->d_dinv_sym6, size_t(c->mesh.nnodes) * 6 * sizeof(double)));
+        mi::launch_extract_dinv_blk(c->dim, c->d_vals, c->d_diagpos, c->d_dinv_blk, c->d_dinv_sym6, c->mesh.nnodes, c->stream);
       }
     c->vals32_stale = true; // the opt-in fp32 copy is refreshed by the first product that needs it (enqueue_spmv)
     HIPCHK(c, hipGetLastError());
@@ -964,7 +969,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base,
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base,
                     c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
                     c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
                     c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};

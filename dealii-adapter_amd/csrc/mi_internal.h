@@ -44,6 +44,10 @@ namespace mi_detail
     int           blk = 0; // dinv = DxD blocks per node
     int           inplace = 0; // matrix-free single-launch product only: the gather applies the step itself, x += d in
                                // place (the product is complete by then); d == null: y = b - K x
+    // ... in three-term form (mf_gather_cheb3): x'' = x' + c1 (x' - xprev) + c2 D^-1 (b - K x') written to xnext (may be
+    // xprev's buffer; xprev == null: zero), D^-1 from its symmetric half
+    const double *dinv6 = nullptr, *xprev = nullptr;
+    double       *xnext = nullptr;
   };
   struct LinearModel; // mi_linear.cpp
   struct Multigrid;   // mi_mg.cpp
@@ -110,6 +114,7 @@ struct mi_ctx
   int64_t  *d_sell_off = nullptr;
   // d_vals IS the sliced-ELL matrix (slice-interleaved block rows): the element scatter writes what the SpMV reads
   double   *d_dinv_blk = nullptr; // inverse diagonal blocks (block-Jacobi smoother), allocated when it is switched on
+  double   *d_dinv_sym6 = nullptr; // 3D: their symmetric halves [nnodes][6] (xx yy zz xy xz yz) for the matrix-free smoother step
   bool      want_dinv_blk = false;
   double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
   uint32_t *d_node_first = nullptr; // per cell: bit a = first touch of local node a (see HostMesh::node_first)

@@ -201,6 +201,8 @@ namespace mi
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);
   // gather fused with the smoother's Chebyshev step (d != null: x += d in place) or residual (d == null: yres = b - K x)
+  void launch_mf_gather_cheb3(const MfParams &p, const double *b, const double *dinv6, const double *xprev, const double *xcur,
+                              double *xnext, double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);
   void launch_mf_gather_cheb(const MfParams &p, const double *b, const double *dinv, double *d, double *xio, double *yres,
                              double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);
   // coarsest multigrid level: dense inverse of the level's sliced-ELL matrix (n <= 96, -1 otherwise) and its application
@@ -222,7 +224,7 @@ namespace mi
                           double s0, int64_t n, hipStream_t s);
   void launch_cheb4_step(double *x, double *d, double *r, const double *q, const double *dinv, double beta, double ca,
                          double cb, int64_t n, hipStream_t s);
-  void launch_extract_dinv_blk(int dim, const double *vals, const int32_t *diagpos, double *dinv, int64_t nnodes,
+  void launch_extract_dinv_blk(int dim, const double *vals, const int32_t *diagpos, double *dinv, double *sym6, int64_t nnodes,
                                hipStream_t s);
   void launch_blk_apply(int dim, double *out, const double *a, const double *dinv, int64_t nnodes, hipStream_t s);
   void launch_cheb_step_blk(int dim, double *x, double *d, const double *b, const double *q, const double *dinv,

@@ -64,6 +64,7 @@ namespace mi_detail
     int    fuse          = 1;    // Chebyshev update / residual in the epilogue of the product (one launch instead of two):
                                  // 0 never, 1 on the latency-bound levels (<= fuse_max_nodes), 2 on every level
     int64_t fuse_max_nodes = 100000;
+    int    three_term    = 1;    // level 0, matrix-free smoother: the Chebyshev step in three-term form (MI_MG_THREE_TERM=0: with d)
     int    block         = 1;    // 1: block-Jacobi diagonal (DxD node blocks) inside the Chebyshev smoother, 0: point Jacobi
     int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
@@ -414,6 +415,8 @@ namespace mi_detail
       mg->fuse = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("MI_MG_FUSE_MAX_NODES"))
       mg->fuse_max_nodes = std::max(0, atoi(e));
+    if (const char *e = getenv("MI_MG_THREE_TERM"))
+      mg->three_term = atoi(e) != 0;
     if (const char *e = getenv("MI_MG_BLOCK"))
       mg->block = atoi(e) != 0;
     if (const char *e = getenv("MI_MG_KIND"))
@@ -530,7 +533,9 @@ namespace mi_detail
       if (m->mg->block && !m->d_dinv_blk) // switched on after the fine tangent was assembled
         {
           HIPCHK(m, hipMalloc((void **)&m->d_dinv_blk, size_t(m->mesh.nnodes) * m->dim * m->dim * sizeof(double)));
-          mi::launch_extract_dinv_blk(m->dim, m->d_vals, m->d_diagpos, m->d_dinv_blk, m->mesh.nnodes, m->stream);
+          if (!m->d_dinv_sym6 && m->dim == 3)
+            HIPCHK(m, hipMalloc((void **)&m->d_dinv_sym6, size_t(m->mesh.nnodes) * 6 * sizeof(double)));
+          mi::launch_extract_dinv_blk(m->dim, m->d_vals, m->d_diagpos, m->d_dinv_blk, m->d_dinv_sym6, m->mesh.nnodes, m->stream);
         }
     for (mi_ctx *m : T.members)
       {
@@ -634,14 +639,29 @@ namespace mi_detail
             mf_fused = mf_fused && mf_gather_fusable(m);
           if (mf_fused)
             {
+              // three-term form where the symmetric halves of D^-1 exist (3D): x'' over the buffer of the iterate before
+              // (zero after the first step of a zero start), then the two x buffers change roles
+              bool three = T.members[0]->mg->three_term;
+              for (mi_ctx *m : T.members)
+                three = three && m->mg->levels[l].ctx->d_dinv_sym6;
               std::vector<ChebFusion> cf;
               for (mi_ctx *m : T.members)
                 {
-                  MgLevel &L = m->mg->levels[l];
-                  cf.push_back(ChebFusion{L.b(), L.ctx->d_dinv_blk, L.d(), nullptr, c1, c2, 1, 1});
+                  MgLevel   &L = m->mg->levels[l];
+                  ChebFusion f{L.b(), L.ctx->d_dinv_blk, L.d(), nullptr, c1, c2, 1, 1};
+                  if (three)
+                    {
+                      f.dinv6 = L.ctx->d_dinv_sym6;
+                      f.xprev = (j == 1 && zero_start) ? nullptr : L.x_other();
+                      f.xnext = L.x_other();
+                    }
+                  cf.push_back(f);
                 }
               if ((rc = level_spmv(T, l, x_of, cf.data())))
                 return rc;
+              if (three)
+                for (mi_ctx *m : T.members)
+                  m->mg->levels[l].x_swapped = !m->mg->levels[l].x_swapped;
               continue;
             }
           bool fused = !skip_spmv && fuse_level(T, l);
@@ -829,6 +849,17 @@ namespace mi_detail
         L0.b_ext    = m->work(W_R);
         L0.x_ext    = m->work(W_Z);
       }
+    {
+      // the three-term smoother steps change the roles of level 0's two x buffers 2 nu - 1 times per cycle: start in the
+      // buffer from which the last step lands in W_Z
+      Multigrid &mg0   = *T.members[0]->mg;
+      bool       three = mg0.three_term && mg0.block && mg0.kind == 1;
+      for (mi_ctx *m : T.members)
+        three = three && mf_gather_fusable(m) && m->d_dinv_sym6;
+      if (three)
+        for (mi_ctx *m : T.members)
+          m->mg->levels[0].x_swapped = ((2 * mg0.nu - 1) & 1) != 0;
+    }
     int rc = vcycle(T, 0);
     if (rc)
       return rc;
