@@ -71,11 +71,12 @@ def test_oracle_reproduces_config2_fixture():
         assert _rel(L.vec(O.L_V).reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-11
 
 
-def _nonlinear(name, tol_u, tol_va):
+def _nonlinear(name, tol_u, tol_va, start=0):
     g = _g()
     n = int(g[name + "_cells"])
     G = M.Context(dim=3, degree=2, reps=(n, n, n))
     assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
+    G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
     ids = g[name + "_nodes"]
     for s, trac in enumerate(g[name + "_traction"]):
         G.set_interface_traction(trac)
@@ -95,8 +96,10 @@ def _nonlinear(name, tol_u, tol_va):
 
 
 @pytest.mark.gpu
-def test_gpu_24cube_block_two_steps_default_path():
-    _nonlinear("blk24", 1e-8, 1e-6)
+@pytest.mark.parametrize("start", [0, 2])
+def test_gpu_24cube_block_two_steps_default_path(start):
+    """(the second step runs on the coarse operators of the first and, with start = 2, from the first step's solutions)"""
+    _nonlinear("blk24", 1e-8, 1e-6, start)
 
 
 @pytest.mark.gpu
