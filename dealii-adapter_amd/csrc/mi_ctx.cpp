@@ -43,7 +43,8 @@ namespace mi_detail
     SC_INVERTED = 7, // set by the element kernels when a quadrature point has det F <= 0; travels with SC_NORM_RHS
     SC_NORM_RHS = 8,
     SC_NORM_UPD = 9,
-    SC_TOT = 10 // [rr, rz, pq, bb] all-reduced totals of the distributed CG
+    SC_TOT = 10, // [rr, rz, pq, bb] all-reduced totals of the distributed CG
+    SC_START = 14 // [h.b, h.Ah] of a predicted start vector (cg_run, scale_start)
   };
 
   int team_size(const mi_ctx *c)
@@ -711,7 +712,7 @@ namespace mi_detail
 
   // Jacobi-PCG (deal.II SolverCG semantics: start from x, stop when ||r||_2 <= tolerance) on the active matrix of
   // every slab of the team; followed by constraints.distribute (x[constrained] = 0)
-  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero)
+  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero, bool scale_start)
   {
     Team      &T    = *c->team;
     mi_ctx    *c0   = T.members[0];
@@ -821,8 +822,28 @@ namespace mi_detail
         for (mi_ctx *m : T.members)
           HIPCHK(m, hipMemsetAsync(m->work(W_Q), 0, size_t(m->n) * sizeof(double), m->stream));
       }
-    else if ((rc = team_spmv(T, self, x_of, q_of, nullptr))) // not under MI_T_SPMV: that class is the fused q = K p only
-      return rc;
+    else
+      {
+        if ((rc = team_spmv(T, self, x_of, q_of, nullptr))) // not under MI_T_SPMV: that class is the fused q = K p only
+          return rc;
+        if (scale_start)
+          {
+            // the start vector is a prediction h (the same solve of the previous time step): take alpha h with
+            // alpha = h.b / h.Ah, the multiple with the smallest energy-norm error -- never worse than starting from
+            // zero, whatever the load did since (A h is at hand: no further product)
+            for (mi_ctx *m : T.members)
+              {
+                mi::launch_dot_partials(m->vec(x_id) + m->own0, m->vec(b_id) + m->own0, m->own_n, m->part(5), m->grid_vec, m->stream);
+                mi::launch_dot_partials(m->vec(x_id) + m->own0, m->work(W_Q) + m->own0, m->own_n, m->part(6), m->grid_vec, m->stream);
+                mi::launch_reduce_to_totals(m->part(5), m->grid_vec, m->d_sc + SC_START, m->part(6), m->grid_vec,
+                                            m->d_sc + SC_START + 1, nullptr, m->stream);
+              }
+            if ((rc = team_allreduce(T, SC_START, 2)))
+              return rc;
+            for (mi_ctx *m : T.members)
+              mi::launch_scale_start(m->vec(x_id), m->work(W_Q), m->d_sc + SC_START, m->n, m->stream);
+          }
+      }
     for (size_t k = 0; k < R; ++k)
       {
         mi_ctx *m = T.members[k];
@@ -1650,20 +1671,22 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   // residual norm relative to |rhs|); costs one product for r0, saves about one iteration in seven on the headline run.
   const int  pj   = c0->solves_this_step++;
   const bool pred = c0->cg_warm_start >= 2 && pj < mi_ctx::NPRED;
+  bool       predicted = false;
   if (pred && x_zero && c0->pred_count[pj] >= 1)
     {
       const bool two = c0->cg_warm_start == 3 && c0->pred_count[pj] >= 2;
       for (mi_ctx *m : c->team->members)
         mi::launch_vec_lincomb2(m->vec(MI_V_NEWTON_UPDATE), two ? 2.0 : 1.0, m->d_pred[pj][0], two ? -1.0 : 0.0, m->d_pred[pj][1],
                                 m->n, m->stream);
-      x_zero = false;
+      x_zero    = false;
+      predicted = true;
     }
   // A multigrid-preconditioned solve needs 7-15 iterations; one that has not converged after 300 has stalled, and
   // iterating on to max_it (dofs x multiplier, i.e. millions) would be a hang in all but name.
   const bool    mg     = mg_active(c);
   const int64_t mg_cap = mg ? std::min<int64_t>(max_it, 300) : max_it;
   int           my_its = 0;
-  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, mg_cap, &my_its, res, x_zero);
+  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, mg_cap, &my_its, res, x_zero, predicted);
   // a breakdown (NaN state, indefinite tangent) is final, as with deal.II's SolverControl: no second attempt from a
   // poisoned iterate
   bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;

@@ -223,7 +223,8 @@ namespace mi_detail
   // Jacobi-PCG on the active matrix (all slabs of the team): x = vector x_id (warm start), b = vector b_id;
   // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
   // x_is_zero: the start vector is known to be zero (r0 = b without a product)
-  int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero = false);
+  int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero = false,
+              bool scale_start = false); // scale_start: the start vector is a prediction h, replaced by its best multiple
   int  team_size(const mi_ctx *c);
   void linear_destroy(mi_ctx *c);
   int  create_member(Team &T, const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int rank,

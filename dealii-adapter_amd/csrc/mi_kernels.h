@@ -234,6 +234,7 @@ namespace mi
   void launch_vec_scale_mul(double *dst, const double *a, const double *b, double s, int64_t n, hipStream_t st);
   void launch_vec_residual(double *res, const double *b, const double *q, int64_t n, hipStream_t s);
   void launch_vec_lincomb2(double *x, double a, const double *h1, double b, const double *h2, int64_t n, hipStream_t s);
+  void launch_scale_start(double *x, double *q, const double *sc, int64_t n, hipStream_t s);
   void launch_copy_owned(double *y, const double *x, int64_t n, int64_t own0, int64_t own_n, hipStream_t s);
   void launch_lattice_interp(int dim, bool add, const LatticeParams &p, double *tgt, const double *src,
                              const uint8_t *cmask_tgt, hipStream_t s);

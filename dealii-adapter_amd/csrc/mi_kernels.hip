@@ -2776,6 +2776,18 @@ namespace mi
     if (i < n)
       x[i] = b != 0.0 ? a * h1[i] + b * h2[i] : a * h1[i];
   }
+  // start vector h of a solve scaled to its best multiple: x = alpha h, q = alpha (A h) with alpha = h.b / h.Ah (the
+  // multiple with the smallest energy-norm error; sc = {h.b, h.Ah}; alpha = 0 if h.Ah is not positive)
+  __global__ __launch_bounds__(256) void scale_start(double *x, double *q, const double *__restrict__ sc, int64_t n)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= n)
+      return;
+    const double hb = sc[0], hq = sc[1];
+    const double alpha = (hq > 0.0 && hb == hb) ? hb / hq : 0.0;
+    x[i] *= alpha;
+    q[i] *= alpha;
+  }
   // y = mask(x): copy the dofs inside [own0, own0+own_n), zero elsewhere (right-hand side of the V-cycle)
   __global__ __launch_bounds__(256) void copy_owned(double *y, const double *__restrict__ x, int64_t n, int64_t own0,
                                                     int64_t own_n)
@@ -4186,6 +4198,10 @@ namespace mi
   void launch_vec_lincomb2(double *x, double a, const double *h1, double b, const double *h2, int64_t n, hipStream_t s)
   {
     hipLaunchKernelGGL(vec_lincomb2, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, a, h1, b, h2, n);
+  }
+  void launch_scale_start(double *x, double *q, const double *sc, int64_t n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(scale_start, dim3(int((n + 255) / 256)), dim3(256), 0, s, x, q, sc, n);
   }
   void launch_copy_owned(double *y, const double *x, int64_t n, int64_t own0, int64_t own_n, hipStream_t s)
   {

@@ -266,7 +266,7 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * matrix), 1: with stored symmetric element tangents, 0: with the assembled matrix; "spmv_variant" 4 +
  * "element_tangents" 2 | 1: mi_spmv through that form whatever the mesh size (tests); "cg_operator" 0 (default) | 1: the
  * CG's own product on the assembled matrix | in the smoother's unassembled form (A/B); "asm_variant" 0 (default): 3D Q2
- * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update, 2 | 3: a solve that would start from zero starts from the solution of the same solve (first, second ... of the step, counted from mi_newton_begin_step) of the previous time step | its linear extrapolation over the last two steps -- the history belongs to mi_state_save / mi_state_restore; the executable and bench.py set 2; "solver_type" 0 (default) | 1: see mi_direct_solve; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
+ * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update, 2 | 3: a solve that would start from zero starts from the solution of the same solve (first, second ... of the step, counted from mi_newton_begin_step) of the previous time step | its linear extrapolation over the last two steps, scaled to its best multiple alpha h, alpha = h.b / h.Ah (never worse than zero) -- the history belongs to mi_state_save / mi_state_restore; the executable and bench.py set 2; "solver_type" 0 (default) | 1: see mi_direct_solve; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
  * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 /* counters since the last mi_reset_timings (what a solve costs in latency-bound events; counted on one slab as well,
