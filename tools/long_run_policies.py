@@ -11,7 +11,7 @@ M = _pkg()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 59
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 G = M.Context(dim=3, degree=2, reps=(n, n, n))
-G.set_tuning("cg_warm_start", 2)
+G.set_tuning("cg_warm_start", int(os.environ.get("MODE", "2")))
 G.reset_timings()
 for k in range(steps):
     ramp = min(1.0, (k + 1) / 10.0)
