@@ -2863,10 +2863,16 @@ namespace mi
             s += int64_t(idx < p.ns[d] ? idx : p.ns[d] - 1) * stride;
             stride *= p.ns[d];
           }
+        // (loads unconditional -- the index is clamped --, so that the 2^D corners travel together; the sum skips the
+        // corners of weight zero and the nodes another slab serves, as before)
+        double v[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+          v[c] = src[(served ? s : 0) * D + c];
         if (ok)
 #pragma unroll
           for (int c = 0; c < D; ++c)
-            acc[c] += wt * src[s * D + c];
+            acc[c] += wt * v[c];
       }
     const int m = cmask_tgt ? cmask_tgt[t] : 0;
 #pragma unroll
@@ -2967,13 +2973,16 @@ namespace mi
       for (int ky = 0; ky < MAXR; ++ky)
 #pragma unroll
         for (int kx = 0; kx < MAXR; ++kx)
-          if (kx < cnt[0] && ky < cnt[1] && kz < cnt[2])
-            {
-              const double  wz = (D == 3) ? fw[2][kz] : 1.0;
-              const double  wt = fw[0][kx] * (fw[1][ky] * wz);
-              const int64_t f  = fi[0][kx] + int64_t(p.ns[0]) * (fi[1][ky] + int64_t(p.ns[1]) * (D == 3 ? fi[2][kz] : 0));
-              acc += wt * fine[f * D + c];
-            }
+          {
+            // the load itself is unconditional (entries past a list point at fine node 0): guarded, the up to MAXR^D
+            // loads would wait for one another; only the sum skips them
+            const double  wz = (D == 3) ? fw[2][kz] : 1.0;
+            const double  wt = fw[0][kx] * (fw[1][ky] * wz);
+            const int64_t f  = fi[0][kx] + int64_t(p.ns[0]) * (fi[1][ky] + int64_t(p.ns[1]) * (D == 3 ? fi[2][kz] : 0));
+            const double  v  = fine[f * D + c];
+            if (kx < cnt[0] && ky < cnt[1] && kz < cnt[2])
+              acc += wt * v;
+          }
     const int m = cmask_coarse ? cmask_coarse[I] : 0;
     coarse[g]   = ((m >> c) & 1) ? 0.0 : acc;
   }
