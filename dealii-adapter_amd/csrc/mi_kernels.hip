@@ -4258,7 +4258,17 @@ namespace mi
                                const uint8_t *cmask_coarse, hipStream_t s)
   {
     const int grid = int((p.n_tgt + 255) / 256);
-    if (p.rmax >= 1 && p.rmax <= 4 && p.n_tgt <= 100000) // (above, the loop form is the faster one: 26 against 30 us at 216 k nodes)
+    // lists of at most 3 (nested lattices): 3^D loads per dof, all of them useful -- at every size; of at most 4: 4^D
+    // loads of which 27-48 are used, worth it on the latency-bound levels only (loop form: 26 us, this: 42 us at 216 k nodes)
+    if (p.rmax >= 1 && p.rmax <= 3)
+      {
+        const int gu = int((p.n_tgt * dim + 255) / 256);
+        if (dim == 3)
+          hipLaunchKernelGGL((lattice_restrict_unrolled<3, 3>), dim3(gu), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
+        else
+          hipLaunchKernelGGL((lattice_restrict_unrolled<2, 3>), dim3(gu), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
+      }
+    else if (p.rmax == 4 && p.n_tgt <= 100000)
       {
         const int gu = int((p.n_tgt * dim + 255) / 256);
         if (dim == 3)
