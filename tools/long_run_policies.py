@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Iteration counts of a long run of the headline problem under the solver policies the executable sets (start vector from
-the previous step, coarse operators rebuilt every 8th step or on demand): python tools/long_run_policies.py [cells] [steps]"""
+the previous step, coarse operators rebuilt every 8th step or on demand): python tools/long_run_policies.py [cells] [steps]
+(MODE=0|1|2|3 in the environment selects another "cg_warm_start")"""
 import os
 import sys
 
