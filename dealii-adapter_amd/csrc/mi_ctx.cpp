@@ -1665,7 +1665,7 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   mi_ctx *c0     = c->team->members[0];
   bool    x_zero = c0->newton_update_is_zero;
   c0->newton_update_is_zero = false;
-  // "cg_warm_start" 2 (default) / 3: when the library has just cleared the update, the j-th solve of a time step starts
+  // "cg_warm_start" 2 (what the executable and bench.py set) / 3: when the library has just cleared the update, the j-th solve of a time step starts
   // from the solution of the j-th solve of the previous step (3: extrapolated linearly over the last two) instead of
   // zero -- the loads of a time-stepping run change little from step to step.  Same stopping rule (:1155-1156, a
   // residual norm relative to |rhs|); costs one product for r0, saves about one iteration in seven on the headline run.
