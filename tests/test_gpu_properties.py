@@ -143,6 +143,32 @@ def test_fp32_stored_smoother_matrix_is_only_a_preconditioner_change(config3):
     assert np.abs(out[32][0] - out[64][0]).max() / np.abs(out[64][0]).max() < 1e-7
 
 
+def test_headline_size_solver_policies_do_not_change_the_solution():
+    """BASELINE configuration 4 (59^3 Q2 cells) under the policies bench.py and the executable run with -- start vectors
+    from the previous step, coarse operators kept over the steps -- against the library's plain setting (zero start,
+    operators rebuilt every step): four ramp steps at a tight linear tolerance, same Newton tables, states equal to 1e-8"""
+    n, out = 59, {}
+    for name, start, every in (("plain", 0, 1), ("policies", 2, 8)):
+        G = M.Context(dim=3, degree=2, reps=(n, n, n))
+        G.set_tuning("cg_warm_start", start)
+        G.set_tuning("mg_refresh_every", every)
+        G.reset_timings()
+        table, its = [], 0
+        for k in range(4):
+            G.set_interface_traction((0.0, -2e3 * (k + 1) / 10.0, 0.0))
+            rc, info = G.newmark_step(tol_lin=1e-10, max_it_mult=1.0)
+            assert rc == 0 and info.converged == 1
+            table.append((info.newton_iterations, info.assemblies))
+            its += info.lin_its_total
+        out[name] = (table, its, G.get(M.V_U), G.get(M.V_V), G.get_tuning("count_mg_refresh"))
+        G.close()
+    assert out["policies"][0] == out["plain"][0]
+    assert out["plain"][4] == 4 and out["policies"][4] == 1
+    assert out["policies"][1] <= out["plain"][1]
+    for k in (2, 3):
+        assert np.abs(out["policies"][k] - out["plain"][k]).max() / np.abs(out["plain"][k]).max() < 1e-8
+
+
 def test_headline_size_invariants():
     """BASELINE configuration 4 (59^3 Q2 cells, the size bench.py runs): sizes of SURVEY.md section 8, bitwise
     repeatable assembly, symmetric operator, a full Newmark step with the reference's Newton bookkeeping and a
