@@ -9,8 +9,8 @@ lattice subsample of the results plus whole-vector functionals:
 
   blk24   24^3 Q2 block (117,649 nodes: the smallest mesh on which the matrix-free smoother is the default), two full
           Newmark steps, traction (0,-2e3,0), linear tolerance 1e-12       [REF nonlinear_elasticity.cc:410-499]
-  cfg3    BASELINE configuration 3: 34^3 Q2 block (985,527 DoFs), first Newmark step of the bench's ramp
-          (traction (0,-2e2,0)), "Residual" = 1e-10                         [REF nonlinear_elasticity.cc:410-499, 1153-1211]
+  cfg3    BASELINE configuration 3: 34^3 Q2 block (985,527 DoFs), the first three Newmark steps of the bench's ramp
+          (traction (0,-2e2 k,0), k = 1, 2, 3), "Residual" = 1e-10          [REF nonlinear_elasticity.cc:410-499, 1153-1211]
   cfg4    BASELINE configuration 4: 59^3 Q2 block (5,055,477 DoFs), ONE Newton iteration of the same step: residual
           norm, right-hand side, Newton update (CG to 1e-10)               [REF nonlinear_elasticity.cc:444-487]
   cfg2    BASELINE configuration 2: 40^3 Q1 cantilever of the linear model (206,763 DoFs), three theta-steps with the
@@ -159,7 +159,7 @@ def main():
         if case == "blk24":
             run_nonlinear("blk24", 24, 2, [(0.0, -2e3, 0.0)] * 2, 1e-12, STRIDES["blk24"][1], out)
         elif case == "cfg3":
-            run_nonlinear("cfg3", 34, 1, [(0.0, -2e2, 0.0)], 1e-10, STRIDES["cfg3"][1], out)
+            run_nonlinear("cfg3", 34, 3, [(0.0, -2e2 * (k + 1), 0.0) for k in range(3)], 1e-10, STRIDES["cfg3"][1], out)
         elif case == "cfg4":
             run_one_newton_iteration("cfg4", 59, (0.0, -2e2, 0.0), 1e-10, STRIDES["cfg4"][1], out)
         elif case == "cfg2":

@@ -6,7 +6,7 @@ sum-factorised element kernel (above 100 k nodes); everything the oracle is comp
 where the preconditioner is Jacobi and the smoother the assembled matrix.
 
   blk24  24^3 Q2 cells (352,947 DoFs), two Newmark steps, linear tolerance 1e-12   [REF nonlinear_elasticity.cc:410-499]
-  cfg3   BASELINE configuration 3, 34^3 Q2 cells (985,527 DoFs), first step, "Residual" 1e-10
+  cfg3   BASELINE configuration 3, 34^3 Q2 cells (985,527 DoFs), the first three steps of the ramp, "Residual" 1e-10
   cfg4   BASELINE configuration 4, 59^3 Q2 cells (5,055,477 DoFs), one Newton iteration (residual, operator, update)
   cfg2   BASELINE configuration 2, 40^3 Q1 cells of the linear model (206,763 DoFs), three theta-steps
                                                                                     [REF linear_elasticity.cc:378-586]
@@ -103,8 +103,10 @@ def test_gpu_24cube_block_two_steps_default_path(start):
 
 
 @pytest.mark.gpu
-def test_gpu_config3_first_step_default_path():
-    _nonlinear("cfg3", 1e-8, 1e-6)
+@pytest.mark.parametrize("start", [0, 2])
+def test_gpu_config3_three_steps_default_path(start):
+    """(steps 2 and 3 run on the coarse operators of step 1 and, with start = 2, from the previous step's solutions)"""
+    _nonlinear("cfg3", 1e-8, 1e-6, start)
 
 
 @pytest.mark.gpu
