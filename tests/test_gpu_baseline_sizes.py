@@ -8,6 +8,7 @@ where the preconditioner is Jacobi and the smoother the assembled matrix.
   blk24  24^3 Q2 cells (352,947 DoFs), two Newmark steps, linear tolerance 1e-12   [REF nonlinear_elasticity.cc:410-499]
   cfg3   BASELINE configuration 3, 34^3 Q2 cells (985,527 DoFs), the first three steps of the ramp, "Residual" 1e-10
   cfg4   BASELINE configuration 4, 59^3 Q2 cells (5,055,477 DoFs), one Newton iteration (residual, operator, update)
+  cfg4s  the same configuration, the whole first Newmark step
   cfg2   BASELINE configuration 2, 40^3 Q1 cells of the linear model (206,763 DoFs), three theta-steps
                                                                                     [REF linear_elasticity.cc:378-586]
 Compared: values at a lattice subsample of the nodes (same lexicographic node ids on both sides), the Euclidean norm of
@@ -49,7 +50,7 @@ def _relfun(v, ref):
 
 def test_fixture_layout():
     g = _g()
-    for name, cells, p in (("blk24", 24, 2), ("cfg3", 34, 2), ("cfg4", 59, 2), ("cfg2", 40, 1)):
+    for name, cells, p in (("blk24", 24, 2), ("cfg3", 34, 2), ("cfg4", 59, 2), ("cfg4s", 59, 2), ("cfg2", 40, 1)):
         assert int(g[name + "_cells"]) == cells
         ids = g[name + "_nodes"]
         assert np.all(np.diff(ids) > 0) and ids[0] == 0 and ids[-1] == (p * cells + 1) ** 3 - 1
@@ -107,6 +108,12 @@ def test_gpu_24cube_block_two_steps_default_path(start):
 def test_gpu_config3_three_steps_default_path(start):
     """(steps 2 and 3 run on the coarse operators of step 1 and, with start = 2, from the previous step's solutions)"""
     _nonlinear("cfg3", 1e-8, 1e-6, start)
+
+
+@pytest.mark.gpu
+def test_gpu_config4_first_step_default_path():
+    """the headline size through a whole Newmark step (three Newton iterations) against the oracle"""
+    _nonlinear("cfg4s", 1e-8, 1e-6)
 
 
 @pytest.mark.gpu
