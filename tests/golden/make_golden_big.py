@@ -9,6 +9,8 @@ lattice subsample of the results plus whole-vector functionals:
 
   blk24   24^3 Q2 block (117,649 nodes: the smallest mesh on which the matrix-free smoother is the default), two full
           Newmark steps, traction (0,-2e3,0), linear tolerance 1e-12       [REF nonlinear_elasticity.cc:410-499]
+  blk24d  the same block with every cell distorted (vertices moved by 8 % of the cell size, seeded): the general-geometry
+          branches of the element kernel and of the matrix-free product at the default solver path
   cfg3    BASELINE configuration 3: 34^3 Q2 block (985,527 DoFs), the first three Newmark steps of the bench's ramp
           (traction (0,-2e2 k,0), k = 1, 2, 3), "Residual" = 1e-10          [REF nonlinear_elasticity.cc:410-499, 1153-1211]
   cfg4    BASELINE configuration 4: 59^3 Q2 block (5,055,477 DoFs), ONE Newton iteration of the same step: residual
@@ -61,8 +63,13 @@ def functionals(v):
     return np.array([np.linalg.norm(v), float(v @ weights(v.size))])
 
 
-def run_nonlinear(name, cells, steps, traction, tol_lin, stride, out):
-    P = O.Problem(O.make_desc(dim=3, degree=2, reps=(cells,) * 3))
+def distortion(cells, seed=77, amp=0.08):
+    """vertex displacements of the distorted block: amp x cell size x standard normal, seeded (the GPU test builds the same)"""
+    return amp / cells * np.random.default_rng(seed).standard_normal(((cells + 1) ** 3, 3))
+
+
+def run_nonlinear(name, cells, steps, traction, tol_lin, stride, out, distorted=False):
+    P = O.Problem(O.make_desc(dim=3, degree=2, reps=(cells,) * 3), distortion(cells) if distorted else None)
     npts = (2 * cells + 1,) * 3
     ids = lattice_sample(npts, stride)
     out[name + "_cells"], out[name + "_nodes"], out[name + "_tol_lin"] = cells, ids, tol_lin
@@ -134,7 +141,7 @@ def run_linear(name, cells, steps, traction, abs_tol, stride, out):
     out[name + "_d"], out[name + "_v"], out[name + "_fun"] = np.array(ds), np.array(vs), np.array(fs)
 
 
-STRIDES = {"blk24": (49, 4), "cfg3": (69, 8), "cfg4": (119, 14), "cfg4s": (119, 14), "cfg2": (41, 4)}  # nodes per direction, stride
+STRIDES = {"blk24": (49, 4), "blk24d": (49, 4), "cfg3": (69, 8), "cfg4": (119, 14), "cfg4s": (119, 14), "cfg2": (41, 4)}  # nodes per direction, stride
 
 
 def thin(out):
@@ -160,6 +167,8 @@ def main():
         t0 = time.perf_counter()
         if case == "blk24":
             run_nonlinear("blk24", 24, 2, [(0.0, -2e3, 0.0)] * 2, 1e-12, STRIDES["blk24"][1], out)
+        elif case == "blk24d":  # the same block with distorted cells: no cell is a box, the general-geometry kernels run
+            run_nonlinear("blk24d", 24, 2, [(0.0, -2e3, 0.0)] * 2, 1e-12, STRIDES["blk24d"][1], out, distorted=True)
         elif case == "cfg3":
             run_nonlinear("cfg3", 34, 3, [(0.0, -2e2 * (k + 1), 0.0) for k in range(3)], 1e-10, STRIDES["cfg3"][1], out)
         elif case == "cfg4":

@@ -6,6 +6,7 @@ sum-factorised element kernel (above 100 k nodes); everything the oracle is comp
 where the preconditioner is Jacobi and the smoother the assembled matrix.
 
   blk24  24^3 Q2 cells (352,947 DoFs), two Newmark steps, linear tolerance 1e-12   [REF nonlinear_elasticity.cc:410-499]
+  blk24d the same block with distorted cells (general-geometry kernels)
   cfg3   BASELINE configuration 3, 34^3 Q2 cells (985,527 DoFs), the first three steps of the ramp, "Residual" 1e-10
   cfg4   BASELINE configuration 4, 59^3 Q2 cells (5,055,477 DoFs), one Newton iteration (residual, operator, update)
   cfg4s  the same configuration, the first three Newmark steps of the ramp
@@ -50,7 +51,7 @@ def _relfun(v, ref):
 
 def test_fixture_layout():
     g = _g()
-    for name, cells, p in (("blk24", 24, 2), ("cfg3", 34, 2), ("cfg4", 59, 2), ("cfg4s", 59, 2), ("cfg2", 40, 1)):
+    for name, cells, p in (("blk24", 24, 2), ("blk24d", 24, 2), ("cfg3", 34, 2), ("cfg4", 59, 2), ("cfg4s", 59, 2), ("cfg2", 40, 1)):
         assert int(g[name + "_cells"]) == cells
         ids = g[name + "_nodes"]
         assert np.all(np.diff(ids) > 0) and ids[0] == 0 and ids[-1] == (p * cells + 1) ** 3 - 1
@@ -72,10 +73,12 @@ def test_oracle_reproduces_config2_fixture():
         assert _rel(L.vec(O.L_V).reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-11
 
 
-def _nonlinear(name, tol_u, tol_va, start=0):
+def _nonlinear(name, tol_u, tol_va, start=0, distorted=False):
     g = _g()
     n = int(g[name + "_cells"])
-    G = M.Context(dim=3, degree=2, reps=(n, n, n))
+    # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
+    perturb = 0.08 / n * np.random.default_rng(77).standard_normal(((n + 1) ** 3, 3)) if distorted else None
+    G = M.Context(dim=3, degree=2, reps=(n, n, n), perturb=perturb)
     assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
     G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
     ids = g[name + "_nodes"]
@@ -101,6 +104,13 @@ def _nonlinear(name, tol_u, tol_va, start=0):
 def test_gpu_24cube_block_two_steps_default_path(start):
     """(the second step runs on the coarse operators of the first and, with start = 2, from the first step's solutions)"""
     _nonlinear("blk24", 1e-8, 1e-6, start)
+
+
+@pytest.mark.gpu
+def test_gpu_24cube_distorted_block_two_steps_default_path():
+    """no cell is a box: the general-geometry branches of the element kernel and of the matrix-free product, at the
+    size where the multigrid + matrix-free path is the default"""
+    _nonlinear("blk24d", 1e-8, 1e-6, 2, distorted=True)
 
 
 @pytest.mark.gpu
