@@ -11,6 +11,8 @@ lattice subsample of the results plus whole-vector functionals:
           Newmark steps, traction (0,-2e3,0), linear tolerance 1e-12       [REF nonlinear_elasticity.cc:410-499]
   blk24d  the same block with every cell distorted (vertices moved by 8 % of the cell size, seeded): the general-geometry
           branches of the element kernel and of the matrix-free product at the default solver path
+  q1_48   48^3 Q1 cells (352,947 DoFs) and
+  q2_2d   300^2 Q2 cells in 2D (722,402 DoFs), two steps each: the other element families on the multigrid path
   cfg3    BASELINE configuration 3: 34^3 Q2 block (985,527 DoFs), the first three Newmark steps of the bench's ramp
           (traction (0,-2e2 k,0), k = 1, 2, 3), "Residual" = 1e-10          [REF nonlinear_elasticity.cc:410-499, 1153-1211]
   cfg4    BASELINE configuration 4: 59^3 Q2 block (5,055,477 DoFs), ONE Newton iteration of the same step: residual
@@ -55,6 +57,9 @@ def lattice_sample(npts, stride):
         if a[-1] != m - 1:
             a.append(m - 1)
         axes.append(np.array(a))
+    if len(npts) == 2:
+        ix, iy = np.meshgrid(axes[0], axes[1], indexing="ij")
+        return np.sort((ix + npts[0] * iy).ravel()).astype(np.int32)
     ix, iy, iz = np.meshgrid(axes[0], axes[1], axes[2], indexing="ij")
     return np.sort((ix + npts[0] * (iy + npts[1] * iz)).ravel()).astype(np.int32)
 
@@ -68,9 +73,9 @@ def distortion(cells, seed=77, amp=0.08):
     return amp / cells * np.random.default_rng(seed).standard_normal(((cells + 1) ** 3, 3))
 
 
-def run_nonlinear(name, cells, steps, traction, tol_lin, stride, out, distorted=False):
-    P = O.Problem(O.make_desc(dim=3, degree=2, reps=(cells,) * 3), distortion(cells) if distorted else None)
-    npts = (2 * cells + 1,) * 3
+def run_nonlinear(name, cells, steps, traction, tol_lin, stride, out, distorted=False, dim=3, degree=2):
+    P = O.Problem(O.make_desc(dim=dim, degree=degree, reps=(cells,) * dim), distortion(cells) if distorted else None)
+    npts = (degree * cells + 1,) * dim
     ids = lattice_sample(npts, stride)
     out[name + "_cells"], out[name + "_nodes"], out[name + "_tol_lin"] = cells, ids, tol_lin
     out[name + "_traction"] = np.array(traction)
@@ -83,12 +88,12 @@ def run_nonlinear(name, cells, steps, traction, tol_lin, stride, out, distorted=
         print("%s step %d: %d Newton / %d CG iterations, %.0f s" % (name, s, info.newton_iterations, info.lin_its_total,
                                                                      time.perf_counter() - t0), flush=True)
         logs.append([info.newton_iterations, info.assemblies, info.res_norm, info.res_abs, info.upd_norm, info.upd_abs])
-        u = P.vec(O.V_U).reshape(-1, 3)
+        u = P.vec(O.V_U).reshape(-1, dim)
         us.append(u[ids].copy())
         fs.append(np.stack([functionals(P.vec(w)) for w in (O.V_U, O.V_V, O.V_A)]))
     out[name + "_log"], out[name + "_u"], out[name + "_fun"] = np.array(logs), np.array(us), np.array(fs)
-    out[name + "_v"] = P.vec(O.V_V).reshape(-1, 3)[ids].copy()
-    out[name + "_a"] = P.vec(O.V_A).reshape(-1, 3)[ids].copy()
+    out[name + "_v"] = P.vec(O.V_V).reshape(-1, dim)[ids].copy()
+    out[name + "_a"] = P.vec(O.V_A).reshape(-1, dim)[ids].copy()
 
 
 def run_one_newton_iteration(name, cells, traction, tol_lin, stride, out):
@@ -141,7 +146,7 @@ def run_linear(name, cells, steps, traction, abs_tol, stride, out):
     out[name + "_d"], out[name + "_v"], out[name + "_fun"] = np.array(ds), np.array(vs), np.array(fs)
 
 
-STRIDES = {"blk24": (49, 4), "blk24d": (49, 4), "cfg3": (69, 8), "cfg4": (119, 14), "cfg4s": (119, 14), "cfg2": (41, 4)}  # nodes per direction, stride
+STRIDES = {"blk24": (49, 4), "blk24d": (49, 4), "q1_48": (49, 6), "q2_2d": (601, 20), "cfg3": (69, 8), "cfg4": (119, 14), "cfg4s": (119, 14), "cfg2": (41, 4)}  # nodes per direction, stride
 
 
 def thin(out):
@@ -149,7 +154,8 @@ def thin(out):
     for name, (m, stride) in STRIDES.items():
         if name + "_nodes" not in out:
             continue
-        keep_ids = lattice_sample((m,) * 3, stride)
+        dim = 2 if name + "_u" in out and np.shape(out[name + "_u"])[-1] == 2 else 3
+        keep_ids = lattice_sample((m,) * dim, stride)
         ids = out[name + "_nodes"]
         sel = np.nonzero(np.isin(ids, keep_ids))[0]
         assert len(sel) == len(keep_ids), (name, len(sel), len(keep_ids))
@@ -169,6 +175,10 @@ def main():
             run_nonlinear("blk24", 24, 2, [(0.0, -2e3, 0.0)] * 2, 1e-12, STRIDES["blk24"][1], out)
         elif case == "blk24d":  # the same block with distorted cells: no cell is a box, the general-geometry kernels run
             run_nonlinear("blk24d", 24, 2, [(0.0, -2e3, 0.0)] * 2, 1e-12, STRIDES["blk24d"][1], out, distorted=True)
+        elif case == "q1_48":  # other element families on the multigrid path (their smoother multiplies with the assembled matrix)
+            run_nonlinear("q1_48", 48, 2, [(0.0, -2e3, 0.0)] * 2, 1e-12, STRIDES["q1_48"][1], out, degree=1)
+        elif case == "q2_2d":
+            run_nonlinear("q2_2d", 300, 2, [(0.0, -2e3)] * 2, 1e-12, STRIDES["q2_2d"][1], out, dim=2)
         elif case == "cfg3":
             run_nonlinear("cfg3", 34, 3, [(0.0, -2e2 * (k + 1), 0.0) for k in range(3)], 1e-10, STRIDES["cfg3"][1], out)
         elif case == "cfg4":

@@ -51,6 +51,7 @@ def _relfun(v, ref):
 
 def test_fixture_layout():
     g = _g()
+    assert int(g["q1_48_cells"]) == 48 and int(g["q2_2d_cells"]) == 300 and g["q2_2d_u"].shape[-1] == 2
     for name, cells, p in (("blk24", 24, 2), ("blk24d", 24, 2), ("cfg3", 34, 2), ("cfg4", 59, 2), ("cfg4s", 59, 2), ("cfg2", 40, 1)):
         assert int(g[name + "_cells"]) == cells
         ids = g[name + "_nodes"]
@@ -73,12 +74,12 @@ def test_oracle_reproduces_config2_fixture():
         assert _rel(L.vec(O.L_V).reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-11
 
 
-def _nonlinear(name, tol_u, tol_va, start=0, distorted=False):
+def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2):
     g = _g()
     n = int(g[name + "_cells"])
     # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
     perturb = 0.08 / n * np.random.default_rng(77).standard_normal(((n + 1) ** 3, 3)) if distorted else None
-    G = M.Context(dim=3, degree=2, reps=(n, n, n), perturb=perturb)
+    G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb)
     assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
     G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
     ids = g[name + "_nodes"]
@@ -89,13 +90,14 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False):
         assert rc == 0 and info.converged == 1
         assert [info.newton_iterations, info.assemblies] == [int(row[0]), int(row[1])]  # nonlinear_elasticity.cc:446-469
         u = G.get(M.V_U)
-        assert _rel(u.reshape(-1, 3)[ids], g[name + "_u"][s]) < tol_u
+        assert _rel(u.reshape(-1, dim)[ids], g[name + "_u"][s]) < tol_u
         assert _relfun(u, g[name + "_fun"][s][0]) < tol_u
         for k, which in ((1, M.V_V), (2, M.V_A)):
             assert _relfun(G.get(which), g[name + "_fun"][s][k]) < tol_va
-    assert G.get_tuning("smoother_operator_active") == 2  # the matrix-free smoother was what ran
-    assert _rel(G.get(M.V_V).reshape(-1, 3)[ids], g[name + "_v"]) < tol_va
-    assert _rel(G.get(M.V_A).reshape(-1, 3)[ids], g[name + "_a"]) < tol_va  # amplified by 1/dt^2
+    # 3D Q2: the matrix-free smoother was what ran; the other elements smooth with the assembled matrix
+    assert G.get_tuning("smoother_operator_active") == (2 if (dim, degree) == (3, 2) else 0)
+    assert _rel(G.get(M.V_V).reshape(-1, dim)[ids], g[name + "_v"]) < tol_va
+    assert _rel(G.get(M.V_A).reshape(-1, dim)[ids], g[name + "_a"]) < tol_va  # amplified by 1/dt^2
     G.close()
 
 
@@ -111,6 +113,14 @@ def test_gpu_24cube_distorted_block_two_steps_default_path():
     """no cell is a box: the general-geometry branches of the element kernel and of the matrix-free product, at the
     size where the multigrid + matrix-free path is the default"""
     _nonlinear("blk24d", 1e-8, 1e-6, 2, distorted=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dim,degree", [("q1_48", 3, 1), ("q2_2d", 2, 2)])
+def test_gpu_other_element_families_on_the_multigrid_path(name, dim, degree):
+    """48^3 Q1 cells in 3D, 300^2 Q2 cells in 2D: the node-pair element kernel and the multigrid with the assembled
+    smoother, two steps against the oracle"""
+    _nonlinear(name, 1e-8, 1e-6, 2, dim=dim, degree=degree)
 
 
 @pytest.mark.gpu
