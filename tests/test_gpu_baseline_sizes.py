@@ -74,12 +74,12 @@ def test_oracle_reproduces_config2_fixture():
         assert _rel(L.vec(O.L_V).reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-11
 
 
-def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2):
+def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, slabs=1, cut_axis=0):
     g = _g()
     n = int(g[name + "_cells"])
     # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
     perturb = 0.08 / n * np.random.default_rng(77).standard_normal(((n + 1) ** 3, 3)) if distorted else None
-    G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb)
+    G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb, slabs=slabs, cut_axis=cut_axis)
     assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
     G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
     ids = g[name + "_nodes"]
@@ -95,7 +95,8 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2):
         for k, which in ((1, M.V_V), (2, M.V_A)):
             assert _relfun(G.get(which), g[name + "_fun"][s][k]) < tol_va
     # 3D Q2: the matrix-free smoother was what ran; the other elements smooth with the assembled matrix
-    assert G.get_tuning("smoother_operator_active") == (2 if (dim, degree) == (3, 2) else 0)
+    if slabs == 1:  # (a slab of a quarter of this block is below the size at which the matrix-free form is chosen)
+        assert G.get_tuning("smoother_operator_active") == (2 if (dim, degree) == (3, 2) else 0)
     assert _rel(G.get(M.V_V).reshape(-1, dim)[ids], g[name + "_v"]) < tol_va
     assert _rel(G.get(M.V_A).reshape(-1, dim)[ids], g[name + "_a"]) < tol_va  # amplified by 1/dt^2
     G.close()
@@ -106,6 +107,15 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2):
 def test_gpu_24cube_block_two_steps_default_path(start):
     """(the second step runs on the coarse operators of the first and, with start = 2, from the first step's solutions)"""
     _nonlinear("blk24", 1e-8, 1e-6, start)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slabs,cut_axis", [(2, 0), (4, 2), (3, 1)])
+def test_gpu_24cube_block_decomposed_against_the_oracle(slabs, cut_axis):
+    """the same fixture on 2 / 4 / 3 slabs cut along the default (last), the y and the x direction: the distributed
+    multigrid levels, halo exchanges and the matrix-free smoother on slabs against the oracle, not against the
+    undecomposed run"""
+    _nonlinear("blk24", 1e-8, 1e-6, 2, slabs=slabs, cut_axis=cut_axis)
 
 
 @pytest.mark.gpu
