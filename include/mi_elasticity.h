@@ -167,7 +167,9 @@ int mi_apply_newton_update(mi_ctx *ctx, double *upd_norm); /* get_error_update :
                                                        the consumed update is cleared, so that the next solve of the
                                                        step starts from zero -- unless mi_set_tuning("cg_warm_start", 1)
                                                        asks for the reference's start vector, the previous update
-                                                       (:419, :472-473: 28 instead of 22 CG iterations per step) */
+                                                       (:419, :472-473: 28 instead of 22 CG iterations per step), or
+                                                       "cg_warm_start" 2 for the solution of the same solve of the
+                                                       previous time step (what the executable sets: 19-20) */
 int mi_newmark_finish_step(mi_ctx *ctx);            /* :139-144: u += delta; a, v updates; old := new      */
 /* the whole of solve_nonlinear_timestep + :139-144 with the reference's convergence logic */
 int mi_newmark_step(mi_ctx *ctx, const mi_solver_desc *s, mi_step_info *info);
