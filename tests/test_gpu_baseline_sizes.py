@@ -151,7 +151,7 @@ def test_gpu_config4_three_steps_default_path(start):
 
 @pytest.mark.gpu
 def test_gpu_config4_at_the_shipped_linear_tolerance():
-    """what bench.py times -- configuration 4, "Residual" = 1e-6 as shipped (parameters.prm:46), the executable's solver
+    """what bench.py times -- configuration 4, "Residual" = 1e-6 as shipped (parameters.prm:51), the executable's solver
     policies -- against the oracle's steps at 1e-10: the same Newton tables, displacements to 1e-5 (with the
     shipped tolerance only ~1e-5 can be claimed; the iterates of different preconditioners differ that much)"""
     g = _g()
