@@ -124,9 +124,77 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // Closed form of the connectivity of a 3D lattice mesh (mi::CellLattice), checked cell by cell against conn: any
+  // disagreement (or a mesh outside the exactness bounds of the reciprocal multiplications) leaves ncol = 0 and the
+  // kernels keep reading conn.  rows: the per-colour table for the device.
+  mi::CellLattice build_cell_lattice(const mi::HostMesh &m, std::vector<mi::CellLatticeRow> &rows)
+  {
+    mi::CellLattice L{};
+    rows.assign(8, mi::CellLatticeRow{1, 1, 0, 0, 0, 0});
+    if (m.dim != 3 || m.ncolours < 1 || m.ncolours > 8 || m.nnodes >= (int64_t(1) << 31))
+      return L;
+    const int p = m.p;
+    L.nn0  = m.nn[0];
+    L.nn01 = m.nn[0] * m.nn[1];
+    L.sx   = 2 * p;
+    L.sy   = 2 * p * m.nn[0];
+    L.sz   = 2 * p * m.nn[0] * m.nn[1];
+    for (int c = 0; c < m.ncolours; ++c)
+      {
+        const int64_t b = m.colour_begin[size_t(c)], e = m.colour_begin[size_t(c) + 1];
+        if (e <= b || e - b >= (int64_t(1) << 22))
+          return mi::CellLattice{};
+        int ci[3];
+        mi::HostMesh::split(m.cell_orig[size_t(b)], m.reps, 3, ci); // first cell of the colour: its parities
+        const int par[3] = {ci[0] & 1, ci[1] & 1, ci[2] & 1};
+        if (ci[0] != par[0] || ci[1] != par[1] || ci[2] != par[2])
+          return mi::CellLattice{};
+        const int mx = (m.reps[0] - par[0] + 1) / 2, my = (m.reps[1] - par[1] + 1) / 2, mz = (m.reps[2] - par[2] + 1) / 2;
+        if (int64_t(mx) * my * mz != e - b || int64_t(mx) * my >= (int64_t(1) << 20))
+          return mi::CellLattice{};
+        L.begin[c]        = int32_t(b);
+        rows[c].mx        = mx;
+        rows[c].mxy       = mx * my;
+        rows[c].magic_mx  = (uint64_t(1) << 42) / uint64_t(mx) + 1;
+        rows[c].magic_mxy = (uint64_t(1) << 42) / uint64_t(mx * my) + 1;
+        rows[c].base      = p * (par[0] + m.nn[0] * (par[1] + m.nn[1] * par[2]));
+      }
+    for (int c = m.ncolours; c <= 8; ++c)
+      L.begin[c] = int32_t(m.ncells); // unused colours are empty ranges at the end
+    L.ncol = m.ncolours;
+    // the check: every node of every cell, with the device's arithmetic
+    const int npc = m.npc, np1 = m.np1;
+    for (int64_t pos = 0; pos < m.ncells; ++pos)
+      {
+        int col = 0;
+        for (int c = 1; c < 8; ++c)
+          col += pos >= L.begin[c] ? 1 : 0;
+        const mi::CellLatticeRow &R = rows[size_t(col)];
+        const uint32_t r   = uint32_t(pos - L.begin[col]);
+        const uint32_t rz  = uint32_t((uint64_t(r) * R.magic_mxy) >> 42);
+        const uint32_t rem = r - rz * uint32_t(R.mxy);
+        const uint32_t ry  = uint32_t((uint64_t(rem) * R.magic_mx) >> 42);
+        const uint32_t rx  = rem - ry * uint32_t(R.mx);
+        const int32_t  n0  = R.base + int32_t(rx) * L.sx + int32_t(ry) * L.sy + int32_t(rz) * L.sz;
+        for (int a = 0; a < npc; ++a)
+          {
+            const int i = a % np1, j = (a / np1) % np1, k = a / (np1 * np1);
+            if (m.conn[size_t(pos) * npc + a] != n0 + i + j * L.nn0 + k * L.nn01)
+              return mi::CellLattice{};
+          }
+      }
+    return L;
+  }
+
   mi::AsmParams asm_params(mi_ctx *c)
   {
     mi::AsmParams p{};
+    // node ids by arithmetic: measured 2 % SLOWER in assemble_q2sf (7.93 against 7.79 ms per tangent, same process: three
+    // workgroups per CU already hide the connectivity load), 4 % faster in mf_spmv -- so only the product uses it;
+    // MI_ASM_CELL_LATTICE=1 switches it on here for A/B
+    static const bool asm_lat = getenv("MI_ASM_CELL_LATTICE") && atoi(getenv("MI_ASM_CELL_LATTICE")) != 0;
+    if (asm_lat)
+      p.lat = c->lat;
     p.conn   = c->d_conn;
     p.cverts = c->d_cverts;
     p.off    = c->d_off;
@@ -337,6 +405,7 @@ namespace mi_detail
         f.x       = x;
         f.y       = y;
         f.mass    = c->alpha[1] * c->mat.rho;
+        f.lat     = c->lat;
         const bool one_launch = kind == 2 && c->mf_slots && c->d_mf_yc;
         if (one_launch)
           {
@@ -593,7 +662,7 @@ namespace mi_detail
         return MI_OK;
       }
     c->ke_valid = (c->d_ke || c->d_qrec) &&
-                  !(c->dim == 3 && c->degree == 2 && c->asm_variant != 0 && c->asm_variant != 1 && c->asm_variant != 2 && c->asm_variant != 9);
+                  !(c->dim == 3 && c->degree == 2 && c->asm_variant >= 6 && c->asm_variant <= 8); // timing-only ablations
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -990,7 +1059,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base,
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_lat_rows,
                     c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
                     c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
                     c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};
@@ -1033,6 +1102,20 @@ namespace mi_detail
         return fail(c, MI_EINVAL, "%s", e.what());
       }
     const mi::HostMesh &m = c->mesh;
+    if (m.dim == 3 && m.p == 2) // the kernels that use it (assemble_q2sf, mf_spmv)
+      {
+        std::vector<mi::CellLatticeRow> rows;
+        c->lat_built = build_cell_lattice(m, rows);
+        if (c->lat_built.ncol > 0)
+          {
+            const int rl = upload(c, &c->d_lat_rows, rows);
+            if (rl)
+              return rl;
+            c->lat_built.rows = c->d_lat_rows;
+          }
+        if (!(getenv("MI_CELL_LATTICE") && atoi(getenv("MI_CELL_LATTICE")) == 0))
+          c->lat = c->lat_built;
+      }
     c->n     = m.ndofs;
     c->own0  = c->slab.own_begin * c->dim;
     c->own_n = (c->slab.own_end - c->slab.own_begin) * c->dim;
@@ -2178,6 +2261,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->mf_slots = value;
       else if (k == "xcd_remap" && (value == 0 || value == 1))
         m->xcd_remap = value;
+      else if (k == "cell_lattice" && (value == 0 || value == 1)) // A/B: node ids by arithmetic (1, default) or from conn
+        m->lat = value ? m->lat_built : mi::CellLattice{};
       else if (k == "sell_unroll" && value >= -2 && value <= 8 && value != 0)
         m->sell_unroll = value;
       else if (k == "spmv_grid" && value >= 1 && value + m->grid_spmv_bnd <= MAX_PART)
@@ -2253,6 +2338,8 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
                0;
   else if (k == "mf_single_launch")
     *value = (m->mf_slots && m->d_mf_yc) ? 1 : 0;
+  else if (k == "cell_lattice")
+    *value = m->lat.ncol > 0 ? 1 : 0;
   else if (k == "precond")
     *value = m->precond;
   else if (k == "spmv_variant")

@@ -123,6 +123,9 @@ struct mi_ctx
   int32_t  *d_mf_dst = nullptr;       // ... their slots [ncells][27] ...
   int32_t  *d_mf_slot_base = nullptr; // ... and the first slot of every node [nnodes+1]
   int       mf_slots = 1;             // tuning "mf_single_launch": 1 one launch + gather (default), 0 eight colour launches
+  mi::CellLattice lat;                // 3D Q2: node ids of a cell by arithmetic (ncol == 0: unavailable / switched off)
+  mi::CellLattice lat_built;          // ... as built at creation (tuning "cell_lattice" 0 / 1 switches lat)
+  mi::CellLatticeRow *d_lat_rows = nullptr; // its per-colour rows
   double   *d_cellbox = nullptr; // with d_qrec when every local cell is an axis-parallel box: [ncells][4] = 1/h, volume
   bool      ke_valid = false; // d_ke / d_qrec belong to the current tangent
   int64_t   ebe_products = 0; // element-tangent products so far (profiling samples every 6th)

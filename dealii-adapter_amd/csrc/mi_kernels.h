@@ -5,6 +5,30 @@
 
 namespace mi
 {
+  // Node ids of a cell WITHOUT reading the connectivity (round 4).  The mesh is a lattice: the cell at colour-sorted
+  // position pos belongs to colour col (begin[col] <= pos < begin[col+1]), is the r-th cell (x fastest) of that colour's
+  // sub-lattice of mx x my x mz cells, and its first node is  base + rx sx + ry sy + rz sz;  local node (i, j, k) of a
+  // 3D cell then is  node0 + i + nn0 j + nn01 k.  The two divisions of r are multiplications by floor(2^42 / d) + 1
+  // (exact for r < 2^22, d < 2^20: r e < 2^42 with e = M d - 2^42 <= d), so a workgroup knows its nodes after a handful
+  // of scalar instructions and ONE scalar load of its colour's row (32 bytes of a 256-byte table every workgroup reads:
+  // scalar-cache resident) instead of after a round trip to memory for the connectivity (conn -> values was a chain of
+  // two dependent vector loads at the head of mf_spmv and assemble_q2sf).  Built and checked against conn by
+  // build_cell_lattice (mi_ctx.cpp); ncol == 0: not available (the kernels then read conn).  The per-colour rows live in
+  // device memory, not in the argument block: a by-value table indexed by the colour made the compiler copy the whole
+  // block to scratch at the head of every wave (0.72 instead of 0.40 ms per product, measured).
+  struct CellLatticeRow
+  {
+    int32_t  mx, mxy, base, pad;
+    uint64_t magic_mx, magic_mxy;
+  };
+  struct CellLattice
+  {
+    int32_t               ncol = 0;
+    int32_t               begin[9] = {};
+    int32_t               sx = 0, sy = 0, sz = 0, nn0 = 0, nn01 = 0;
+    const CellLatticeRow *rows = nullptr; // [8] device
+  };
+
   // arguments of assemble_cells / neumann_faces (device pointers unless noted)
   struct AsmParams
   {
@@ -35,6 +59,7 @@ namespace mi
                                 // tangent wave at the phase boundaries of assemble_q2sf (mi_bench_assemble, MI_ASM_STAMPS)
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
+    CellLattice     lat;    // 3D Q2: node ids by arithmetic (ncol == 0: read conn)
   };
 
   // product with the unassembled element tangents (see ebe_spmv in mi_kernels.hip)
@@ -69,6 +94,7 @@ namespace mi
     double         *yc;        // [nslots][3] contributions
     const int32_t  *dst;       // [ncells][27] slot of (cell, local node)
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
+    CellLattice     lat;       // node ids by arithmetic (ncol == 0: read conn)
   };
 
   // constant operators of the linear model (linear_elasticity.cc:248-374), one launch per colour

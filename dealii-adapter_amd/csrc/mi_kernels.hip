@@ -670,6 +670,29 @@ namespace mi
   }
 
 
+  // first node of the cell at colour-sorted position pos, from the lattice description alone (mi::CellLattice): uniform
+  // operands, i.e. scalar instructions and one scalar load -- no vector-memory round trip between a workgroup's start
+  // and its first gather
+  __device__ __forceinline__ int32_t lattice_node0(const CellLattice &L, int64_t pos)
+  {
+    const int32_t p   = int32_t(pos);
+    int           col = 0;
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+      col += (p >= L.begin[c]) ? 1 : 0; // empty trailing colours begin at ncells
+    int32_t begin = L.begin[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c)
+      begin = (p >= L.begin[c]) ? L.begin[c] : begin;
+    const CellLatticeRow R = L.rows[col];
+    const uint32_t r   = uint32_t(p - begin);
+    const uint32_t rz  = uint32_t((uint64_t(r) * R.magic_mxy) >> 42);
+    const uint32_t rem = r - rz * uint32_t(R.mxy);
+    const uint32_t ry  = uint32_t((uint64_t(rem) * R.magic_mx) >> 42);
+    const uint32_t rx  = rem - ry * uint32_t(R.mx);
+    return R.base + int32_t(rx) * L.sx + int32_t(ry) * L.sy + int32_t(rz) * L.sz;
+  }
+
   // ------------------------------------------------------------------ 3D Q2 cell assembly, sum factorised (default)
   // Same element tangent, residual and scatter as assemble_cells, a third of its arithmetic.  With g_a = M^T grad_xi N_a,
   // M = Jinv Finv, every term of the tangent is a bilinear form in the UNIT-CELL gradients:
@@ -698,7 +721,11 @@ namespace mi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                        \
       }                                                                                                               \
     while (0)
-  template <bool RES_ONLY>
+  // XV (A/B experiments of round 4, "asm_variant" 3-5): bit 0 = the role of "wave 0" rotates over the four waves of the
+  // workgroup with the cell index (where wave w of a workgroup always runs on SIMD w, the serial prologues of the
+  // three workgroups of a CU otherwise share one SIMD); bit 1 = later touches of a block are added by no-return
+  // atomics in the L2 instead of load / add / store (colour launches keep the order of the additions: same bits)
+  template <bool RES_ONLY, int XV = 0>
   __global__ __launch_bounds__(RES_ONLY ? 64 : 256, RES_ONLY ? 4 : 3) void assemble_q2sf(AsmParams prm)
   {
     constexpr int NPC = 27, FS = 66, NF = 82; // field stride (padded: fields of different ij on different banks), fields
@@ -709,7 +736,7 @@ namespace mi
     __shared__ int2 s_ri[RES_ONLY ? 1 : NPC]; // rowinfo of the cell's nodes (where their rows are in the global matrix)
     __shared__ int  s_cm[RES_ONLY ? 1 : NPC]; // their constraint bits
     typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
-    const int     tid  = threadIdx.x;
+    const int     tid  = (XV & 1) ? int((((threadIdx.x >> 6) + blockIdx.x) & 3) << 6 | (threadIdx.x & 63)) : int(threadIdx.x);
     const int64_t cell = prm.cell_begin + blockIdx.x;
     // 1D tables (uniform)
     double S[4][3], D[4][3];
@@ -760,9 +787,18 @@ namespace mi
         double       xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
         int32_t      node = 0;
         double       accn[3] = {0.0, 0.0, 0.0};
+        // the cell's nodes: by arithmetic on a lattice (mi::CellLattice; the gathers below are then the wave's first
+        // memory accesses) or from the connectivity
+        const int32_t node0 = prm.lat.ncol > 0 ? lattice_node0(prm.lat, cell) : 0;
         if (lane < NPC)
           {
-            node         = prm.conn[cell * NPC + lane];
+            if (prm.lat.ncol > 0)
+              {
+                const int k9 = lane / 9, r9 = lane - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
+                node         = node0 + i3 + j3 * prm.lat.nn0 + k9 * prm.lat.nn01;
+              }
+            else
+              node = prm.conn[cell * NPC + lane];
             s_conn[lane] = node;
             if constexpr (!RES_ONLY)
               {
@@ -1213,7 +1249,7 @@ namespace mi
               for (int u = 0; u < 9; ++u)
                 {
                   const int  blk = (bb + u) * 28 + tq;
-                  const bool rd  = tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu && !((t[u] >> 42) & 1);
+                  const bool rd  = !(XV & 2) && tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu && !((t[u] >> 42) & 1);
                   old[bb + u]    = rd ? vbase[int64_t(uint32_t(t[u])) * 9] : 0.0;
                 }
             }
@@ -1244,7 +1280,12 @@ namespace mi
                   if ((fl >> 12) & cm)
                     w_ = (((fl >> 11) & 1) && on_diag) ? fabs(w_) : 0.0;
                   if (tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu)
-                    vbase[int64_t(uint32_t(t[u])) * 9] = w_ + old[bb + u];
+                    {
+                      if ((XV & 2) && !((t[u] >> 42) & 1))
+                        unsafeAtomicAdd(&vbase[int64_t(uint32_t(t[u])) * 9], w_);
+                      else
+                        vbase[int64_t(uint32_t(t[u])) * 9] = w_ + old[bb + u];
+                    }
                 }
             }
           if (prm.ke) // the cell's own masked blocks (what entered the global matrix) for the element-tangent product: the
@@ -2110,7 +2151,7 @@ namespace mi
   // contribution array (slot = position of the cell among the cells of the node, in processing order) and ONE launch
   // covers all cells; mf_gather then sums the slots of every node in that order -- the same additions in the same
   // order as the colour-by-colour update, i.e. the same bits, in 2 launches instead of 8.
-  template <bool BOX, bool SLOTS>
+  template <bool BOX, bool SLOTS, bool LAT>
   __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0) // 5 waves per SIMD spill and lose 7 %
   {
     constexpr int NPC = 27;
@@ -2137,7 +2178,26 @@ namespace mi
           return;
         cell = cell0 + local;
       }
-    // the cell's records: issued first, consumed after the gradient passes
+    // LAT: the cell's nodes by arithmetic (mi::CellLattice) -- the gather of x is then the FIRST memory access of the
+    // wave and the records follow it (the memory counter retires loads in order: what is needed first is asked first);
+    // otherwise the records go first and the gather waits for the connectivity
+    int32_t node_l = 0, cm_l = 0; // lane < 27: this lane's node and its constraint bits
+    double  xg[3]  = {0.0, 0.0, 0.0};
+    int32_t node0  = 0;
+    if constexpr (LAT)
+      {
+        node0 = lattice_node0(prm.lat, cell);
+        if (lane < NPC)
+          {
+            const int k9 = lane / 9, r9 = lane - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
+            node_l       = node0 + i3 + j3 * prm.lat.nn0 + k9 * prm.lat.nn01;
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              xg[c] = prm.x[int64_t(node_l) * 3 + c];
+            cm_l = prm.cmask[node_l];
+          }
+      }
+    // the cell's records: consumed after the gradient passes
     double rec[MF_NREC];
     {
       const double *__restrict__ rp = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
@@ -2175,16 +2235,19 @@ namespace mi
     // ---- gather x (constrained entries masked): X[c][a] at c*27 + a, a = (k*3 + j)*3 + i
     if (lane < NPC)
       {
-        const int32_t node = prm.conn[cell * NPC + lane];
-        const int     cm   = prm.cmask[node];
-        s_conn[lane]       = node;
-        s_cm[lane]         = cm;
+        if constexpr (!LAT)
+          {
+            node_l = prm.conn[cell * NPC + lane];
+            cm_l   = prm.cmask[node_l];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              xg[c] = prm.x[int64_t(node_l) * 3 + c];
+          }
+        s_conn[lane] = node_l;
+        s_cm[lane]   = cm_l;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          {
-            const double xv    = prm.x[int64_t(node) * 3 + c];
-            s0[c * NPC + lane] = ((cm >> c) & 1) ? 0.0 : xv;
-          }
+          s0[c * NPC + lane] = ((cm_l >> c) & 1) ? 0.0 : xg[c];
       }
     // the entries of y this lane will update at the very end (lane = line (c,k,j), its three nodes i): read now, the
     // colouring keeps every other cell of this launch away from them
@@ -2197,6 +2260,8 @@ namespace mi
         for (int i = 0; i < 3; ++i)
           if constexpr (SLOTS)
             ydst[i] = prm.dst[cell * NPC + lkj * 3 + i];
+          else if constexpr (LAT)
+            yold[i] = prm.y[int64_t(node0 + i + (lkj % 3) * prm.lat.nn0 + (lkj / 3) * prm.lat.nn01) * 3 + lc];
           else
             yold[i] = prm.y[int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc];
       }
@@ -3899,9 +3964,18 @@ namespace mi
           {
             case 0: // sum factorised (default): 4 waves per cell, 51 kB LDS
               if (p.residual_only)
-                hipLaunchKernelGGL(assemble_q2sf<true>, dim3(p.cell_count), dim3(64), 0, s, p);
+                hipLaunchKernelGGL((assemble_q2sf<true, 0>), dim3(p.cell_count), dim3(64), 0, s, p);
               else
-                hipLaunchKernelGGL(assemble_q2sf<false>, dim3(p.cell_count), dim3(256), 0, s, p);
+                hipLaunchKernelGGL((assemble_q2sf<false, 0>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 3: // A/B (round 4): the prologue's wave rotates with the cell index
+              hipLaunchKernelGGL((assemble_q2sf<false, 1>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 4: // A/B (round 4): later touches by L2 atomics
+              hipLaunchKernelGGL((assemble_q2sf<false, 2>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 5: // A/B (round 4): both
+              hipLaunchKernelGGL((assemble_q2sf<false, 3>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
             case 9: // node-pair form (the default until round 2): 16.4 ms per assembly at 5 M DoFs
               launch_asm_sel<3, 2, 2, 256, 8>(p, s);
@@ -4084,8 +4158,11 @@ namespace mi
     q.count               = cell_count;
     q.xcd_chunk           = xcd ? (cell_count + 7) / 8 : 0;
     const int grid        = xcd ? q.xcd_chunk * 8 : cell_count;
-    auto *kern = q.yc ? (q.cellbox ? mf_spmv<true, true> : mf_spmv<false, true>) :
-                        (q.cellbox ? mf_spmv<true, false> : mf_spmv<false, false>);
+    auto *kern = q.lat.ncol > 0 ?
+                   (q.yc ? (q.cellbox ? mf_spmv<true, true, true> : mf_spmv<false, true, true>) :
+                           (q.cellbox ? mf_spmv<true, false, true> : mf_spmv<false, false, true>)) :
+                   (q.yc ? (q.cellbox ? mf_spmv<true, true, false> : mf_spmv<false, true, false>) :
+                           (q.cellbox ? mf_spmv<true, false, false> : mf_spmv<false, false, false>));
     if (ev_start || ev_stop)
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, q, cell_begin);
     else

@@ -150,6 +150,17 @@ def test_gpu_config4_three_steps_default_path(start):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,slabs,cut_axis", [("cfg4s", 8, 0), ("cfg4s", 4, 1), ("cfg3", 8, 0)])
+def test_gpu_baseline_configurations_decomposed_against_the_oracle(name, slabs, cut_axis):
+    """BASELINE configuration 4 IS a decomposed run ("domain-decomposed 8 x MI355X"): the headline block on 8 slabs
+    (automatic cut direction) and on 4 slabs cut along x (the lattice lies rotated over the box), configuration 3 on 8
+    slabs -- three ramp steps each with the executable's start vectors, against the oracle's steps, not against the
+    undecomposed run (emulated slabs: the same halo / all-reduce choreography on one GPU)
+    [REF nonlinear_elasticity.cc:410-499; adapter.h:152-154: the reference itself is single rank]"""
+    _nonlinear(name, 1e-8, 1e-6, 2, slabs=slabs, cut_axis=cut_axis)
+
+
+@pytest.mark.gpu
 def test_gpu_config4_at_the_shipped_linear_tolerance():
     """what bench.py times -- configuration 4, "Residual" = 1e-6 as shipped (parameters.prm:51), the executable's solver
     policies -- against the oracle's steps at 1e-10: the same Newton tables, displacements to 1e-5 (with the
