@@ -2410,6 +2410,43 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_launch = double(ms) / std::max(1, reps);
+  if (getenv("MI_MF_STAMPS") && c->spmv_variant == 4 && element_form(c) == 2 && c->mf_slots && c->d_mf_yc && c->d_cellbox)
+    {
+      // diagnostic: where a wavefront of the matrix-free product spends its life (shader-clock stamps of lane 0 at the
+      // stage boundaries), averaged over all cells of one launch
+      const int64_t       ncell = c->mesh.ncells;
+      unsigned long long *d_st  = nullptr;
+      HIPCHK(c, hipMalloc((void **)&d_st, size_t(ncell) * 8 * sizeof(unsigned long long)));
+      HIPCHK(c, hipMemsetAsync(d_st, 0, size_t(ncell) * 8 * sizeof(unsigned long long), c->stream));
+      mi::MfParams f{};
+      f.qrec = c->d_qrec, f.conn = c->d_conn, f.first = c->d_node_first, f.cmask = c->d_cmask, f.vals = c->d_vals;
+      f.diagpos = c->d_diagpos, f.tab1d = c->d_tab, f.cverts = c->d_cverts, f.mu = c->mat.mu, f.kappa = c->kappa;
+      f.cellbox = c->d_cellbox, f.x = c->work(W_P), f.y = c->work(W_Q), f.mass = c->alpha[1] * c->mat.rho, f.lat = c->lat;
+      f.yc = c->d_mf_yc, f.dst = c->d_mf_dst, f.slot_base = c->d_mf_slot_base, f.stamps = d_st;
+      mi::launch_mf_spmv(f, 0, int32_t(ncell), c->stream);
+      std::vector<unsigned long long> st(size_t(ncell) * 8);
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      HIPCHK(c, hipMemcpy(st.data(), d_st, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      hipFree(d_st);
+      double             sum[5] = {0, 0, 0, 0, 0};
+      unsigned long long tmin = ~0ull, tmax = 0;
+      for (int64_t e = 0; e < ncell; ++e)
+        {
+          for (int i = 0; i < 5; ++i)
+            sum[i] += double(st[size_t(e) * 8 + i + 1] - st[size_t(e) * 8 + i]);
+          tmin = std::min(tmin, st[size_t(e) * 8]);
+          tmax = std::max(tmax, st[size_t(e) * 8 + 5]);
+        }
+      const char *name[5] = {"start -> x gathered", "E1-E3 (gradients at the points)", "point stage (incl. wait for the records)",
+                             "I3 + I2", "I1 + stores issued"};
+      double      tot     = 0;
+      for (int i = 0; i < 5; ++i)
+        tot += sum[i];
+      fprintf(stderr, "mf_spmv stages (%lld cells; launch spans %.0f ticks; %.0f ticks per wave):\n", (long long)ncell,
+              double(tmax - tmin), tot / double(ncell));
+      for (int i = 0; i < 5; ++i)
+        fprintf(stderr, "  %-42s %8.0f ticks  %5.1f %%\n", name[i], sum[i] / double(ncell), 100.0 * sum[i] / tot);
+    }
   return MI_OK;
 }
 

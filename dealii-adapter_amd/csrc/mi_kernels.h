@@ -95,6 +95,7 @@ namespace mi
     const int32_t  *dst;       // [ncells][27] slot of (cell, local node)
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
     CellLattice     lat;       // node ids by arithmetic (ncol == 0: read conn)
+    unsigned long long *stamps; // diagnostic (null in production): [cells][8] shader-clock stamps at the stage boundaries
   };
 
   // constant operators of the linear model (linear_elasticity.cc:248-374), one launch per colour

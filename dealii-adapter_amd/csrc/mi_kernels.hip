@@ -2151,9 +2151,12 @@ namespace mi
   // contribution array (slot = position of the cell among the cells of the node, in processing order) and ONE launch
   // covers all cells; mf_gather then sums the slots of every node in that order -- the same additions in the same
   // order as the colour-by-colour update, i.e. the same bits, in 2 launches instead of 8.
-  template <bool BOX, bool SLOTS, bool LAT>
+  // DBG (diagnostic instantiations, never in production): bit 0 stage stamps; timing-only ablations: bit 1 no result
+  // stores, bit 2 every cell reads the records of cell 0 (cache hits), bit 3 every cell gathers the x of cell 0's nodes
+  template <bool BOX, bool SLOTS, bool LAT, int DBG = 0>
   __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0) // 5 waves per SIMD spill and lose 7 %
   {
+    constexpr bool STAMP = (DBG & 1) != 0;
     constexpr int NPC = 27;
     // LDS (per cell, 7.9 kB): s0 = x (81 at 0) and the i-contracted lines A (2 x 108 at AO), then the (i,j)-contracted
     // planes B (3 x 9 x 20 at 0; plane stride 20 and the lane order (c*3+k)*4 + qx keep their stores conflict free), then
@@ -2178,6 +2181,17 @@ namespace mi
           return;
         cell = cell0 + local;
       }
+    // diagnostic instantiation: shader-clock stamps at the stage boundaries, kept in LDS until the end (a global store
+    // in the middle of the kernel makes the compiler give up the scalar registers of the 1D tables)
+    __shared__ unsigned long long s_st[STAMP ? 8 : 1];
+#define MF_STAMP(i_)                                                                     \
+  do                                                                                     \
+    {                                                                                    \
+      if constexpr (STAMP)                                                               \
+        if (lane == 0)                                                                   \
+          s_st[(i_)] = __builtin_amdgcn_s_memtime();                                     \
+    }                                                                                    \
+  while (0)
     // LAT: the cell's nodes by arithmetic (mi::CellLattice) -- the gather of x is then the FIRST memory access of the
     // wave and the records follow it (the memory counter retires loads in order: what is needed first is asked first);
     // otherwise the records go first and the gather waits for the connectivity
@@ -2186,7 +2200,7 @@ namespace mi
     int32_t node0  = 0;
     if constexpr (LAT)
       {
-        node0 = lattice_node0(prm.lat, cell);
+        node0 = lattice_node0(prm.lat, (DBG & 8) ? int64_t(0) : cell);
         if (lane < NPC)
           {
             const int k9 = lane / 9, r9 = lane - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
@@ -2200,7 +2214,7 @@ namespace mi
     // the cell's records: consumed after the gradient passes
     double rec[MF_NREC];
     {
-      const double *__restrict__ rp = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
+      const double *__restrict__ rp = prm.qrec + ((DBG & 4) ? int64_t(0) : cell) * int64_t(MF_NREC * 64) + lane;
 #pragma unroll
       for (int f = 0; f < MF_NREC; ++f)
         rec[f] = __builtin_nontemporal_load(&rp[f * 64]);
@@ -2232,6 +2246,17 @@ namespace mi
         xiq[1] = prm.tab1d[28 + ((lane >> 2) & 3)];
         xiq[2] = prm.tab1d[28 + qz];
       }
+    // the cell's geometry (BOX): 1/hx, 1/hy, 1/hz, hx hy hz -- uniform, scalar loads
+    double cbox[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (BOX)
+      {
+        const double *__restrict__ cb = prm.cellbox + cell * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          cbox[k] = cb[k];
+      }
+    MF_STAMP(0); // (after every uniform load: the clock read is a scalar-memory instruction with side effects, and loads
+                 // behind it would no longer be scalar)
     // ---- gather x (constrained entries masked): X[c][a] at c*27 + a, a = (k*3 + j)*3 + i
     if (lane < NPC)
       {
@@ -2266,6 +2291,7 @@ namespace mi
             yold[i] = prm.y[int64_t(prm.conn[cell * NPC + lkj * 3 + i]) * 3 + lc];
       }
     __syncthreads();
+    MF_STAMP(1); // x has arrived
     // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at AO + {0,108} + qx*27 + lane
     if (lane < 27)
       {
@@ -2313,9 +2339,10 @@ namespace mi
           }
       }
     __syncthreads(); // B is consumed: the point results go on top of it
+    MF_STAMP(2); // gradients at the points
     if constexpr (BOX) // the mass term first: it needs only the cell's volume, and V dies before the tensor algebra
       {
-        const double wm = prm.mass * prm.cellbox[cell * 4 + 3] * wq;
+        const double wm = prm.mass * cbox[3] * wq;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           s0[(i * 4 + 3) * 64 + (lane ^ ((i & 1) << 4))] = wm * V[i];
@@ -2329,9 +2356,8 @@ namespace mi
         neo_hooke_from_F<3>(F, det3x3(F), rec[9], rec[10], prm.mu, prm.kappa, Finv, tau, tiso, cII, cS);
         if constexpr (BOX)
           {
-            const double *__restrict__ cb = prm.cellbox + cell * 4; // 1/hx, 1/hy, 1/hz, hx hy hz (uniform: scalar loads)
-            const double rx = cb[0], ry = cb[1], rz = cb[2];
-            detJ            = cb[3];
+            const double rx = cbox[0], ry = cbox[1], rz = cbox[2];
+            detJ            = cbox[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
               {
@@ -2397,6 +2423,7 @@ namespace mi
         }
     }
     __syncthreads();
+    MF_STAMP(3); // point stage (waits for the records)
     // ---- I3: contract qz.  lane = c*16 + (qy*4+qx); C_DS / C_SD / C_SS [c][k][qy][qx] replace Q[c][0 / 1 / 2][z = k][qy][qx],
     // entries only this lane has read
     if (lane < 48)
@@ -2457,6 +2484,7 @@ namespace mi
           }
       }
     __syncthreads();
+    MF_STAMP(4); // I3 + I2
     // ---- I1: contract qx and update y.  lane = line (c,k,j)
     if (lane < 27)
       {
@@ -2480,7 +2508,8 @@ namespace mi
               }
             if constexpr (SLOTS)
               {
-                prm.yc[int64_t(ydst[i]) * 3 + lc] = yv;
+                if (!(DBG & 2) || yv == 1.2345678e300)
+                  prm.yc[int64_t(ydst[i]) * 3 + lc] = yv;
                 continue;
               }
             const int     a     = lkj * 3 + i;
@@ -2498,6 +2527,14 @@ namespace mi
               prm.y[yi] = first ? yv : yold[i] + yv;
           }
       }
+    MF_STAMP(5); // I1 and the stores issued
+    if constexpr (STAMP)
+      {
+        __syncthreads();
+        if (lane < 6)
+          prm.stamps[cell * 8 + lane] = s_st[lane];
+      }
+#undef MF_STAMP
   }
 
   // y = sum of the cells' contributions, node by node in slot order (= processing order of the cells: the order of the
@@ -4163,6 +4200,12 @@ namespace mi
                            (q.cellbox ? mf_spmv<true, false, true> : mf_spmv<false, false, true>)) :
                    (q.yc ? (q.cellbox ? mf_spmv<true, true, false> : mf_spmv<false, true, false>) :
                            (q.cellbox ? mf_spmv<true, false, false> : mf_spmv<false, false, false>));
+    if (q.stamps) // diagnostic: the production shape only (boxes, one launch, lattice ids or not)
+      kern = q.lat.ncol > 0 ? mf_spmv<true, true, true, 1> : mf_spmv<true, true, false, 1>;
+    static const int dbg = getenv("MI_MF_DBG") ? atoi(getenv("MI_MF_DBG")) : 0; // timing-only ablations (wrong results)
+    if (dbg && q.yc && q.cellbox && q.lat.ncol > 0)
+      kern = dbg == 2 ? mf_spmv<true, true, true, 2> : dbg == 4 ? mf_spmv<true, true, true, 4> : dbg == 8 ? mf_spmv<true, true, true, 8> :
+             dbg == 14 ? mf_spmv<true, true, true, 14> : dbg == 6 ? mf_spmv<true, true, true, 6> : kern;
     if (ev_start || ev_stop)
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, q, cell_begin);
     else
