@@ -118,7 +118,8 @@ def cpu_baseline_worker(cells, its_a, its_b, full):
         t0 = time.perf_counter()
         P.assemble()
         out["t_assembly_s"] = time.perf_counter() - t0
-        for key, solver in (("A_cg_ssor", O.SOLVER_CG_SSOR), ("B_cg_jacobi", O.SOLVER_CG_JACOBI)):
+        print(json.dumps(out), file=sys.stderr, flush=True)
+        for key, solver in (("B_cg_jacobi", O.SOLVER_CG_JACOBI), ("A_cg_ssor", O.SOLVER_CG_SSOR)):  # the short one first
             P.vec(O.V_NEWTON)[:] = 0.0
             t0 = time.perf_counter()
             rc, its, res = P.solve_linear(solver, tol_lin=1e-6, max_it_mult=1.0)
@@ -148,68 +149,89 @@ def cpu_baseline_worker(cells, its_a, its_b, full):
     print(json.dumps(out))
 
 
-def cpu_baseline(cells, its_a, its_b):
-    """bounded CPU sample on the metric's neighbouring configuration 3 (34^3 Q2 cells), one pinned socket.  Per-unit
-    times are measured live; the unit counts of a whole step (assemblies, CG iterations -- deterministic for this
-    algorithm) come from the full run of the same code committed in profiles/r02/cpu_baseline_config3_full.json"""
-    small = cells <= 12  # seconds of CPU work: time the whole step instead of a sample
-    p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker",
-                        "%d,%d,%d,%d" % (cells, its_a, its_b, 1 if small else 0)], capture_output=True, text=True, timeout=1500)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    if p.returncode != 0 or not lines:
-        return {"value": None, "unit": "DoF-updates/s", "cores": 0, "kind": "port",
-                "sample": "CPU sample failed: " + (p.stderr or p.stdout)[-300:]}
-    s = json.loads(lines[-1])
-    if small:
-        a, b = s["A_cg_ssor"], s["B_cg_jacobi"]
-        return {"value": a["dof_updates_per_s"], "value_cg_jacobi": b["dof_updates_per_s"], "unit": "DoF-updates/s",
-                "cores": s["cores"], "threads": s["threads"], "kind": "port", "cpu_model": s["cpu_model"],
-                "pinned_cpus": s["pinned_cpus"], "n_dofs": s["n_dofs"],
-                "sample": "whole first Newmark step of a 3D Q2 block %d^3 cells (%d DoFs) on ONE pinned socket (%s, %d cores): (A) "
-                          "CG+SSOR(0.65) %d Newton / %d CG iterations in %.2f s, (B) CG+Jacobi %d / %d in %.2f s; restatement "
-                          "of the reference algorithm (oracle/), not the deal.II binary"
-                          % (cells, s["n_dofs"], s["cpu_model"], s["cores"], a["newton_iterations"], a["cg_iterations"],
-                             a["t_step_s"], b["newton_iterations"], b["cg_iterations"], b["t_step_s"])}
-    counts = None
-    if os.path.exists(CPU_FULL_RUN):
-        full = json.load(open(CPU_FULL_RUN))
-        if full.get("cells") == cells and "A_cg_ssor" in full:
-            counts = full
-    ta, tia, tib = s["t_assembly_s"], s["A_cg_ssor"]["t_per_iteration_s"], s["B_cg_jacobi"]["t_per_iteration_s"]
-    out = {"unit": "DoF-updates/s", "cores": s["cores"], "kind": "port", "threads": s["threads"],
-           "cpu_model": s["cpu_model"], "pinned_cpus": s["pinned_cpus"], "config": "3 (34^3 Q2 cells)" if cells == 34 else
-           "%d^3 Q2 cells" % cells, "n_dofs": s["n_dofs"], "t_assembly_s": ta, "t_cg_ssor_iteration_s": tia,
-           "t_cg_jacobi_iteration_s": tib}
-    what = ("BASELINE configuration 3 (3D Q2 block %d^3 cells, %d DoFs, %d nnz), first ramp step, ONE socket pinned (%s, %d "
-            "cores, %d threads): measured live = 1 assembly (%.1f s, threaded over cells, ordered scatter), %d CG+SSOR(0.65) "
-            "iterations (%.2f s each; SSOR sweeps serial as in deal.II), %d CG+Jacobi iterations (%.3f s each)"
-            % (cells, s["n_dofs"], s["nnz"], s["cpu_model"], s["cores"], s["threads"], ta,
-               s["A_cg_ssor"]["iterations_timed"], tia, s["B_cg_jacobi"]["iterations_timed"], tib))
-    if counts:
-        a, b = counts["A_cg_ssor"], counts["B_cg_jacobi"]
-        t_a = a["assemblies"] * ta + a["cg_iterations"] * tia
-        t_b = b["assemblies"] * ta + b["cg_iterations"] * tib
-        out["value"] = s["n_dofs"] / t_a
-        out["value_cg_jacobi"] = s["n_dofs"] / t_b
-        out["step_estimate_s"] = {"A_cg_ssor": t_a, "B_cg_jacobi": t_b}
-        out["full_run"] = {"file": os.path.relpath(CPU_FULL_RUN, ROOT), "A_t_step_s": a["t_step_s"], "B_t_step_s": b["t_step_s"],
-                           "A_dof_updates_per_s": a["dof_updates_per_s"], "B_dof_updates_per_s": b["dof_updates_per_s"]}
-        what += ("; value = DoFs / (assemblies x t_assembly + CG iterations x t_iteration) with the step's unit counts from the "
-                 "full run of the same code in %s: (A) CG+SSOR %d assemblies + %d iterations (that run: %.0f s per step), "
-                 "(B) CG+Jacobi %d + %d (%.0f s)" % (os.path.relpath(CPU_FULL_RUN, ROOT), a["assemblies"], a["cg_iterations"],
-                                                     a["t_step_s"], b["assemblies"], b["cg_iterations"], b["t_step_s"]))
+def _run_cpu_worker(spec, timeout_s):
+    """one pinned CPU child; returns (last complete JSON object or None, last partial object from stderr or None, note)"""
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec], capture_output=True, text=True,
+                           timeout=max(1.0, timeout_s))
+        out, err, note = p.stdout, p.stderr, "" if p.returncode == 0 else "exit code %d: %s" % (p.returncode, (p.stderr or "")[-200:])
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+        err = e.stderr.decode() if isinstance(e.stderr, bytes) else (e.stderr or "")
+        note = "stopped by the wall-clock guard after %.0f s" % timeout_s
+    full = [l for l in out.splitlines() if l.startswith("{")]
+    part = [l for l in err.splitlines() if l.startswith("{")]
+    return (json.loads(full[-1]) if full else None), (json.loads(part[-1]) if part else None), note
+
+
+def cpu_baseline(cells, its_a, its_b, budget_s, config4):
+    """CPU leg of the bench line, measured LIVE in a child pinned to one socket:
+      * BASELINE configuration 3 (cells = 34): the WHOLE first Newmark step with (A) CG+SSOR(0.65), as the reference
+        configures it, and (B) CG+Jacobi -- ~200 s on a 64-core socket;
+      * BASELINE configuration 4 (59^3 cells, the metric's own mesh): ONE Newton iteration (one assembly + one linear
+        solve from zero with (A) and with (B)) -- ~310 s.
+    `budget_s` (MI_BENCH_CPU_BUDGET_S, default 900) is a wall-clock guard over both: a leg that would not fit is
+    replaced by the bounded sample of round 3 (one assembly, its_a / its_b iterations, scaled with the step's unit
+    counts from the committed full run) resp. skipped, and `sample` says so.  Nothing here is read from a committed file
+    unless the guard fired."""
+    t_begin = time.time()
+    left = lambda: budget_s - (time.time() - t_begin)
+    small = cells <= 12  # seconds of CPU work
+    full, part, note = _run_cpu_worker("%d,%d,%d,1" % (cells, its_a, its_b), left() if not small else 600)
+    label = "3 (34^3 Q2 cells)" if cells == 34 else "%d^3 Q2 cells" % cells
+    if full and full.get("A_cg_ssor", {}).get("rc") == 0 and full.get("B_cg_jacobi", {}).get("rc") == 0:
+        s, a, b = full, full["A_cg_ssor"], full["B_cg_jacobi"]
+        out = {"value": a["dof_updates_per_s"], "value_cg_jacobi": b["dof_updates_per_s"], "unit": "DoF-updates/s",
+               "cores": s["cores"], "threads": s["threads"], "kind": "port", "cpu_model": s["cpu_model"],
+               "pinned_cpus": s["pinned_cpus"], "config": label, "n_dofs": s["n_dofs"], "live": True,
+               "A_cg_ssor": a, "B_cg_jacobi": b,
+               "sample": "LIVE in this run: the whole first Newmark step of BASELINE configuration %s = 3D Q2 block %d^3 cells (%d DoFs, "
+                         "%d nnz) on ONE pinned socket (%s, %d cores, %d threads): (A) CG+SSOR(0.65) as the reference configures it "
+                         "(nonlinear_elasticity.cc:1180-1182; sweeps serial as in deal.II) %d Newton iterations / %d assemblies / %d CG "
+                         "iterations in %.1f s (assembly %.1f s, solves %.1f s), (B) CG+Jacobi %d / %d / %d in %.1f s; assembly threaded "
+                         "over cells with ordered scatter; restatement of the reference algorithm (oracle/), not the deal.II binary"
+                         % (label, cells, s["n_dofs"], s["nnz"], s["cpu_model"], s["cores"], s["threads"], a["newton_iterations"],
+                            a["assemblies"], a["cg_iterations"], a["t_step_s"], a["t_assemble_s"], a["t_solve_s"],
+                            b["newton_iterations"], b["assemblies"], b["cg_iterations"], b["t_step_s"])}
     else:
-        out["value"] = None
-        what += "; no committed full run for this size: per-unit times only"
-    out["sample"] = what + "; restatement of the reference algorithm (oracle/), not the deal.II binary"
-    c4 = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config4_one_newton_iteration.json")
-    if os.path.exists(c4):
-        # committed one-off run on the metric's own mesh (BASELINE.md section 2: one Newton iteration of configuration 4)
-        f = json.load(open(c4))
-        out["config4_one_newton_iteration_committed"] = {
-            "file": os.path.relpath(c4, ROOT), "n_dofs": f["n_dofs"], "cores": f["cores"], "t_assembly_s": f["t_assembly_s"],
-            "A_cg_ssor_s": f["A_cg_ssor"]["t_newton_iteration_s"], "A_cg_iterations": f["A_cg_ssor"]["cg_iterations"],
-            "B_cg_jacobi_s": f["B_cg_jacobi"]["t_newton_iteration_s"], "B_cg_iterations": f["B_cg_jacobi"]["cg_iterations"]}
+        # the guard fired (or the child failed): the bounded sample of round 3, scaled with committed unit counts
+        s, _, note2 = _run_cpu_worker("%d,%d,%d,0" % (cells, its_a, its_b), max(120.0, left()))
+        if not s:
+            return {"value": None, "unit": "DoF-updates/s", "cores": 0, "kind": "port", "live": False,
+                    "sample": "CPU leg failed: full step: %s; sample: %s" % (note, note2)}
+        ta, tia, tib = s["t_assembly_s"], s["A_cg_ssor"]["t_per_iteration_s"], s["B_cg_jacobi"]["t_per_iteration_s"]
+        out = {"unit": "DoF-updates/s", "cores": s["cores"], "kind": "port", "threads": s["threads"], "cpu_model": s["cpu_model"],
+               "pinned_cpus": s["pinned_cpus"], "config": label, "n_dofs": s["n_dofs"], "live": False, "t_assembly_s": ta,
+               "t_cg_ssor_iteration_s": tia, "t_cg_jacobi_iteration_s": tib, "value": None}
+        what = ("FALLBACK (the whole-step CPU leg did not fit the wall-clock guard of %.0f s: %s): bounded sample of configuration %s "
+                "on ONE pinned socket (%s, %d cores): 1 assembly %.1f s, %d CG+SSOR iterations %.2f s each, %d CG+Jacobi iterations "
+                "%.3f s each" % (budget_s, note, label, s["cpu_model"], s["cores"], ta, s["A_cg_ssor"]["iterations_timed"], tia,
+                                 s["B_cg_jacobi"]["iterations_timed"], tib))
+        if os.path.exists(CPU_FULL_RUN) and json.load(open(CPU_FULL_RUN)).get("cells") == cells:
+            c = json.load(open(CPU_FULL_RUN))
+            a, b = c["A_cg_ssor"], c["B_cg_jacobi"]
+            out["value"] = s["n_dofs"] / (a["assemblies"] * ta + a["cg_iterations"] * tia)
+            out["value_cg_jacobi"] = s["n_dofs"] / (b["assemblies"] * ta + b["cg_iterations"] * tib)
+            what += ("; scaled with the unit counts of the committed full run %s ((A) %d assemblies + %d iterations, (B) %d + %d)"
+                     % (os.path.relpath(CPU_FULL_RUN, ROOT), a["assemblies"], a["cg_iterations"], b["assemblies"], b["cg_iterations"]))
+        out["sample"] = what + "; restatement of the reference algorithm (oracle/), not the deal.II binary"
+    if config4 and not small:
+        # the metric's own mesh: one Newton iteration (BASELINE.md section 2), with what is left of the budget
+        if left() < 60:
+            out["config4_one_newton_iteration"] = {"live": False, "note": "skipped: %.0f s of the CPU budget left" % left()}
+        else:
+            f, part4, note4 = _run_cpu_worker("59,0,0,2", left())
+            got = f or part4  # (the child reports after every phase on stderr: a guard that fires late keeps the phases done)
+            if got:
+                got["live"] = True
+                got["complete"] = bool(f)
+                if note4:
+                    got["note"] = note4
+                out["config4_one_newton_iteration"] = got
+            else:
+                out["config4_one_newton_iteration"] = {"live": False, "note": note4 or "no output"}
+    out["wall_s"] = time.time() - t_begin
+    out["budget_s"] = budget_s
     return out
 
 
@@ -266,10 +288,10 @@ def main():
     ap.add_argument("--cpu-cells", type=int, default=34,
                     help="cells per side of the CPU-baseline sample (34 = BASELINE configuration 3; 0: skip)")
     ap.add_argument("--cpu-its", type=str, default="8,30", help="CG iterations timed by the CPU sample: SSOR,Jacobi")
-    ap.add_argument("--cpu-config4", action="store_true",
-                    help="also run the CPU leg on the metric's own mesh (BASELINE configuration 4, 59^3 cells): ONE Newton iteration = "
-                         "one assembly + CG+SSOR and CG+Jacobi solves, ~6 minutes on a 64-core socket; reproduces the constants "
-                         "committed in profiles/r02/cpu_baseline_config4_one_newton_iteration.json inside a driver run")
+    ap.add_argument("--no-cpu-config4", action="store_true",
+                    help="skip the CPU leg on the metric's own mesh (BASELINE configuration 4, 59^3 cells: ONE Newton iteration = one "
+                         "assembly + CG+Jacobi and CG+SSOR solves, ~5 minutes on a 64-core socket), which the default run includes")
+    ap.add_argument("--cpu-config4", action="store_true", help=argparse.SUPPRESS)  # (round 3's opt-in; now the default)
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -395,7 +417,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "nonlinear_elasticity 3D Q2 neo-Hookean block %dx%dx%d cells, %d DoFs, %d nnz, "
-                            "Newton+Newmark, %s-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005"
+                            "Newton+Newmark, %s-PCG Residual=%g, traction (0,-2e3,0) Pa ramped over 10 steps, dt=0.005; "
+                            "boundary roles: face x- clamped (all components, boundary id 1 of the reference), the other FIVE "
+                            "faces x+ y- y+ z- z+ are the coupling interface (id 7) and carry the traction -- no out-of-plane clamp "
+                            "(id 8) on z+-: SURVEY 8d's 'choose and state'"
                             % (n, n, nz, G.n, G.nnz, "multigrid" if args.precond == "mg" else "Jacobi", args.tol_lin),
                 "preconditioner": "geometric multigrid V-cycle (Chebyshev block-Jacobi smoothing, re-assembled coarse levels; Q2 "
                                   "and Q1 levels of the fine cells distributed over the slabs, coarser levels replicated)"
@@ -403,9 +428,11 @@ def main():
                 "preconditioner_storage": args.precond_storage,
                 "n_dofs": G.n,
                 "nnz": G.nnz,
-                "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs emulated on one GPU" % args.slabs) if world == 1 else
+                "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs cut along %s, emulated on one GPU"
+                                  % (args.slabs, " xyz"[G.get_tuning("cut_axis")])) if world == 1 else
                 ("%d independent replicas (--no-rccl diagnostic)" % world if replicas else
-                 "%d z-slabs (one per GPU), ghost-cell redundant assembly, RCCL send/recv halo + all-reduce" % world),
+                 "%d slabs cut along %s (one per GPU; automatic choice: the direction with most cell layers, ties -> z), ghost-cell "
+                 "redundant assembly, RCCL send/recv halo + all-reduce" % (world, " xyz"[G.get_tuning("cut_axis")])),
                 "team_size": R["comm"][0],
                 "rccl_ranks": R["comm"][1],
                 "newton_iterations_per_step": R["newton"] / args.steps,
@@ -624,14 +651,15 @@ def main():
             del S
         else:
             gpu_same = {"value": out["value"], "ms_per_step": out["ms_per_step"], "n_dofs": out["config"]["n_dofs"]}
-        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, its_a, its_b)
+        budget = float(os.environ.get("MI_BENCH_CPU_BUDGET_S", "900"))
+        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, its_a, its_b, budget, not args.no_cpu_config4 and n == 59)
         out["cpu_baseline"]["gpu_same_config"] = gpu_same
-        if args.cpu_config4:
-            p4 = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "59,0,0,2"], capture_output=True,
-                                text=True, timeout=3000)
-            l4 = [l for l in p4.stdout.splitlines() if l.startswith("{")]
-            out["cpu_baseline"]["config4_one_newton_iteration_live"] = json.loads(l4[-1]) if (p4.returncode == 0 and l4) else {
-                "error": (p4.stderr or p4.stdout)[-300:]}
+        c4 = out["cpu_baseline"].get("config4_one_newton_iteration")
+        if c4 and c4.get("live") and "t_assembly_s" in c4:
+            # the GPU's first Newton iteration of a step on the same mesh: one tangent assembly + the first solve's share
+            c4["gpu_first_newton_iteration_ms_estimate"] = (
+                out["config"]["ms_assemble_cells_per_assembly"] +
+                out["config"]["ms_cg_per_step"] / max(out["config"]["newton_iterations_per_step"], 1))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -490,7 +490,7 @@ namespace mi_detail
   // the team's communication stream) while the interior rows are computed; the boundary rows follow it.
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
                 const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother,
-                const ChebFusion *cheb)
+                const ChebFusion *cheb, bool ghosts_current)
   {
     auto launch = [&](int part) {
       for (size_t k = 0; k < T.members.size(); ++k)
@@ -501,7 +501,7 @@ namespace mi_detail
                        cheb ? &cheb[k] : nullptr);
         }
     };
-    if (T.size == 1)
+    if (T.size == 1 || (ghosts_current && T.halo_skip)) // (all rows in one launch where the kernel splits them)
       {
         launch(0);
         return MI_OK;
@@ -781,7 +781,8 @@ namespace mi_detail
 
   // Jacobi-PCG (deal.II SolverCG semantics: start from x, stop when ||r||_2 <= tolerance) on the active matrix of
   // every slab of the team; followed by constraints.distribute (x[constrained] = 0)
-  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero, bool scale_start)
+  int cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero, bool scale_start,
+             int expected_its)
   {
     Team      &T    = *c->team;
     mi_ctx    *c0   = T.members[0];
@@ -865,7 +866,10 @@ namespace mi_detail
         return MI_OK;
       }
     // z = M^-1 r by the team-wide V-cycle, then the partials of r.z (and their team totals)
-    auto precondition = [&]() -> int {
+    // with_rr: the team total of ||r||^2 (partials of the last update) travels in the same all-reduce -- the iterations
+    // whose V-cycle is enqueued before their convergence test is known (see `speculate` below); with_init: ... and |b|^2
+    // of the initial residual (nobody needs either before the first V-cycle has run)
+    auto precondition = [&](bool with_rr, bool with_init) -> int {
       int e = mg_apply(T);
       if (e)
         return e;
@@ -874,10 +878,10 @@ namespace mi_detail
           mi_ctx *m = T.members[k];
           mi::launch_dot_partials(cgs[k].r, cgs[k].z, m->own_n, cgs[k].part_rz, m->grid_vec, m->stream);
           if (dist)
-            mi::launch_reduce_to_totals(cgs[k].part_rz, m->grid_vec, m->d_sc + SC_TOT + 1, nullptr, 0, nullptr, nullptr,
-                                        m->stream);
+            mi::launch_reduce_to_totals(cgs[k].part_rz, m->grid_vec, m->d_sc + SC_TOT + 1, with_rr ? cgs[k].part_rr : nullptr,
+                                        m->grid_vec, m->d_sc + SC_TOT, with_init ? nullptr : cgs[k].flags, m->stream);
         }
-      return team_allreduce(T, SC_TOT + 1, 1);
+      return with_init ? team_allreduce(T, SC_TOT, 4) : with_rr ? team_allreduce(T, SC_TOT, 2) : team_allreduce(T, SC_TOT + 1, 1);
     };
     const int64_t batch = use_mg ? 1 : CG_BATCH; // a V-cycle costs ~5 SpMVs: poll every iteration, never waste one
     auto         x_of = [x_id](mi_ctx *m) { return m->vec(x_id); };
@@ -919,15 +923,16 @@ namespace mi_detail
         mi::launch_cg_init_residual(cgs[k], m->vec(b_id) + m->own0, m->part(4), m->grid_vec, m->stream);
         if (dist)
           {
-            mi::launch_reduce_to_totals(cgs[k].part_rr, m->grid_vec, m->d_sc + SC_TOT, cgs[k].part_rz, m->grid_vec,
-                                        m->d_sc + SC_TOT + 1, nullptr, m->stream);
+            if (!use_mg) // (multigrid: ||r0||^2 joins r.z after the first V-cycle)
+              mi::launch_reduce_to_totals(cgs[k].part_rr, m->grid_vec, m->d_sc + SC_TOT, cgs[k].part_rz, m->grid_vec,
+                                          m->d_sc + SC_TOT + 1, nullptr, m->stream);
             mi::launch_reduce_to_totals(m->part(4), m->grid_vec, m->d_sc + SC_TOT + 3, nullptr, 0, nullptr, nullptr,
                                         m->stream);
           }
       }
-    if ((rc = team_allreduce(T, SC_TOT, 4)))
+    if (!use_mg && (rc = team_allreduce(T, SC_TOT, 4)))
       return rc;
-    if (use_mg && (rc = precondition()))
+    if (use_mg && (rc = precondition(true, true)))
       return rc;
     for (size_t k = 0; k < R; ++k)
       mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
@@ -943,6 +948,15 @@ namespace mi_detail
       done = h_flags[0] != 0;
       return MI_OK;
     };
+    // Multigrid-PCG: an iteration costs milliseconds, so the host learns the outcome of every convergence test before
+    // it enqueues the next V-cycle (one synchronisation per iteration) -- except where the outcome is as good as known:
+    // the same solve of the previous time step took expected_its iterations ("cg_warm_start" >= 2), so iterations
+    // 1 .. expected_its - 2 are enqueued back to back, V-cycle included, and the test of iteration i is taken on the
+    // device by the update of iteration i + 1 (as in the Jacobi batches).  Should the solve converge earlier after all,
+    // the flag turns every later CG kernel into a no-op and the V-cycles in the queue are wasted work, nothing else:
+    // iterates, iteration count and residual are those of the polled loop bit by bit.  Saves expected_its - 2 host
+    // synchronisations and as many scalar all-reduces per solve (||r||^2 then travels with r.z).
+    const int64_t speculate_to = (use_mg && c0->cg_speculate) ? std::min<int64_t>(max_it - 1, int64_t(expected_its) - 2) : 0;
     while (!done && it < max_it)
       {
         const int64_t stop = std::min<int64_t>(max_it, it + batch);
@@ -981,7 +995,7 @@ namespace mi_detail
             for (size_t k = 0; k < R; ++k)
               mi::launch_cg_update_xr(cgs[k], int(it), T.members[k]->grid_vec, T.members[k]->stream);
             toc(c0, t);
-            if (dist)
+            if (dist && it > speculate_to)
               {
                 for (size_t k = 0; k < R; ++k)
                   mi::launch_reduce_to_totals(cgs[k].part_rr, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT,
@@ -991,11 +1005,17 @@ namespace mi_detail
                   return rc;
               }
           }
+        if (it <= speculate_to) // no test, no poll: the next update takes the decision
+          {
+            if ((rc = precondition(true, false)))
+              return rc;
+            continue;
+          }
         for (size_t k = 0; k < R; ++k)
           mi::launch_cg_final_check(cgs[k], int(it), T.members[k]->stream);
         if ((rc = poll()))
           return rc;
-        if (use_mg && !done && it < max_it && (rc = precondition()))
+        if (use_mg && !done && it < max_it && (rc = precondition(false, false)))
           return rc;
       }
     if (max_it <= 0)
@@ -1769,7 +1789,11 @@ int mi_cg_solve(mi_ctx *c, double rel_tol, int64_t max_it, int *its, double *res
   const bool    mg     = mg_active(c);
   const int64_t mg_cap = mg ? std::min<int64_t>(max_it, 300) : max_it;
   int           my_its = 0;
-  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, mg_cap, &my_its, res, x_zero, predicted);
+  // (the iteration count of the same solve one step earlier tells cg_run how far it may enqueue without polling)
+  const int expect = (pred && predicted) ? c0->pred_its[pj] : 0;
+  int rc = cg_run(c, MI_V_NEWTON_UPDATE, MI_V_SYSTEM_RHS, rel_tol, mg_cap, &my_its, res, x_zero, predicted, expect);
+  if (pred)
+    c0->pred_its[pj] = rc == MI_OK ? my_its : 0;
   // a breakdown (NaN state, indefinite tangent) is final, as with deal.II's SolverControl: no second attempt from a
   // poisoned iterate
   bool broke = rc == MI_ENOCONV_LIN && c->team->members[0]->cg_breakdown;
@@ -2292,6 +2316,10 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_warm_start = value;
       else if (k == "cg_operator" && (value == 0 || value == 1))
         m->cg_operator = value;
+      else if (k == "cg_speculate" && (value == 0 || value == 1))
+        m->cg_speculate = value;
+      else if (k == "halo_skip" && (value == 0 || value == 1))
+        c->team->halo_skip = value;
       else if (k == "mg_fuse" && value >= 0 && value <= 2)
         {
           const int rc = mg_set_fuse(m, value);
@@ -2340,6 +2368,12 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = (m->mf_slots && m->d_mf_yc) ? 1 : 0;
   else if (k == "cell_lattice")
     *value = m->lat.ncol > 0 ? 1 : 0;
+  else if (k == "cut_axis") // the box direction the slabs are cut along: 1 / 2 / 3 = x / y / z, 0: not decomposed
+    *value = c->team->size > 1 ? c->team->amap.ext_axis[c->team->dim - 1] + 1 : 0;
+  else if (k == "cg_speculate")
+    *value = m->cg_speculate;
+  else if (k == "halo_skip")
+    *value = c->team->halo_skip;
   else if (k == "precond")
     *value = m->precond;
   else if (k == "spmv_variant")

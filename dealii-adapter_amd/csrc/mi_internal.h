@@ -64,6 +64,9 @@ namespace mi_detail
     hipStream_t           comm_stream = nullptr; // RCCL halo exchange next to the interior rows of the SpMV
     hipEvent_t            ev_ready = nullptr, ev_halo = nullptr;
     int                   overlap  = 1;          // 0: halo exchange in line on `stream`
+    int                   halo_skip = 1;         // 1: products whose operand's ghost planes are known to be current (the
+                                                 // first post-smoothing step after a prolongation that filled them) run
+                                                 // without an exchange; 0: every product exchanges (A/B, bitwise the same)
     int                   device   = 0;
     int                   dim      = 0;
     int64_t               n_global = 0, nnodes_global = 0;
@@ -139,6 +142,9 @@ struct mi_ctx
   int       cg_warm_start = 0; // 0 (library default): every solve starts from zero, 1: later solves of a step start from the previous Newton
                                // update, as the reference's do, 2 / 3: from the same solve of the previous time step(s)
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
+  int       cg_speculate = 1; // multigrid-PCG: enqueue the iterations the previous step's same solve needed (minus two)
+                              // without polling the convergence flag in between (tuning "cg_speculate" 0: poll every one)
+  int       pred_its[NPRED] = {}; // iterations of the j-th solve of the previous time step (0: unknown)
   int       ebe = 2;          // tuning "smoother_operator": 2 matrix-free from the quadrature-point records, 1 element
                               // tangents (both where available), 0 assembled matrix
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)
@@ -227,7 +233,8 @@ namespace mi_detail
   // tol >= 0 relative to ||b||, tol < 0 absolute (-tol)
   // x_is_zero: the start vector is known to be zero (r0 = b without a product)
   int  cg_run(mi_ctx *c, int x_id, int b_id, double tol, int64_t max_it, int *its, double *res, bool x_is_zero = false,
-              bool scale_start = false); // scale_start: the start vector is a prediction h, replaced by its best multiple
+              bool scale_start = false, // scale_start: the start vector is a prediction h, replaced by its best multiple
+              int expected_its = 0);    // multigrid-PCG: iterations the same solve took one time step earlier (0: unknown)
   int  team_size(const mi_ctx *c);
   void linear_destroy(mi_ctx *c);
   int  create_member(Team &T, const mi_mesh_desc *md, const mi_material_desc *mat, const mi_newmark_desc *nm, int rank,
@@ -253,7 +260,8 @@ namespace mi_detail
   int team_halo_end(Team &T);
   int team_spmv(Team &T, const std::function<mi_ctx *(mi_ctx *)> &ctx_of, const std::function<double *(mi_ctx *)> &x_of,
                 const std::function<double *(mi_ctx *)> &y_of, const SpmvFusion *fusion, bool smoother = false,
-                const ChebFusion *cheb = nullptr); // cheb: one entry per member
+                const ChebFusion *cheb = nullptr, // cheb: one entry per member
+                bool ghosts_current = false);     // the ghost planes of x are up to date: no exchange (Team::halo_skip)
   int mg_set_storage(mi_ctx *c, int bits); // mi_mg.cpp: forwards to the level contexts
   int mg_set_fuse(mi_ctx *c, int fuse);
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);

@@ -226,14 +226,16 @@ namespace mi_detail
 
     // q = A_l x on level l of every slab: distributed levels exchange the ghost planes of x (overlapped with the
     // interior rows), the coarser levels are replicated
-    int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of, const ChebFusion *cheb = nullptr)
+    // ghosts_current: the ghost planes of x are up to date on every slab -- no exchange (see vcycle)
+    int level_spmv(Team &T, size_t l, const std::function<double *(mi_ctx *)> &x_of, const ChebFusion *cheb = nullptr,
+                   bool ghosts_current = false)
     {
       const int t  = (l == 0) ? tic(T.members[0], MI_T_SPMV_PRECOND) : -1; // fine-level products, for the byte accounting
       int       rc = MI_OK;
       if (is_dist(T, l))
         rc = team_spmv(
           T, [l](mi_ctx *m) { return m->mg->levels[l].ctx; }, x_of, [l](mi_ctx *m) { return m->mg->levels[l].q(); },
-          nullptr, true, cheb);
+          nullptr, true, cheb, ghosts_current);
       else
         for (size_t k = 0; k < T.members.size(); ++k)
           {
@@ -610,7 +612,8 @@ namespace mi_detail
 
     // k Chebyshev-Jacobi steps on level l for A x = b over [lmax/ratio, lmax]; zero_start: x = 0 on entry.
     // Level 0 runs on all slabs in lockstep (halo exchange of x before every SpMV, update on the owned dofs).
-    int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start)
+    // ghosts_current: the ghost planes of x are up to date, the first product needs no exchange
+    int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start, bool ghosts_current = false)
     {
       const double b = T.members[0]->mg->levels[l].lmax, a = b / ratio;
       const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
@@ -657,7 +660,7 @@ namespace mi_detail
                     }
                   cf.push_back(f);
                 }
-              if ((rc = level_spmv(T, l, x_of, cf.data())))
+              if ((rc = level_spmv(T, l, x_of, cf.data(), first && ghosts_current)))
                 return rc;
               if (three)
                 for (mi_ctx *m : T.members)
@@ -677,13 +680,13 @@ namespace mi_detail
                   else
                     cf.push_back(ChebFusion{L.b(), L.ctx->work(W_DINV), L.d(), L.x_other(), c1, c2, 0});
                 }
-              if ((rc = level_spmv(T, l, x_of, cf.data())))
+              if ((rc = level_spmv(T, l, x_of, cf.data(), first && ghosts_current)))
                 return rc;
               for (mi_ctx *m : T.members)
                 m->mg->levels[l].x_swapped = !m->mg->levels[l].x_swapped;
               continue;
             }
-          if (!skip_spmv && (rc = level_spmv(T, l, x_of)))
+          if (!skip_spmv && (rc = level_spmv(T, l, x_of, nullptr, first && ghosts_current)))
             return rc;
           for (mi_ctx *m : T.members)
             {
@@ -751,10 +754,10 @@ namespace mi_detail
       return MI_OK;
     }
 
-    int smooth(Team &T, size_t l, int k, bool zero_start)
+    int smooth(Team &T, size_t l, int k, bool zero_start, bool ghosts_current = false)
     {
       Multigrid &mg0 = *T.members[0]->mg;
-      return mg0.kind == 4 ? chebyshev4(T, l, k, zero_start) : chebyshev(T, l, k, mg0.smooth_ratio, zero_start);
+      return mg0.kind == 4 ? chebyshev4(T, l, k, zero_start) : chebyshev(T, l, k, mg0.smooth_ratio, zero_start, ghosts_current);
     }
 
     int vcycle(Team &T, size_t l)
@@ -836,7 +839,12 @@ namespace mi_detail
           MgLevel &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
           mi::launch_lattice_interp(L.ctx->dim, true, L.to_coarse.prolong, L.x(), C.x(), L.ctx->d_cmask, L.ctx->stream);
         }
-      return smooth(T, l, nu, false);
+      // The first product of the post-smoother needs no halo exchange (round 4): the residual product above exchanged the
+      // ghost planes of x, nothing has written x since, and the prolongation has just added the coarse correction on ALL
+      // local planes -- from coarse values that are the same on both sides of a cut (replicated level, or ghost planes
+      // exchanged two statements up) through tables that are functions of the global lattice index.  A ghost value is
+      // therefore what its owner holds, bit by bit ("halo_skip" 0 exchanges anyway: test_halo_skip_is_bitwise_neutral).
+      return smooth(T, l, nu, false, dist_l);
     }
   } // namespace
 

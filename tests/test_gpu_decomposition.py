@@ -155,6 +155,73 @@ def test_halo_overlap_is_bitwise_neutral(precond):
     assert _relmax(runs[0][3], G1.get(M.V_NEWTON)) < 1e-6
 
 
+def _ramp_steps(G, nsteps=3, tol_lin=1e-6):
+    """Newmark steps under the bench's ramp; Newton tables, iteration counts and the final state"""
+    rows = []
+    for s in range(nsteps):
+        G.set_interface_traction((0.0, -2e3 * (s + 1) / 10.0, 0.0))
+        rc, info = G.newmark_step(tol_lin=tol_lin)
+        assert rc == 0 and info.converged == 1
+        rows.append((info.newton_iterations, info.assemblies, info.lin_its_total))
+    return rows, G.get(M.V_U), G.get(M.V_V), G.get(M.V_A)
+
+
+@pytest.mark.parametrize("reps,slabs", [((10, 10, 24), 3), ((24, 24, 48), 2)])
+def test_halo_skip_is_bitwise_neutral(reps, slabs):
+    """round 4: the first product of every post-smoother runs WITHOUT a halo exchange -- the residual product before the
+    coarse correction exchanged the ghost planes of x and the prolongation updated them with the owner's arithmetic.
+    With "halo_skip" 0 every product exchanges: the same bits, two exchanges more per V-cycle.  The second mesh has
+    slabs above 100 k nodes: the matrix-free smoother (fused three-term steps, alternating x buffers) on slabs."""
+    runs = []
+    for skip in (1, 0):
+        _, G = _setup(3, 2, reps, slabs, perturb_amp=0.0)
+        G.set_tuning("precond", 1)
+        G.set_tuning("cg_warm_start", 2)
+        G.set_tuning("halo_skip", skip)
+        G.reset_timings()
+        rows, u, v, a = _ramp_steps(G, 2)
+        runs.append((rows, u, v, a, G.get_tuning("count_halo_exchange"), G.get_tuning("count_cg_iterations"),
+                     G.get_tuning("smoother_operator_active")))
+        G.close()
+    assert runs[0][0] == runs[1][0]
+    for k in (1, 2, 3):
+        assert np.array_equal(runs[0][k], runs[1][k])
+    its = runs[0][5]
+    assert runs[1][4] - runs[0][4] >= 2 * its  # two exchanges per V-cycle (one per distributed level), one cycle per iteration
+    assert runs[0][6] == (2 if reps[0] > 20 else 0)
+
+
+@pytest.mark.parametrize("slabs", [1, 3])
+def test_speculative_enqueue_does_not_change_the_solve(slabs):
+    """round 4: from the second time step on, a multigrid-PCG solve enqueues the iterations the same solve needed one
+    step earlier (minus two) without polling the convergence flag, ||r||^2 travelling with r.z in one all-reduce; the
+    device takes the decisions the host used to poll.  Same Newton tables, same iteration counts, same bits; fewer host
+    synchronisations and scalar all-reduces ("cg_speculate" 0: a poll and an all-reduce more per iteration)."""
+    runs = []
+    for spec in (1, 0):
+        _, G = _setup(3, 2, (12, 12, 24), slabs, perturb_amp=0.0)
+        G.set_tuning("precond", 1)
+        G.set_tuning("cg_warm_start", 2)
+        G.set_tuning("cg_speculate", spec)
+        _ramp_steps(G, 1, tol_lin=1e-9)  # the first step has nothing to go by
+        G.reset_timings()
+        rows, u, v, a = _ramp_steps(G, 3, tol_lin=1e-9)
+        runs.append((rows, u, v, a, G.get_tuning("count_cg_host_sync"), G.get_tuning("count_scalar_allreduce"),
+                     G.get_tuning("count_cg_solves")))
+        G.close()
+    assert runs[0][0] == runs[1][0]
+    for k in (1, 2, 3):
+        assert np.array_equal(runs[0][k], runs[1][k])
+    solves, its = runs[0][6], sum(r[2] for r in runs[0][0])
+    assert its >= 5 * solves  # (several iterations per solve, or there is nothing to save)
+    print("polls %d -> %d, scalar all-reduces %d -> %d over %d solves / %d iterations" % (
+        runs[1][4], runs[0][4], runs[1][5], runs[0][5], solves, its))
+    assert runs[1][4] == its                      # polled loop: one synchronisation per iteration
+    assert runs[0][4] <= its - 2 * solves         # speculative: at least two per solve saved (typically all but two)
+    if slabs > 1:  # (a single slab reduces on the device without a collective)
+        assert runs[0][5] <= runs[1][5] - 2 * solves  # and an all-reduce less for every iteration not polled
+
+
 @pytest.mark.parametrize("dim,p,reps,slabs", [(3, 1, (3, 3, 6), 3), (3, 2, (2, 2, 4), 2), (2, 3, (4, 6), 3)])
 def test_team_linear_model_steps(dim, p, reps, slabs):
     """the linear theta-model (linear_elasticity.cc:378-586) on a decomposed mesh: host assembly per slab, both
