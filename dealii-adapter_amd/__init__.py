@@ -113,6 +113,8 @@ def lib():
         L.mi_assemble_residual.restype = C.c_int
         L.mi_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.mi_comm_info.restype = C.c_int
+        L.mi_comm_broadcast.argtypes = [vp, C.POINTER(C.c_double), C.c_int32]
+        L.mi_comm_broadcast.restype = C.c_int
         L.mi_cg_solve.argtypes = [vp, C.c_double, C.c_int64, C.POINTER(C.c_int), dp]
         L.mi_apply_newton_update.argtypes = [vp, dp]
         L.mi_direct_solve.argtypes = [vp, dp]
@@ -349,6 +351,12 @@ class Context:
         if check:
             self._chk(rc)
         return rc, info
+
+    def comm_broadcast(self, values):
+        """values of rank 0 to every rank (collective; returns the received array)"""
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        self._chk(lib().mi_comm_broadcast(self.h, _dp(v), v.size))
+        return v
 
     def state_save(self):
         self._chk(lib().mi_state_save(self.h))

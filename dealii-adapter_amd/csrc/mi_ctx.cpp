@@ -1669,6 +1669,44 @@ int mi_get_interface_displacement(mi_ctx *c, int n, double *vals)
   return MI_OK;
 }
 
+// Values of rank 0 to every rank of the team (round 4): what the ONE preCICE-facing process has learnt from the coupling
+// library -- read data, isCouplingOngoing, the checkpoint decisions -- reaches the other ranks through the library's own
+// communicator (host/include/adapter/rank_zero_participant.h).  Ranks > 0 contribute zeros to an all-reduce of the
+// interface scratch: x + 0 + ... + 0 = x bit by bit (a -0.0 arrives as +0.0).  One process (single or emulated slabs): no-op.
+int mi_comm_broadcast(mi_ctx *c, double *values, int32_t n)
+{
+  if (!c || (n > 0 && !values) || n < 0)
+    return fail(c, MI_EINVAL, "mi_comm_broadcast: bad arguments");
+  Team &T = *c->team;
+  if (!T.nccl || n == 0)
+    return MI_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t cap  = std::max<size_t>(1, T.iface_global.size() * size_t(c->dim));
+  const size_t capp = std::min(cap, c->h_pinned_doubles > 64 ? c->h_pinned_doubles - 64 : size_t(0));
+  if (capp == 0)
+    return fail(c, MI_EINVAL, "mi_comm_broadcast: no staging buffer");
+  const bool root = c->slab.rank == 0;
+  for (size_t off = 0; off < size_t(n); off += capp)
+    {
+      const size_t cnt = std::min(capp, size_t(n) - off);
+      if (root)
+        {
+          std::memcpy(c->h_pinned + 64, values + off, cnt * sizeof(double));
+          HIPCHK(c, hipMemcpyAsync(T.d_ifbuf, c->h_pinned + 64, cnt * sizeof(double), hipMemcpyHostToDevice, T.stream));
+        }
+      else
+        HIPCHK(c, hipMemsetAsync(T.d_ifbuf, 0, cnt * sizeof(double), T.stream));
+      int rc = team_allreduce_buffer(T, T.d_ifbuf, cnt);
+      if (rc)
+        return rc;
+      HIPCHK(c, hipMemcpyAsync(c->h_pinned + 64, T.d_ifbuf, cnt * sizeof(double), hipMemcpyDeviceToHost, T.stream));
+      if ((rc = sync(c)))
+        return rc;
+      std::memcpy(values + off, c->h_pinned + 64, cnt * sizeof(double));
+    }
+  return MI_OK;
+}
+
 int mi_newton_begin_step(mi_ctx *c)
 {
   HIPCHK(c, hipSetDevice(c->device));

@@ -17,7 +17,9 @@
 #include <string>
 #include <vector>
 
+#include "../mi/rank_identity.h"
 #include "precice_participant.h"
+#include "rank_zero_participant.h"
 #include "time_handler.h"
 
 namespace Adapter
@@ -27,28 +29,19 @@ namespace Adapter
   {
   public:
     Adapter(const ParameterClass &parameters, const unsigned int deal_boundary_interface_id)
-      : precice(parameters.participant_name, parameters.config_file, this_mpi_process, n_mpi_processes)
+      : precice(parameters.participant_name, parameters.config_file, mi::host_rank(), mi::host_world_size())
       , deal_boundary_interface_id(deal_boundary_interface_id)
       , mesh_name(parameters.mesh_name)
       , read_data_name(parameters.read_data_name)
       , write_data_name(parameters.write_data_name)
-    {
-#ifdef MI_WITH_PRECICE
-      // With the real libprecice every process of tools/launch_elasticity.py would register as the ONE rank of the same
-      // participant (this_mpi_process = 0 of n_mpi_processes = 1, as in the reference, adapter.h:152-154, 217-220) and the
-      // coupling would see N copies of "Solid".  Until the ranks > 0 join as ranks of one participant with empty vertex
-      // sets, a multi-process run against libprecice is refused; MI_SLABS=N (one process) is not affected.
-      if (const char *w = std::getenv("MI_WORLD_SIZE"))
-        if (std::atoi(w) > 1)
-          throw std::runtime_error("MI_WORLD_SIZE > 1 is not supported in a -DMI_WITH_PRECICE build: every process would "
-                                   "register as the single rank of participant <" + parameters.participant_name + ">");
-#endif
-    }
+    {}
 
     // adapter.h:229-342
     template <typename DoFSource>
     void initialize(const DoFSource &dof_handler, const VectorType &deal_to_precice)
     {
+      // several ranks: what rank 0 reads from the coupling library reaches the others through the solver's communicator
+      bind_broadcast(dof_handler, 0);
       if (dim != precice.getMeshDimensions(mesh_name))
         throw std::runtime_error("The dimension of your solver needs to be consistent with the dimension "
                                  "specified in your precice-config file. In case you run one of the tutorials, "
@@ -116,17 +109,25 @@ namespace Adapter
         }
     }
 
-    precice::Participant precice;
-    const unsigned int   deal_boundary_interface_id;
+    // adapter.h:136 `precice::Participant precice;` -- here the participant of rank 0 behind the same calls
+    RankZeroParticipant precice;
+    const unsigned int  deal_boundary_interface_id;
 
   private:
     const std::string mesh_name;
     const std::string read_data_name;
     const std::string write_data_name;
 
-    // one preCICE-facing process, as in the reference (:152-154), also when the mesh is spread over several GPUs
-    static constexpr unsigned int this_mpi_process = 0;
-    static constexpr unsigned int n_mpi_processes  = 1;
+    // one preCICE-facing process, as in the reference (:152-154: this_mpi_process = 0, n_mpi_processes = 1), also when the
+    // mesh is spread over several GPUs: RankZeroParticipant
+    template <typename DoFSource>
+    auto bind_broadcast(const DoFSource &d, int) -> decltype(d.broadcaster(), void())
+    {
+      precice.bind(d.broadcaster());
+    }
+    template <typename DoFSource>
+    void bind_broadcast(const DoFSource &, long) // a DoF source without a communicator (single-rank tests)
+    {}
 
     int                 n_interface_nodes = 0;
     std::vector<int>    interface_nodes_ids;

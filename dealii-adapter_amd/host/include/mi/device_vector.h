@@ -15,26 +15,11 @@
 #include <vector>
 
 #include "mi_elasticity.h"
+#include "rank_identity.h"
 
 namespace mi
 {
-  // Decomposition of the executables, taken from the environment (the reference is single-rank, adapter.h:152-154):
-  //   MI_SLABS=N                                   N slabs inside this process on one GPU (emulation; tests)
-  //   MI_WORLD_SIZE=N MI_RANK=r MI_UID_FILE=path   one process per GPU over RCCL (tools/launch_elasticity.py sets them
-  //   [MI_LOCAL_RANK=d]                            and starts the N processes); rank 0 creates the RCCL id and leaves
-  //                                                it in the file, the others wait for it; device = local rank
-  // Every rank holds the whole interface and global views of the vectors (the library gathers them), so the Adapter
-  // and the solvers above run unchanged on every rank; ranks > 0 keep quiet and write no files.
-  inline int host_world_size()
-  {
-    const char *e = std::getenv("MI_WORLD_SIZE");
-    return e ? std::max(1, std::atoi(e)) : 1;
-  }
-  inline int host_rank()
-  {
-    const char *e = std::getenv("MI_RANK");
-    return (e && host_world_size() > 1) ? std::atoi(e) : 0;
-  }
+  // (decomposition of the executables: mi/rank_identity.h)
   struct Error : std::runtime_error
   {
     int code;
@@ -59,16 +44,26 @@ namespace mi
           comm.size = world;
           if (comm.rank < 0 || comm.rank >= world)
             throw Error(MI_EINVAL, "MI_RANK outside [0, MI_WORLD_SIZE)");
-          const char *file = std::getenv("MI_UID_FILE");
-          if (!file)
-            throw Error(MI_EINVAL, "MI_WORLD_SIZE > 1 needs MI_UID_FILE (see tools/launch_elasticity.py)");
-          exchange_unique_id(file, comm.rank, uid_);
-          comm.nccl_unique_id = uid_;
-          if (const char *e = std::getenv("MI_LOCAL_RANK"))
-            device_id = std::atoi(e);
+          if (thread_identity().world > 0) // rank threads of one process (tests): id and device come with the identity
+            {
+              if (!thread_identity().uid)
+                throw Error(MI_EINVAL, "rank thread without an RCCL id");
+              std::memcpy(uid_, thread_identity().uid, 128);
+              device_id = thread_identity().device;
+            }
           else
-            device_id = comm.rank;
-          use = &comm;
+            {
+              const char *file = std::getenv("MI_UID_FILE");
+              if (!file)
+                throw Error(MI_EINVAL, "MI_WORLD_SIZE > 1 needs MI_UID_FILE (see tools/launch_elasticity.py)");
+              exchange_unique_id(file, comm.rank, uid_);
+              if (const char *e = std::getenv("MI_LOCAL_RANK"))
+                device_id = std::atoi(e);
+              else
+                device_id = comm.rank;
+            }
+          comm.nccl_unique_id = uid_;
+          use                 = &comm;
         }
       else if (const char *e = std::getenv("MI_SLABS"))
         {

@@ -4,6 +4,7 @@
 // into 2), a warm-started CG on M + theta^2 dt^2 K with the Dirichlet rows eliminated, and the displacement
 // update -- all on the device (mi_linear_step).
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -31,6 +32,12 @@ namespace Linear_Elasticity
       void              interface_nodes(int *ids, double *xyz) const
       {
         dev->check(mi_get_interface_nodes(dev->ctx(), ids, xyz), "mi_get_interface_nodes");
+      }
+      // values of rank 0 to every rank of the decomposition (Adapter::RankZeroParticipant)
+      std::function<void(double *, int)> broadcaster() const
+      {
+        const mi::Device *d = dev;
+        return [d](double *v, int n) { d->check(mi_comm_broadcast(d->ctx(), v, n), "mi_comm_broadcast"); };
       }
     };
 

@@ -4,6 +4,7 @@
 // same constructor/run() surface, same time loop, Newton logic, convergence table and timer sections; the
 // work inside assemble_system / solve_linear_system / update_* happens in HIP kernels behind the mi_* C-ABI.
 #pragma once
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -32,6 +33,12 @@ namespace Nonlinear_Elasticity
       void              interface_nodes(int *ids, double *xyz) const
       {
         dev->check(mi_get_interface_nodes(dev->ctx(), ids, xyz), "mi_get_interface_nodes");
+      }
+      // values of rank 0 to every rank of the decomposition (Adapter::RankZeroParticipant)
+      std::function<void(double *, int)> broadcaster() const
+      {
+        const mi::Device *d = dev;
+        return [d](double *v, int n) { d->check(mi_comm_broadcast(d->ctx(), v, n), "mi_comm_broadcast"); };
       }
     };
 

@@ -97,6 +97,11 @@ int mi_partition_spmv_rows(const mi_mesh_desc *mesh, int rank, int size, int64_t
 int mi_comm_unique_id(void *out128); /* ncclGetUniqueId */
 /* slabs of the decomposition this context belongs to, and ncclCommCount of its RCCL communicator (0: none) */
 int mi_comm_info(const mi_ctx *ctx, int *team_size, int *rccl_ranks);
+/* values[0..n) of rank 0 to every rank of the decomposition (collective; no-op in one process).  The reference couples
+ * through ONE process (adapter.h:152-154, 213-225): with several GPUs only rank 0 owns the precice::Participant and what
+ * it reads -- coupling data (:346-361), isCouplingOngoing, getMaxTimeStepSize, the checkpoint requests (:447-489) --
+ * travels to the other ranks through this call (host/include/adapter/rank_zero_participant.h). */
+int mi_comm_broadcast(mi_ctx *ctx, double *values, int32_t n);
 
 /* parameters.cc:61-99 ("Solver" subsection) */
 typedef struct

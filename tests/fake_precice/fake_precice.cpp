@@ -8,6 +8,7 @@
 // behaviour, and therefore bit-identical results with the default build (tests/test_host_gpu.py).
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <fstream>
 #include <iomanip>
 #include <iostream>
@@ -51,6 +52,11 @@ namespace precice
                                                              solverProcessIndex, solverProcessSize);
     std::lock_guard<std::mutex> lk(g_mutex);
     g_impl[this] = std::move(obj);
+    // tests: how many participants this PROCESS has constructed so far (a multi-rank run must construct exactly one)
+    static int constructed = 0;
+    ++constructed;
+    if (const char *f = std::getenv("MI_FAKE_PRECICE_COUNT"))
+      std::ofstream(f) << constructed << "\n";
   }
   Participant::~Participant()
   {

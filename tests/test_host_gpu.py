@@ -157,6 +157,50 @@ def test_precice_v3_code_path_links_and_runs(tmp_path, name):
     assert logs[0] == logs[1] and logs[0].count("\n") >= 3
 
 
+@pytest.mark.parametrize("name", ["fsi3_neo_3d_q3", "fsi3_neo_3d_implicit"])
+def test_multi_rank_coupling_goes_through_rank_zero(tmp_path, name):
+    """BASELINE configuration 5 on several GPUs with a REAL participant [REF adapter.h:213-225, 346-385, 447-489]: under
+    -DMI_WITH_PRECICE only rank 0 constructs precice::Participant(name, config, 0, 1); what it reads -- coupling data,
+    isCouplingOngoing, the time-window size, the checkpoint requests of an implicit scheme -- reaches the other ranks through
+    mi_comm_broadcast (Adapter::RankZeroParticipant), and only rank 0 writes.  Run against the libprecice test double:
+      * one process, undecomposed (the reference's situation);
+      * MI_SLABS=4: one process, four emulated slabs (the flap is cut along x);
+      * four RANK THREADS through the library's RCCL branch against the RCCL test double (tests/fake_rccl/
+        elasticity_ranks.cc -- a single-GPU box cannot host two real RCCL ranks).
+    The test double counts its participants: exactly ONE may exist in every run.  Displacement logs agree to the linear
+    tolerance (the decomposition changes the order of the sums), slabs and rank threads among themselves to 1e-13."""
+    fake, frccl = os.path.join(ROOT, "tests", "fake_precice"), os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dealii-adapter_amd"), "-j4", "all"])
+    subprocess.check_call(["make", "-C", fake])
+    subprocess.check_call(["make", "-C", frccl, "libmi_elasticity_fakerccl.so", "ranks"])
+    runs = {"one": ([os.path.join(fake, "elasticity_precice3d")], {}),
+            "slabs": ([os.path.join(fake, "elasticity_precice3d")], {"MI_SLABS": "4"}),
+            "ranks": ([os.path.join(frccl, "elasticity_ranks3d_precice"), "4"], {}),
+            "ranks_replay": ([os.path.join(frccl, "elasticity_ranks3d"), "4"], {})}  # default build, same harness
+    rows, outs = {}, {}
+    for key, (cmd, env) in runs.items():
+        d = tmp_path / key
+        d.mkdir()
+        for f in ("parameters.prm", "precice-config.xml"):
+            (d / f).write_text(open(os.path.join(CASES, name, f)).read())
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, MI_FAKE_PRECICE_COUNT=str(d / "participants.txt"), **env))
+        assert r.returncode == 0, key + ": " + r.stdout[-2000:] + r.stderr[-2000:]
+        rows[key] = [np.array(l.split(), dtype=float) for l in open(d / "displacement.log") if not l.startswith("#")]
+        outs[key] = r.stdout
+        if key != "ranks_replay":
+            assert open(d / "participants.txt").read().split() == ["1"], key  # ONE participant, whatever the rank count
+    n = len(rows["one"])
+    assert n >= 2 and all(len(v) == n for v in rows.values())
+    for key in ("slabs", "ranks", "ranks_replay"):
+        for a, b in zip(rows["one"], rows[key]):
+            assert a[0] == b[0] and np.abs(a[1:] - b[1:]).max() <= 1e-8 * np.abs(a[1:]).max(), key
+    for a, b, c in zip(rows["slabs"], rows["ranks"], rows["ranks_replay"]):
+        assert np.abs(a[1:] - b[1:]).max() <= 1e-13 * np.abs(a[1:]).max() and np.array_equal(b, c)
+    assert "rank 0 couples" in outs["ranks"] and outs["ranks"].count("Number of coupling nodes") == 1  # ranks > 0 keep quiet
+    assert (tmp_path / "ranks" / "out" / "solution-000.vtk").exists()
+
+
 def test_executable_nonlinear_implicit_checkpointing(tmp_path):
     """implicit coupling: 3 coupling iterations per window with save/reload of the 6 state vectors on the device"""
     name = "fsi3_neo_2d_implicit"
