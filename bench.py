@@ -582,7 +582,7 @@ def main():
             G.set_tuning("spmv_variant", 3)
             out["roofline"]["calibration_stream_read"] = {"ms": ms_cal, "GB": 8 * G.nnz / 1e9,
                                                           "GB_per_s": 8 * G.nnz / ms_cal / 1e6}
-        pmc_file = os.path.join(ROOT, "profiles", "r03", "pmc_bench_n59.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r04", "pmc_bench_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
             # NOT a measurement of this run: per-launch HBM traffic of the same command under `rocprofv3 --pmc`
             # (tools/pmc_bench.sh), as committed with the round's profiles; `roofline.traffic` itself stays null because
@@ -602,7 +602,7 @@ def main():
                 tot = sum(v["traffic_GB_per_launch"] * v["launches"] for v in eb) / sum(v["launches"] for v in eb)
                 ref["dominant_kernel"] = {"GB_per_launch": tot,
                                           "ratio_to_algorithmic": tot / out["roofline"]["algorithmic_GB_per_launch"]}
-            asm = [v for k, v in pmc.items() if k.startswith("mi::assemble_q2sf<false>")]
+            asm = [v for k, v in pmc.items() if k.startswith("mi::assemble_q2sf<false")]
             if asm:
                 ref["assemble_q2sf_per_tangent_assembly"] = {
                     "GB": sum(v["traffic_GB_per_launch"] * v["launches"] for v in asm) / (sum(v["launches"] for v in asm) / 8.0),

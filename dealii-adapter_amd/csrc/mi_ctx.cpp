@@ -217,6 +217,7 @@ namespace mi_detail
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
     p.inverted = c->d_sc + SC_INVERTED;
+    p.correct_face_F = c->correct_face_F;
     p.axmap    = 0;
     for (int d = 0; d < 3; ++d)
       p.axmap |= (c->team->amap.ext_axis[d] << (2 * d)) | ((c->team->amap.dir[d] < 0 ? 1 : 0) << (6 + d));
@@ -1481,6 +1482,8 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
         m->ebe = std::max(0, std::min(2, atoi(e)));
       if (const char *e = getenv("MI_MF_SINGLE_LAUNCH"))
         m->mf_slots = atoi(e) != 0;
+      if (const char *e = getenv("MI_CORRECT_FACE_F")) // the executables' "--correct-face-F" (SURVEY section 9); default: the reference's quirk
+        m->correct_face_F = atoi(e) != 0;
       const int rc = ensure_element_tangents(m);
       if (rc != MI_OK)
         return bail(rc, m->err);
@@ -2354,6 +2357,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_warm_start = value;
       else if (k == "cg_operator" && (value == 0 || value == 1))
         m->cg_operator = value;
+      else if (k == "correct_face_F" && (value == 0 || value == 1)) // default 0 reproduces :825-827
+        m->correct_face_F = value;
       else if (k == "cg_speculate" && (value == 0 || value == 1))
         m->cg_speculate = value;
       else if (k == "halo_skip" && (value == 0 || value == 1))

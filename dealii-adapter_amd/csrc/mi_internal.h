@@ -142,6 +142,7 @@ struct mi_ctx
   int       cg_warm_start = 0; // 0 (library default): every solve starts from zero, 1: later solves of a step start from the previous Newton
                                // update, as the reference's do, 2 / 3: from the same solve of the previous time step(s)
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
+  int       correct_face_F = 0; // tuning "correct_face_F": the Neumann pull-back with F at the face point (default: the reference's quirk)
   int       cg_speculate = 1; // multigrid-PCG: enqueue the iterations the previous step's same solve needed (minus two)
                               // without polling the convergence flag in between (tuning "cg_speculate" 0: poll every one)
   int       pred_its[NPRED] = {}; // iterations of the j-th solve of the previous time step (0: unknown)

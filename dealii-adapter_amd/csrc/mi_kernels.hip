@@ -1550,15 +1550,37 @@ namespace mi
             ql[d] = q1d(d, qe[ext[d]]);
           cq = ql[0] + NQ1 * (ql[1] + NQ1 * ql[2]);
         }
-        // (1) F at the CELL quadrature point with index fq  -- the reference's quirk (:825-827 vs :902-903)
+        // (1) F at the CELL quadrature point with index fq  -- the reference's quirk (:825-827 vs :902-903) -- or, with
+        // "correct_face_F", at the face quadrature point itself: the 1D bases at the face's end of the normal direction
+        // (values 0 / 1, derivatives from the table behind qx) and at the face point's abscissae along the face
         double gxi[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k)
           gxi[k] = 0.0;
+        const double *dN_end = prm.tab1d + 2 * NQ1 * NP1 + 2 * NQ1 + side * NP1;
         for (int a = part; a < NPC; a += 4)
           {
             double N, dN[3];
-            shape_at_qp<DIM, P>(s_N1, s_dN1, cq, a, N, dN);
+            if (prm.correct_face_F)
+              {
+                const int ai[3] = {a % NP1, (a / NP1) % NP1, (DIM == 3) ? a / (NP1 * NP1) : 0};
+                double    n1[3] = {1.0, 1.0, 1.0}, d1[3] = {0.0, 0.0, 0.0};
+                n1[nd]  = (ai[nd] == (side ? P : 0)) ? 1.0 : 0.0;
+                d1[nd]  = dN_end[ai[nd]];
+                n1[ax0] = s_N1[f1 * NP1 + ai[ax0]];
+                d1[ax0] = s_dN1[f1 * NP1 + ai[ax0]];
+                if (DIM == 3)
+                  {
+                    n1[ax1] = s_N1[f2 * NP1 + ai[ax1]];
+                    d1[ax1] = s_dN1[f2 * NP1 + ai[ax1]];
+                  }
+                N     = n1[0] * n1[1] * n1[2];
+                dN[0] = d1[0] * n1[1] * n1[2];
+                dN[1] = n1[0] * d1[1] * n1[2];
+                dN[2] = (DIM == 3) ? n1[0] * n1[1] * d1[2] : 0.0;
+              }
+            else
+              shape_at_qp<DIM, P>(s_N1, s_dN1, cq, a, N, dN);
 #pragma unroll
             for (int i = 0; i < DIM; ++i)
 #pragma unroll
@@ -1578,6 +1600,13 @@ namespace mi
           for (int d = 0; d < DIM; ++d)
             xi[d] = s_qx[qi[d]];
         }
+        if (prm.correct_face_F) // the Jacobian at the face point as well
+          {
+            xi[nd]  = side ? 1.0 : 0.0;
+            xi[ax0] = s_qx[f1];
+            if (DIM == 3)
+              xi[ax1] = s_qx[f2];
+          }
         double Jm[9], Ji[9], F[9], Fi[9];
         q1_jacobian<DIM>(s_verts, xi, Jm);
         inv3x3(Jm, det3x3(Jm), Ji);

@@ -135,11 +135,12 @@ namespace mi
       }
   }
 
-  // 1D tables handed to the kernels: N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1]
+  // 1D tables handed to the kernels: N1[nq1][np1], dN1[nq1][np1], qw[nq1], qx[nq1], then dN_end[2][np1] = the basis
+  // derivatives at the two ends of the unit interval (the face term with F evaluated ON the face, "correct_face_F")
   struct Tables1D
   {
     int                 p, np1, nq1;
-    std::vector<double> nodes, qx, qw, N, dN;
+    std::vector<double> nodes, qx, qw, N, dN, dN_end;
     void                build(int p_, int nq1_)
     {
       p   = p_;
@@ -151,6 +152,10 @@ namespace mi
       dN.resize(size_t(nq1) * np1);
       for (int q = 0; q < nq1; ++q)
         lagrange_eval(nodes, qx[q], &N[size_t(q) * np1], &dN[size_t(q) * np1]);
+      dN_end.resize(size_t(2) * np1);
+      std::vector<double> val(static_cast<size_t>(np1), 0.0);
+      lagrange_eval(nodes, 0.0, val.data(), &dN_end[0]);
+      lagrange_eval(nodes, 1.0, val.data(), &dN_end[size_t(np1)]);
     }
     std::vector<double> packed() const
     {
@@ -159,6 +164,7 @@ namespace mi
       t.insert(t.end(), dN.begin(), dN.end());
       t.insert(t.end(), qw.begin(), qw.end());
       t.insert(t.end(), qx.begin(), qx.end());
+      t.insert(t.end(), dN_end.begin(), dN_end.end());
       return t;
     }
   };

@@ -147,6 +147,36 @@ def test_neumann_only_residual_isolated():
     assert np.allclose(r.sum(0), P.vec(O.V_RHS).reshape(-1, 3).sum(0), rtol=1e-12)
 
 
+@pytest.mark.parametrize("dim,p,reps,slabs,cut_axis", [(3, 2, (3, 2, 3), 1, 0), (2, 3, (4, 3), 1, 0), (3, 1, (3, 3, 4), 2, 0),
+                                                       (2, 2, (6, 3), 3, 1), (3, 3, (2, 2, 2), 1, 0), (3, 2, (4, 2, 2), 2, 1)])
+def test_face_pull_back_with_the_deformation_gradient_on_the_face(dim, p, reps, slabs, cut_axis):
+    """the reference pulls the traction back with F of CELL quadrature point fq (nonlinear_elasticity.cc:
+    825-827 against :902-903) -- reproduced by default; mi_set_tuning("correct_face_F", 1) evaluates F at the face
+    quadrature point itself, which is what the oracle's correct_face_F switch does.  Distorted cells, a deformed state,
+    per-node tractions; also on slabs and on a lattice that lies rotated over the box (cut along x)."""
+    lo, hi = (0.0,) * dim, tuple(0.1 * r for r in reps)
+    nverts = int(np.prod([r + 1 for r in reps]))
+    perturb = 0.04 * 0.1 * np.random.default_rng(11).standard_normal((nverts, dim))
+    roles = [O.FACE_CLAMPED] + [O.FACE_INTERFACE] * 5
+    res = {}
+    for correct in (0, 1):
+        P = O.Problem(O.make_desc(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, correct_face_F=correct), perturb)
+        G = M.Context(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, perturb=perturb, slabs=slabs, cut_axis=cut_axis)
+        G.set_tuning("correct_face_F", correct)
+        _randomise_state(P, G, seed=5, amp_u=0.05)
+        t = 1e3 * np.random.default_rng(3).standard_normal((len(P.interface_nodes), dim))
+        P.set_interface_traction(t)
+        G.set_interface_traction(t)
+        P.update_acceleration()
+        G.update_acceleration()
+        P.assemble()
+        G.assemble()
+        res[correct] = (G.get(M.V_RHS), P.vec(O.V_RHS).copy())
+        assert _relmax(res[correct][0], res[correct][1]) < TOL_ASM
+        G.close()
+    assert _relmax(res[1][1], res[0][1]) > 1e-4  # the two pull-backs really differ on a deformed mesh
+
+
 @pytest.mark.parametrize("dim,p,reps", [(3, 2, (3, 3, 3)), (3, 1, (4, 4, 4)), (2, 3, (6, 3))])
 def test_spmv_matches_reference_matrix(dim, p, reps):
     P, G = _pair(dim, p, reps, perturb_amp=0.05, seed=5)

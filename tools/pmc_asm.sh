@@ -16,7 +16,7 @@ from collections import defaultdict
 acc = defaultdict(list)
 for f in glob.glob("gpurun_out/pmc_asm/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f, newline="")):
-        if "assemble_q2sf<false>" in row["Kernel_Name"]:
+        if "assemble_q2sf<false" in row["Kernel_Name"]:
             acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
 a = {k: sum(v) / len(v) for k, v in sorted(acc.items())}
 a["launches"] = max(len(v) for v in acc.values()) if acc else 0
