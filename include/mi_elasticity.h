@@ -257,32 +257,75 @@ typedef struct
   int64_t count[MI_T_COUNT]; /* launches / calls           */
 } mi_timings;
 int mi_set_profiling(mi_ctx *ctx, int enable);
-/* run-time switches (A/B timing, tests): "spmv_variant" 3 sliced-ELL (default), 1 block-CSR; "spmv_grid" workgroups;
- * "sell_unroll" 1..4; "xcd_remap" 0/1; "precond" 1 multigrid V-cycle (default), 0 Jacobi; "mg_lag" 1 coarse
- * operators kept over the Newton iterations of a step (default), 0 rebuilt after every assembly; "mg_refresh_every" k
- * (default 8, 1..1000): with "mg_lag" 1 the coarse operators (levels >= 1 of the preconditioner; the fine-level
- * smoother always works on the current tangent) are rebuilt at the first solve of every k-th time step, or before
- * the next solve when one needed a quarter (at least 2) more iterations than the first solve after the last rebuild; "asm_variant"
- * element-kernel ablations; "halo_overlap" 1 ghost-plane exchange on the communication stream next to the interior
- * rows of the SpMV (default), 0 in line on the compute stream; "precond_storage" 64 (default) | 32: the multigrid
- * smoother multiplies with an fp32-rounded copy of the level matrices (arithmetic, the CG's own product and its
- * residuals stay fp64); "sell_icol" 1 (default): the SpMV generates the column indices of a row from its
- * column box (lattice meshes) instead of reading them, 0: reads the index array; "smoother_operator" 2 (default): on 3D Q2
- * meshes above 100k nodes per slab the multigrid smoother applies the tangent matrix-free from the quadrature-point
- * state of the last assembly (6x fewer bytes than the assembled matrix; the CG's own product stays on the assembled
- * matrix), 1: with stored symmetric element tangents, 0: with the assembled matrix; "spmv_variant" 4 +
- * "element_tangents" 2 | 1: mi_spmv through that form whatever the mesh size (tests); "cg_operator" 0 (default) | 1: the
- * CG's own product on the assembled matrix | in the smoother's unassembled form (A/B); "asm_variant" 0 (default): 3D Q2
- * cells by the sum-factorised element kernel, 9: by the node-pair kernel every other element uses; "mg_fuse" 0|1|2: smoother update fused into the product never / on small levels (default) / always (tests); "cg_warm_start" 0 (default) | 1: see mi_apply_newton_update, 2 | 3: a solve that would start from zero starts from the solution of the same solve (first, second ... of the step, counted from mi_newton_begin_step) of the previous time step | its linear extrapolation over the last two steps, scaled to its best multiple alpha h, alpha = h.b / h.Ah (never worse than zero) -- the history belongs to mi_state_save / mi_state_restore; the executable and bench.py set 2; "solver_type" 0 (default) | 1: see mi_direct_solve; "small_cg" 1 (default): problems whose matrix values fit 1 MiB (a few hundred dofs) on one slab run the whole
- * Jacobi-PCG in a single launch, 0: the three-launches-per-iteration path.  Unknown key / value: MI_EINVAL. */
+/* Run-time switches of a context (all its slabs).  None is needed for production use: the defaults are what bench.py and
+ * the executables run, except "cg_warm_start", which both set to 2.  Unknown key or value out of range: MI_EINVAL.
+ * Environment variables of the same meaning are read once at context creation (column "env").
+ *
+ *  key                  values (default first)     meaning                                                            env
+ *  -------------------  -------------------------  -----------------------------------------------------------------  ----------------
+ *  SOLVER POLICIES
+ *  precond              1 | 0                      CG preconditioner: multigrid V-cycle (default from 75 k dofs) |      MI_PRECOND
+ *                                                  Jacobi (default below)
+ *  solver_type          0 | 1                      mi_newmark_step / mi_linear_step solve by PCG | banded Cholesky      -
+ *                                                  ("Solver type = Direct", nonlinear_elasticity.cc:1192-1200)
+ *  cg_warm_start        0 | 1 | 2 | 3              start vector of a solve: zero | the previous Newton update (the      MI_CG_WARM_START
+ *                                                  reference, :419,472) | the same solve of the previous time step |
+ *                                                  ... extrapolated over two steps; see mi_apply_newton_update
+ *  cg_speculate         1 | 0                      multigrid-PCG: iterations up to (count of the same solve one step    -
+ *                                                  earlier) - 2 are enqueued without polling the convergence flag, the
+ *                                                  device decides; same iterates bit by bit | poll every iteration
+ *  mg_lag               1 | 0                      coarse operators kept over the Newton iterations of a step | rebuilt  -
+ *                                                  after every assembly
+ *  mg_refresh_every     8 (1..1000)                coarse operators rebuilt at the first solve of every k-th step, or   MI_MG_REFRESH_EVERY
+ *                                                  earlier when a solve needs 25 % (>= 2) more iterations than the
+ *                                                  first one after a rebuild
+ *  correct_face_F       0 | 1                      Neumann pull-back with F of CELL point fq (the reference's quirk,    MI_CORRECT_FACE_F
+ *                                                  :825-827) | with F at the face point
+ *  OPERATOR FORMS
+ *  smoother_operator    2 | 1 | 0                  fine-level products of the smoother on 3D Q2 slabs > 100 k nodes:    MI_EBE
+ *                                                  matrix-free from the assembly's point records | stored element
+ *                                                  tangents | assembled matrix
+ *  cg_operator          0 | 1                      the CG's own product on the assembled matrix (north star) | in the   -
+ *                                                  smoother's unassembled form (A/B)
+ *  precond_storage      64 | 32                    smoother multiplies with the fp64 matrices | an fp32-rounded copy    -
+ *                                                  (opt-in; arithmetic, CG product, residuals stay fp64)
+ *  mf_single_launch     1 | 0                      matrix-free product: one launch + gather | eight colour launches     MI_MF_SINGLE_LAUNCH
+ *  cell_lattice         1 | 0                      mf_spmv: node ids of a cell by lattice arithmetic | from conn        MI_CELL_LATTICE
+ *  element_tangents     2 | 1                      tests: keep point records / element tangents whatever the size       -
+ *  DECOMPOSITION
+ *  halo_overlap         1 | 0                      ghost planes exchanged on the communication stream next to the       MI_HALO_OVERLAP
+ *                                                  interior rows | in line (same bits)
+ *  halo_skip            1 | 0                      no exchange before a product whose operand's ghost planes are        -
+ *                                                  current (first post-smoothing step) | always exchange (same bits)
+ *  KERNEL A/B (timing, tests)
+ *  spmv_variant         3 | 1 | 4 | 11..14         sliced-ELL LDS-DMA product | row-per-wave cross-check | mi_spmv      MI_SPMV_VARIANT
+ *                                                  through the unassembled form | streaming calibration kernels
+ *  sell_icol            1 | 0                      column indices generated from the rows' column boxes | read          MI_SELL_ICOL
+ *  sell_unroll, spmv_grid, xcd_remap               launch shape of the sliced-ELL product (MI_SELL_SPLIT=0: never the   MI_SELL_UNROLL
+ *                                                  one-workgroup-per-slice kernel on short launches)
+ *  cg_fused_dot         1 | 0                      p.q partials in the product's epilogue | separate reduction          MI_CG_FUSED_DOT
+ *  small_cg             1 | 0                      matrices <= 1 MiB: whole Jacobi-PCG in one launch | three launches   MI_SMALL_CG
+ *                                                  per iteration
+ *  asm_variant          0 | 9 | 1,2 | 3,4,5 | 6-8  3D Q2 element kernel: sum factorised | node-pair form | its chunk    -
+ *                                                  sizes | round-4 experiments (rotating prologue wave, L2 atomics:
+ *                                                  no gain) | timing-only ablations
+ *  mg_fuse              1 | 0 | 2                  smoother update fused into the product on small levels | never |     MI_MG_FUSE
+ *                                                  always
+ *  mg_scale_lmax_percent 10..400                   tests: spoil the eigenvalue estimates once                           -
+ *
+ * Further environment switches (read at creation; diagnostics): MI_MG_NU, MI_MG_NU_COARSE, MI_MG_RATIO, MI_MG_KIND,
+ * MI_MG_BLOCK, MI_MG_THREE_TERM, MI_MG_COARSEST, MI_MG_DENSE, MI_MG_FACTOR, MI_MG_SAFETY, MI_MG_POWER_ITS,
+ * MI_MG_COARSE_DEGREE, MI_MG_COARSE_RATIO, MI_MG_FUSE_MAX_NODES, MI_MG_VERBOSE (multigrid parameters);
+ * MI_MF_XCD (XCD-aware cell order of mf_spmv), MI_ASM_CELL_LATTICE, MI_ASM_STAMPS / MI_MF_STAMPS / MI_MF_DBG (phase stamps
+ * and timing-only ablations of the two element kernels). */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
-/* counters since the last mi_reset_timings (what a solve costs in latency-bound events; counted on one slab as well,
- * where the collectives themselves are no-ops): "count_scalar_allreduce", "count_vector_allreduce",
+/* Read back.  Counters since the last mi_reset_timings (what a solve costs in latency-bound events; counted on one slab
+ * as well, where the collectives themselves are no-ops): "count_scalar_allreduce", "count_vector_allreduce",
  * "count_halo_exchange", "count_cg_host_sync", "count_cg_iterations", "count_cg_solves", "count_mg_refresh" (rebuilds of
- * the multigrid preconditioner's coarse operators) */
-/* read back: "smoother_operator_active" (2 / 1: the smoother's fine-level products are matrix-free / use the stored
- * element tangents, 0: the assembled matrix), "precond",
- * "spmv_variant" */
+ * the preconditioner's coarse operators).  State: "smoother_operator_active" (2 / 1: the smoother's fine-level products
+ * are matrix-free / use the stored element tangents, 0: the assembled matrix), "precond", "spmv_variant",
+ * "mf_single_launch", "cell_lattice", "mg_refresh_every", "cg_speculate", "halo_skip", "cut_axis" (1 / 2 / 3: the slabs
+ * are cut along x / y / z, 0: not decomposed). */
 int mi_get_tuning(mi_ctx *ctx, const char *key, int *value);
 int mi_reset_timings(mi_ctx *ctx);
 int mi_get_timings(mi_ctx *ctx, mi_timings *out);
