@@ -25,10 +25,10 @@ python bench.py --steps 5 --warmup 2 --cpu-cells 0 --precond-storage f32 --smoot
 python bench.py --steps 5 --warmup 2 --cpu-cells 0 --cells 34 2>/dev/null | tail -1 > "$OUT/bench_n34_config3.json"
 mkdir -p "$OUT/emulated_slabs"
 for N in 1 2 4 8; do
-  python bench.py --steps 3 --warmup 1 --cpu-cells 0 --slabs $N 2>/dev/null | tail -1 > "$OUT/emulated_slabs/slabs$N.json"
+  python bench.py --steps 8 --warmup 2 --cpu-cells 0 --slabs $N 2>/dev/null | tail -1 > "$OUT/emulated_slabs/slabs$N.json"
 done
 for N in 2 4 8; do
-  python bench.py --steps 3 --warmup 1 --cpu-cells 0 --slabs $N --scaling weak 2>/dev/null | tail -1 > "$OUT/emulated_slabs/weak_slabs$N.json"
+  python bench.py --steps 4 --warmup 2 --cpu-cells 0 --slabs $N --scaling weak 2>/dev/null | tail -1 > "$OUT/emulated_slabs/weak_slabs$N.json"
 done
 timeout 400 python bench.py --cells 120 --steps 3 --warmup 1 --cpu-cells 0 2>/dev/null | tail -1 > "$OUT/bench_n120_42M_dofs.json"
 MI_ASM_STAMPS=1 python tools/tune_assemble.py --cells 59 --rounds 2 --reps 3 --variants 0,9 > "$OUT/assembly_kernels_n59.txt" 2>&1
@@ -37,3 +37,5 @@ bash tools/pmc_mf.sh > /dev/null 2>&1; cp gpurun_out/pmc_mf.json "$OUT/pmc_count
 bash tools/pmc_asm.sh > /dev/null 2>&1; cp gpurun_out/pmc_asm.json "$OUT/pmc_counters_assemble_q2sf_n59.json"
 python tools/time_element_products.py 59 2,1 > "$OUT/fine_level_product_forms_n59.txt" 2>&1
 ls -la "$OUT"
+python tools/mf_stamps.py 59 > "$OUT/mf_spmv_stage_stamps_n59.txt" 2>&1
+python tools/mf_ablate.py 59 > "$OUT/mf_spmv_ablations_n59.txt" 2>&1
