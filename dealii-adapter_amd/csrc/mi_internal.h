@@ -143,6 +143,8 @@ struct mi_ctx
                                // update, as the reference's do, 2 / 3: from the same solve of the previous time step(s)
   int       cg_fused_dot = 1; // 1: p.q partials in the epilogue of the CG's product, 0: separate reduction (A/B)
   int       correct_face_F = 0; // tuning "correct_face_F": the Neumann pull-back with F at the face point (default: the reference's quirk)
+  int       cg_r0_unassembled = 1; // A h of a predicted start vector by the matrix-free product where available ("cg_r0_operator")
+  bool      unassembled_now = false; // (set around that one product)
   int       cg_speculate = 1; // multigrid-PCG: enqueue the iterations the previous step's same solve needed (minus two)
                               // without polling the convergence flag in between (tuning "cg_speculate" 0: poll every one)
   int       pred_its[NPRED] = {}; // iterations of the j-th solve of the previous time step (0: unknown)

@@ -2182,12 +2182,12 @@ namespace mi
   // order as the colour-by-colour update, i.e. the same bits, in 2 launches instead of 8.
   // DBG (diagnostic instantiations, never in production): bit 0 stage stamps; timing-only ablations: bit 1 no result
   // stores, bit 2 every cell reads the records of cell 0 (cache hits), bit 3 every cell gathers the x of cell 0's nodes
-  template <bool BOX, bool SLOTS, bool LAT, int DBG = 0>
-  __global__ __launch_bounds__(64, 4) void mf_spmv(MfParams prm, int64_t cell0) // 5 waves per SIMD spill and lose 7 %
+  template <bool BOX, bool SLOTS, bool LAT, int DBG = 0, int OCC = 4>
+  __global__ __launch_bounds__(64, OCC) void mf_spmv(MfParams prm, int64_t cell0) // OCC = 5 (96 VGPRs) spills 8 registers: A/B MI_MF_OCC=5
   {
     constexpr bool STAMP = (DBG & 1) != 0;
     constexpr int NPC = 27;
-    // LDS (per cell, 7.9 kB): s0 = x (81 at 0) and the i-contracted lines A (2 x 108 at AO), then the (i,j)-contracted
+    // LDS (per cell, 7.9 kB): s0 = x (81 at AO) and the (i,j)-contracted
     // planes B (3 x 9 x 20 at 0; plane stride 20 and the lane order (c*3+k)*4 + qx keep their stores conflict free), then
     // the point results Q (12 x 64; the 16-lane groups of component 1 are swapped so that components 0 and 1, one
     // half-wave in I3, read different banks), then the qz-contracted planes C IN PLACE of the Q entries their lane
@@ -2266,6 +2266,13 @@ namespace mi
         Sz[k] = prm.tab1d[qz * 3 + k];
         Dz[k] = prm.tab1d[12 + qz * 3 + k];
       }
+    double Sx[3], Dx[3]; // rows qx = lane & 3 of the tables for the fused first gradient stage (lane = (c*3+k)*4 + qx)
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      {
+        Sx[i] = prm.tab1d[(lane & 3) * 3 + i];
+        Dx[i] = prm.tab1d[12 + (lane & 3) * 3 + i];
+      }
     // this lane's quadrature weight and (general geometry) unit-cell point: tab1d holds qw[4] at 24 and qx[4] at 28
     const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
     double       xiq[3];
@@ -2301,7 +2308,7 @@ namespace mi
         s_cm[lane]   = cm_l;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          s0[c * NPC + lane] = ((cm_l >> c) & 1) ? 0.0 : xg[c];
+          s0[AO + c * NPC + lane] = ((cm_l >> c) & 1) ? 0.0 : xg[c]; // (behind the planes B: they can land while x is read)
       }
     // the entries of y this lane will update at the very end (lane = line (c,k,j), its three nodes i): read now, the
     // colouring keeps every other cell of this launch away from them
@@ -2321,32 +2328,38 @@ namespace mi
       }
     __syncthreads();
     MF_STAMP(1); // x has arrived
-    // ---- E1: contract i.  lane = line (c,k,j); A_S / A_D [qx][c,k,j] at AO + {0,108} + qx*27 + lane
-    if (lane < 27)
-      {
-        const double x0 = v0[lane * 3], x1 = v0[lane * 3 + 1], x2 = v0[lane * 3 + 2];
-#pragma unroll
-        for (int qx = 0; qx < 4; ++qx)
-          {
-            s0[AO + qx * 27 + lane]       = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
-            s0[AO + 108 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
-          }
-      }
-    __syncthreads();
-    // ---- E2: contract j.  lane = (c*3+k)*4 + qx; B_DS / B_SD / B_SS [c*3+k][qy][qx] at {0,PW,2PW} (over x)
-    const int pck = lane >> 2, pqx = lane & 3; // plane index c*3+k and qx of this lane in E2 / I2
+    // ---- E1 + E2 in one stage (round 4): contract i, then j.  lane = (c*3+k)*4 + qx reads the nine x values of its
+    // plane (c,k) -- 9 LDS reads, as many as the two stages had between them --, forms A_S / A_D [qx][c,k,j] for ITS qx in
+    // registers (no lane computes one twice: 36 lanes x 6 = the 216 values the old first stage wrote to LDS and the second
+    // read back) and contracts j.  One stage and eight LDS stores fewer per cell; the 1D tables of the i-contraction
+    // are per-lane operands here (row qx of S and D).  x sits behind the planes (at AO, where the first stage's lines
+    // used to go), so they can be stored while other lanes still read.  B_DS / B_SD / B_SS [c*3+k][qy][qx] at {0,PW,2PW}
+    const int pck = lane >> 2, pqx = lane & 3; // plane index c*3+k and qx of this lane in E12 / I2
     if (lane < 36)
       {
-        const int    ia  = AO + pqx * 27 + pck * 3;
-        const double as0 = v0[ia], as1 = v0[ia + 1], as2 = v0[ia + 2];
-        const double ad0 = v0[108 + ia], ad1 = v0[108 + ia + 1], ad2 = v0[108 + ia + 2];
+        double bds[4], bsd[4], bss[4];
+        double as[3], ad[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          {
+            const double x0 = v0[AO + pck * 9 + j * 3], x1 = v0[AO + pck * 9 + j * 3 + 1], x2 = v0[AO + pck * 9 + j * 3 + 2];
+            as[j] = Sx[0] * x0 + Sx[1] * x1 + Sx[2] * x2;
+            ad[j] = Dx[0] * x0 + Dx[1] * x1 + Dx[2] * x2;
+          }
 #pragma unroll
         for (int qy = 0; qy < 4; ++qy)
           {
-            const int o     = pck * PS + qy * 4 + pqx;
-            s0[o]           = S[qy][0] * ad0 + S[qy][1] * ad1 + S[qy][2] * ad2; // d/dx
-            s0[o + PW]      = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2; // d/dy
-            s0[o + 2 * PW]  = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2; // value / d/dz
+            bds[qy] = S[qy][0] * ad[0] + S[qy][1] * ad[1] + S[qy][2] * ad[2]; // d/dx
+            bsd[qy] = D[qy][0] * as[0] + D[qy][1] * as[1] + D[qy][2] * as[2]; // d/dy
+            bss[qy] = S[qy][0] * as[0] + S[qy][1] * as[1] + S[qy][2] * as[2]; // value / d/dz
+          }
+#pragma unroll
+        for (int qy = 0; qy < 4; ++qy)
+          {
+            const int o    = pck * PS + qy * 4 + pqx;
+            s0[o]          = bds[qy];
+            s0[o + PW]     = bsd[qy];
+            s0[o + 2 * PW] = bss[qy];
           }
       }
     __syncthreads();
@@ -4231,6 +4244,9 @@ namespace mi
                            (q.cellbox ? mf_spmv<true, false, false> : mf_spmv<false, false, false>));
     if (q.stamps) // diagnostic: the production shape only (boxes, one launch, lattice ids or not)
       kern = q.lat.ncol > 0 ? mf_spmv<true, true, true, 1> : mf_spmv<true, true, false, 1>;
+    static const bool occ5 = getenv("MI_MF_OCC") && atoi(getenv("MI_MF_OCC")) == 5; // A/B: five waves per SIMD (spills)
+    if (occ5 && q.yc && q.cellbox && q.lat.ncol > 0 && !q.stamps)
+      kern = mf_spmv<true, true, true, 0, 5>;
     static const int dbg = getenv("MI_MF_DBG") ? atoi(getenv("MI_MF_DBG")) : 0; // timing-only ablations (wrong results)
     if (dbg && q.yc && q.cellbox && q.lat.ncol > 0)
       kern = dbg == 2 ? mf_spmv<true, true, true, 2> : dbg == 4 ? mf_spmv<true, true, true, 4> : dbg == 8 ? mf_spmv<true, true, true, 8> :

@@ -287,6 +287,8 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  tangents | assembled matrix
  *  cg_operator          0 | 1                      the CG's own product on the assembled matrix (north star) | in the   -
  *                                                  smoother's unassembled form (A/B)
+ *  cg_r0_operator       1 | 0                      A h of a predicted start vector h ("cg_warm_start" 2 / 3) by the     -
+ *                                                  matrix-free product where the point records exist | assembled
  *  precond_storage      64 | 32                    smoother multiplies with the fp64 matrices | an fp32-rounded copy    -
  *                                                  (opt-in; arithmetic, CG product, residuals stay fp64)
  *  mf_single_launch     1 | 0                      matrix-free product: one launch + gather | eight colour launches     MI_MF_SINGLE_LAUNCH

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Start the `elasticity` executable on N GPUs of one node: one process per GPU, the box cut into N slabs (along the direction with most cell layers), ghost planes
 and reductions over RCCL (the reference is single-rank, adapter.h:152-154; this is the launcher DESIGN.md section 6
-describes).  Every process runs the same program on global views of the interface; with the replay participant (the
-default build) the coupling side of the case is therefore unchanged, and rank 0 prints and writes the output files.
-A -DMI_WITH_PRECICE build refuses MI_WORLD_SIZE > 1: N processes would each register as the single rank of the same
-preCICE participant (host/include/adapter/adapter.h).
+describes).  Every process runs the same program on global views of the interface; ONE process talks to the coupling
+library: rank 0 owns the precice::Participant (replay participant or, in a -DMI_WITH_PRECICE build, libprecice) and the other
+ranks receive what it reads through mi_comm_broadcast (host/include/adapter/rank_zero_participant.h); rank 0 prints and
+writes the output files.
 
   python tools/launch_elasticity.py -n 8 [--exe dealii-adapter_amd/host/elasticity3d] [parameters.prm]
 
