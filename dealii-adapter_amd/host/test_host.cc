@@ -1,6 +1,10 @@
 // CPU-only unit tests of the host-side boundary code (no device calls): parameter file reader, Adapter::Time,
 // replay participant, Adapter call sequence with a mock vector type.  Run by tests/test_host_cpu.py.
 #include <cassert>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <fstream>
@@ -281,6 +285,124 @@ int main()
     time.increment();
     ad.advance(u, 0.01);
     CHECK(throws([&] { ad.reload_old_state_if_required(two, time); }, "not the same as previously saved"));
+  }
+  // several ranks, ONE participant (round 4; adapter.h:152-154, 213-225): two rank THREADS drive an Adapter each through an
+  // implicit-coupling run; rank 0 owns the participant, rank 1 receives read data and every coupling decision through the
+  // broadcast its DoF source provides (here: a buffer in shared memory and a two-thread barrier standing in for
+  // mi_comm_broadcast).  Both ranks must see the same call results, and only one participant may write the log.
+  {
+    write_file("t_ranks.xml", R"(<precice-configuration dimensions="2">
+  <!-- replay: read-data = constant 0 -8 0 -->
+  <!-- replay: write-log = t_ranks.log -->
+  <coupling-scheme:serial-implicit>
+    <max-time-windows value="2" /> <time-window-size value="0.01" /> <max-iterations value="3" />
+  </coupling-scheme:serial-implicit>
+</precice-configuration>)");
+    struct P
+    {
+      std::string participant_name = "Solid", config_file = "t_ranks.xml", mesh_name = "m", read_data_name = "Stress",
+                  write_data_name = "Displacement";
+    };
+    struct Shared
+    {
+      std::mutex              m;
+      std::condition_variable cv;
+      int                     arrived = 0, generation = 0;
+      std::vector<double>     buf;
+      void barrier()
+      {
+        std::unique_lock<std::mutex> lk(m);
+        const int                    g = generation;
+        if (++arrived == 2)
+          {
+            arrived = 0;
+            ++generation;
+            cv.notify_all();
+          }
+        else
+          cv.wait(lk, [&] { return generation != g; });
+      }
+    } sh;
+    struct RankDofs : MockDofs
+    {
+      Shared *sh;
+      int     rank;
+      std::function<void(double *, int)> broadcaster() const
+      {
+        Shared   *s = sh;
+        const int r = rank;
+        return [s, r](double *v, int n) {
+          if (r == 0)
+            s->buf.assign(v, v + n);
+          s->barrier(); // rank 0 has published
+          if (r != 0)
+            std::copy(s->buf.begin(), s->buf.begin() + n, v);
+          s->barrier(); // everyone has read: the buffer may be reused
+        };
+      }
+    };
+    std::vector<std::vector<double>> seen(2);
+    std::vector<int>                 calls(2, 0), completed(2, 0), steps(2, 0);
+    std::vector<std::string>         errors(2);
+    auto rank_main = [&](int r) {
+      try
+        {
+          mi::thread_identity() = mi::RankIdentity{r, 2, nullptr, 0};
+          P                                  par;
+          Adapter::Adapter<2, MockVector, P> ad(par, 7);
+          MockVector                         u, stress;
+          Adapter::Time                      time(1.0, 0.01);
+          RankDofs                           dofs;
+          dofs.sh   = &sh;
+          dofs.rank = r;
+          ad.initialize(dofs, u);
+          std::vector<MockVector *> state = {&u};
+          while (ad.precice.isCouplingOngoing())
+            {
+              ad.save_current_state_if_required(state, time);
+              time.increment();
+              if (std::abs(ad.precice.getMaxTimeStepSize() - 0.01) > 1e-15)
+                errors[size_t(r)] = "window size";
+              ad.read_data(0.01, stress);
+              seen[size_t(r)].push_back(stress.v[1]);
+              u.v[0] += 1.0;
+              ad.advance(u, 0.01);
+              ad.reload_old_state_if_required(state, time);
+              if (ad.precice.isTimeWindowComplete())
+                ++completed[size_t(r)];
+              if (++calls[size_t(r)] > 50)
+                break;
+            }
+          ad.precice.finalize();
+          steps[size_t(r)] = int(time.get_timestep());
+          mi::thread_identity() = mi::RankIdentity{};
+        }
+      catch (std::exception &e)
+        {
+          errors[size_t(r)] = e.what();
+        }
+    };
+    std::thread t1(rank_main, 1);
+    rank_main(0);
+    t1.join();
+    CHECK(errors[0].empty() && errors[1].empty());
+    CHECK(calls[0] == 6 && calls[1] == 6 && completed[0] == 2 && completed[1] == 2 && steps[0] == 2 && steps[1] == 2);
+    CHECK(seen[0] == seen[1] && seen[0].size() == 6 && std::abs(seen[1][0] + 4.0) < 1e-12 && std::abs(seen[1][2] + 8.0) < 1e-12);
+    std::ifstream log("t_ranks.log");
+    std::string   line;
+    int           rows = 0;
+    while (std::getline(log, line))
+      rows += (!line.empty() && line[0] != '#');
+    CHECK(rows == 2); // one participant, one row per completed window
+    // several ranks but no broadcast bound: refused, not silently wrong
+    mi::thread_identity() = mi::RankIdentity{1, 2, nullptr, 0};
+    {
+      P                                  par;
+      Adapter::Adapter<2, MockVector, P> ad(par, 7);
+      MockVector                         u;
+      CHECK(throws([&] { ad.initialize(MockDofs(), u); }, "no broadcast bound"));
+    }
+    mi::thread_identity() = mi::RankIdentity{};
   }
   // per-vertex trace replay: rows "t vertex fx fy", linear interpolation in time per vertex, constant outside the
   // recorded range; the coupling-mesh vertices are written out for whoever records such a trace
