@@ -735,6 +735,8 @@ namespace mi
     __shared__ int  s_conn[NPC];
     __shared__ int2 s_ri[RES_ONLY ? 1 : NPC]; // rowinfo of the cell's nodes (where their rows are in the global matrix)
     __shared__ int  s_cm[RES_ONLY ? 1 : NPC]; // their constraint bits
+    __shared__ int  s_plain;                  // 1: no node of the cell is constrained and every node has a row here (the
+                                              // scatter then skips the per-entry masking: all but the boundary cells)
     typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
     const int     tid  = (XV & 1) ? int((((threadIdx.x >> 6) + blockIdx.x) & 3) << 6 | (threadIdx.x & 63)) : int(threadIdx.x);
     const int64_t cell = prm.cell_begin + blockIdx.x;
@@ -1105,6 +1107,12 @@ namespace mi
         {
           const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
           uint64_t *const tab = reinterpret_cast<uint64_t *>(s_w);
+          {
+            const bool special = lane < NPC && (s_cm[lane] != 0 || s_ri[lane].x < 0);
+            const bool any     = __builtin_amdgcn_ballot_w64(special) != 0;
+            if (lane == 0)
+              s_plain = any ? 0 : 1;
+          }
           uint16_t        o[12];
 #pragma unroll
           for (int r = 0; r < 12; ++r) // all twelve (coalesced) loads in flight at once
@@ -1231,6 +1239,7 @@ namespace mi
           const uint32_t cm      = (1u << ei) | (8u << ej);                          // constraint bits that kill this entry
           const bool     on_diag = ei == ej;
           double *const  vbase   = prm.vals + e;
+          const bool     plain   = s_plain != 0; // uniform: the table is complete since barrier (2)
           // phase A: the old values of every entry that is not a first touch, all requested before anything is stored
           // (loads and stores share the wave's memory counter: a load issued after a store waits for that store).
           // Batches of nine: the table words of a batch in one LDS round trip, then its nine loads.
@@ -1249,7 +1258,7 @@ namespace mi
               for (int u = 0; u < 9; ++u)
                 {
                   const int  blk = (bb + u) * 28 + tq;
-                  const bool rd  = !(XV & 2) && tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu && !((t[u] >> 42) & 1);
+                  const bool rd  = !(XV & 2) && tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu) && !((t[u] >> 42) & 1);
                   old[bb + u]    = rd ? vbase[int64_t(uint32_t(t[u])) * 9] : 0.0;
                 }
             }
@@ -1277,9 +1286,9 @@ namespace mi
                   const int      blk = (bb + u) * 28 + tq;
                   const uint32_t fl  = uint32_t(t[u] >> 32);
                   double         w_  = v[u];
-                  if ((fl >> 12) & cm)
+                  if (!plain && ((fl >> 12) & cm))
                     w_ = (((fl >> 11) & 1) && on_diag) ? fabs(w_) : 0.0;
-                  if (tq < 28 && blk < NPC * NPC && uint32_t(t[u]) != 0xffffffffu)
+                  if (tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu))
                     {
                       if ((XV & 2) && !((t[u] >> 42) & 1))
                         unsafeAtomicAdd(&vbase[int64_t(uint32_t(t[u])) * 9], w_);
