@@ -61,6 +61,7 @@ namespace mi_detail
     size_t n_dist        = 1;    // levels [0, n_dist) are distributed over the slabs of the team, the others replicated
     int    nu            = 3;    // Chebyshev degree of the pre- and post-smoother on the finest level
     int    nu_coarse     = 2;    // ... on the coarser levels
+    int    nu_level1     = 0;    // ... on level 1 alone (0: nu_coarse; MI_MG_NU_L1, experiment of round 4)
     int    fuse          = 1;    // Chebyshev update / residual in the epilogue of the product (one launch instead of two):
                                  // 0 never, 1 on the latency-bound levels (<= fuse_max_nodes), 2 on every level
     int64_t fuse_max_nodes = 100000;
@@ -413,6 +414,8 @@ namespace mi_detail
       mg->nu = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_NU_COARSE"))
       mg->nu_coarse = std::max(1, atoi(e));
+    if (const char *e = getenv("MI_MG_NU_L1"))
+      mg->nu_level1 = std::max(0, atoi(e));
     if (const char *e = getenv("MI_MG_FUSE"))
       mg->fuse = std::min(2, std::max(0, atoi(e)));
     if (const char *e = getenv("MI_MG_FUSE_MAX_NODES"))
@@ -778,7 +781,7 @@ namespace mi_detail
           return MI_OK;
         }
       const bool dist_l = is_dist(T, l), dist_c = is_dist(T, l + 1);
-      const int  nu     = (l == 0) ? mg0.nu : mg0.nu_coarse;
+      const int  nu     = (l == 0) ? mg0.nu : ((l == 1 && mg0.nu_level1 > 0) ? mg0.nu_level1 : mg0.nu_coarse);
       if ((rc = smooth(T, l, nu, true)))
         return rc;
       auto x_of   = [l](mi_ctx *m) { return m->mg->levels[l].x(); };

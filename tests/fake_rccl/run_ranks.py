@@ -77,6 +77,11 @@ def scenario(G, M, kw, log):
     out["restored"] = G.get(M.V_U)
     lin = linear_scenario(G, M)
     out["lin_d"], out["lin_v"] = lin["d"], lin["v"]
+    # rank 0's values to every rank (what carries the ONE preCICE-facing process's answers to the others): each rank offers
+    # different numbers, longer than the interface scratch (several chunks), with a -0.0 and a huge value among them
+    rank = kw.get("rank", 0)
+    mine = (rank + 1.0) * np.concatenate([[-0.0, 1e300, -3.5], np.arange(3 * G.dim * len(ids) + 11, dtype=np.float64)])
+    out["bcast"] = G.comm_broadcast(mine)
     return out
 
 
@@ -96,7 +101,7 @@ def main():
     def rank_main(r):
         try:
             G = M.Context(rank=r, world=world, unique_id=uid, **common)
-            results[r] = scenario(G, M, dict(overlap=overlap, ebe=ebe), None)
+            results[r] = scenario(G, M, dict(overlap=overlap, ebe=ebe, rank=r), None)
             G.close()
         except BaseException as e:  # noqa: BLE001 -- reported to the parent test
             errors.append("rank %d: %r" % (r, e))
@@ -117,6 +122,8 @@ def main():
 
     rep = {"ok": True, "world": world, "its_ranks": [results[r]["its0"] + results[r]["its1"] for r in range(world)],
            "its_single": single["its0"] + single["its1"], "its_emulated": emu["its0"] + emu["its1"]}
+    ref = np.concatenate([[0.0, 1e300, -3.5], np.arange(results[0]["bcast"].size - 3, dtype=np.float64)])
+    rep["broadcast_ok"] = bool(all(np.array_equal(results[r]["bcast"], ref) for r in range(world)))
     keys = ("u0", "u1", "if0", "if1", "Kx", "restored", "lin_d", "lin_v")
     rep["rank_spread"] = max(rel(results[r][k], results[0][k]) for r in range(1, world) for k in keys) if world > 1 else 0.0
     rep["vs_single"] = {k: rel(results[0][k], single[k]) for k in keys}

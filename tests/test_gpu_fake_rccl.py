@@ -41,6 +41,7 @@ def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, ove
     r = json.loads(lines[-1])
     assert r["ok"], r
     assert r["rank_spread"] == 0.0  # every rank returns the same global arrays, bit for bit
+    assert r["broadcast_ok"]  # mi_comm_broadcast: rank 0's values on every rank, whatever the others passed in
     for k, v in r["vs_single"].items():
         assert v < 1e-7, (k, v, r)  # CG tolerance 1e-10 on both sides
     for k, v in r["vs_emulated"].items():
