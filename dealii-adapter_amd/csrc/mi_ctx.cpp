@@ -158,6 +158,7 @@ namespace mi_detail
         rows[c].magic_mx  = (uint64_t(1) << 42) / uint64_t(mx) + 1;
         rows[c].magic_mxy = (uint64_t(1) << 42) / uint64_t(mx * my) + 1;
         rows[c].base      = p * (par[0] + m.nn[0] * (par[1] + m.nn[1] * par[2]));
+        rows[c].pz        = par[2];
       }
     for (int c = m.ncolours; c <= 8; ++c)
       L.begin[c] = int32_t(m.ncells); // unused colours are empty ranges at the end
@@ -388,7 +389,12 @@ namespace mi_detail
         // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
         // by layer: the whole product waits for the ghost planes of x (part 2 = after the halo exchange); the rows of
         // the ghost planes receive partial sums that nobody reads
-        if (part == 1)
+        // ... unless the cells can be told apart by their layer (round 4: matrix-free, one launch, lattice ids): the cells that
+        // touch no ghost plane of x -- all but the lowest layer (rank > 0) and the ghost layer (rank < size - 1) -- run as part 1
+        // while the halo is in flight, the others as part 2; every cell still writes its own slots, so the sum is the same
+        const bool mf_split = part != 0 && kind == 2 && c->mf_slots && c->d_mf_yc && c->lat.ncol > 0 && c->team->mf_overlap &&
+                              !ebe_for_cg;
+        if (part == 1 && !mf_split)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
         mi::MfParams  f{};
@@ -420,9 +426,46 @@ namespace mi_detail
         const bool sample = c0->profiling && (c->ebe_products++ % 6 == 0);
         if (one_launch) // all cells at once (no two cells share a slot), then the sum over the slots of every node
           {
-            const int t = sample ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
-            mi::launch_mf_spmv(f, 0, int32_t(c->mesh.ncells), c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
-                               t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+            if (mf_split)
+              {
+                // layers [za, zb) of the slab's cells: one contiguous range of positions per colour (z slowest)
+                auto layers = [&](int za, int zb) {
+                  mi::MfParams g = f;
+                  int32_t      n = 0;
+                  for (int col = 0; col < 8; ++col)
+                    {
+                      g.sel_begin[col] = n;
+                      g.sel_pos0[col]  = 0;
+                      if (col >= c->lat.ncol)
+                        continue;
+                      const mi::CellLatticeRow &R = c->lat_rows_host[size_t(col)];
+                      const int mz = int((c->lat.begin[col + 1] - c->lat.begin[col]) / R.mxy);
+                      // cells of the colour have cz = 2 rz + pz: rz in [ceil((za - pz) / 2), ceil((zb - pz) / 2))
+                      const int ra = std::min(mz, std::max(0, (za - R.pz + 1) / 2)), rb = std::min(mz, std::max(0, (zb - R.pz + 1) / 2));
+                      g.sel_pos0[col] = c->lat.begin[col] + ra * R.mxy;
+                      n += std::max(0, rb - ra) * R.mxy;
+                    }
+                  g.sel_begin[8] = n;
+                  g.sel_n        = n;
+                  if (n > 0)
+                    mi::launch_mf_spmv(g, 0, n, c->stream);
+                };
+                const int nzl = c->mesh.reps[2];
+                const int zlo = c->slab.rank > 0 ? 1 : 0, zhi = c->slab.rank + 1 < c->team->size ? nzl - 1 : nzl;
+                if (part == 1)
+                  {
+                    layers(zlo, zhi); // no ghost plane of x in reach: while the halo is in flight
+                    return;           // (the slot sum follows the other layers)
+                  }
+                layers(0, zlo);
+                layers(zhi, nzl);
+              }
+            else
+              {
+                const int t = sample ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
+                mi::launch_mf_spmv(f, 0, int32_t(c->mesh.ncells), c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                   t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+              }
             if (cheb && cheb->xnext) // the smoother's step on the owned nodes, straight from the slots (three-term form)
               mi::launch_mf_gather_cheb3(f, cheb->b, cheb->dinv6, cheb->xprev, x, cheb->xnext, cheb->c1, cheb->c2, c->own0 / 3,
                                          c->own_n / 3, c->stream);
@@ -1142,6 +1185,7 @@ namespace mi_detail
             if (rl)
               return rl;
             c->lat_built.rows = c->d_lat_rows;
+            c->lat_rows_host  = rows;
           }
         if (!(getenv("MI_CELL_LATTICE") && atoi(getenv("MI_CELL_LATTICE")) == 0))
           c->lat = c->lat_built;
@@ -2374,6 +2418,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_speculate = value;
       else if (k == "halo_skip" && (value == 0 || value == 1))
         c->team->halo_skip = value;
+      else if (k == "mf_halo_overlap" && (value == 0 || value == 1))
+        c->team->mf_overlap = value;
       else if (k == "mg_fuse" && value >= 0 && value <= 2)
         {
           const int rc = mg_set_fuse(m, value);

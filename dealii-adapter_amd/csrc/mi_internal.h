@@ -64,6 +64,8 @@ namespace mi_detail
     hipStream_t           comm_stream = nullptr; // RCCL halo exchange next to the interior rows of the SpMV
     hipEvent_t            ev_ready = nullptr, ev_halo = nullptr;
     int                   overlap  = 1;          // 0: halo exchange in line on `stream`
+    int                   mf_overlap = 1;        // the matrix-free product of a slab in two launches around its halo exchange
+                                                 // (inner layers while the ghost planes travel); 0: one launch after it
     int                   halo_skip = 1;         // 1: products whose operand's ghost planes are known to be current (the
                                                  // first post-smoothing step after a prolongation that filled them) run
                                                  // without an exchange; 0: every product exchanges (A/B, bitwise the same)
@@ -129,6 +131,7 @@ struct mi_ctx
   mi::CellLattice lat;                // 3D Q2: node ids of a cell by arithmetic (ncol == 0: unavailable / switched off)
   mi::CellLattice lat_built;          // ... as built at creation (tuning "cell_lattice" 0 / 1 switches lat)
   mi::CellLatticeRow *d_lat_rows = nullptr; // its per-colour rows
+  std::vector<mi::CellLatticeRow> lat_rows_host; // (host copy: layer ranges of a slab's product, enqueue_spmv)
   double   *d_cellbox = nullptr; // with d_qrec when every local cell is an axis-parallel box: [ncells][4] = 1/h, volume
   bool      ke_valid = false; // d_ke / d_qrec belong to the current tangent
   int64_t   ebe_products = 0; // element-tangent products so far (profiling samples every 6th)

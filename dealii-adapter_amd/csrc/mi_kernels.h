@@ -18,7 +18,7 @@ namespace mi
   // block to scratch at the head of every wave (0.72 instead of 0.40 ms per product, measured).
   struct CellLatticeRow
   {
-    int32_t  mx, mxy, base, pad;
+    int32_t  mx, mxy, base, pz; // pz: parity of the colour's cells along the last lattice direction
     uint64_t magic_mx, magic_mxy;
   };
   struct CellLattice
@@ -99,6 +99,12 @@ namespace mi
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
     CellLattice     lat;       // node ids by arithmetic (ncol == 0: read conn)
     unsigned long long *stamps; // diagnostic (null in production): [cells][8] shader-clock stamps at the stage boundaries
+    // slabs, lattice ids only: a launch over the cells of the layers [z_a, z_b) of the last lattice direction alone (the
+    // layers that touch no ghost plane of x run while the halo is in flight, the others after it).  Cells are sorted by
+    // colour with z slowest, so the layers' cells are ONE contiguous range of positions per colour: workgroup `local` of the
+    // launch takes position sel_pos0[c] + (local - sel_begin[c]) of colour c, sel_begin[c] <= local < sel_begin[c + 1].
+    // sel_n == 0: all cells, position = local.
+    int32_t         sel_n, sel_begin[9], sel_pos0[8];
   };
 
   // constant operators of the linear model (linear_elasticity.cc:248-374), one launch per colour

@@ -673,7 +673,7 @@ namespace mi
   // first node of the cell at colour-sorted position pos, from the lattice description alone (mi::CellLattice): uniform
   // operands, i.e. scalar instructions and one scalar load -- no vector-memory round trip between a workgroup's start
   // and its first gather
-  __device__ __forceinline__ int32_t lattice_node0(const CellLattice &L, int64_t pos)
+  __device__ __forceinline__ int32_t lattice_node0(const CellLattice &L, int64_t pos, int32_t *cz = nullptr)
   {
     const int32_t p   = int32_t(pos);
     int           col = 0;
@@ -690,6 +690,8 @@ namespace mi
     const uint32_t rem = r - rz * uint32_t(R.mxy);
     const uint32_t ry  = uint32_t((uint64_t(rem) * R.magic_mx) >> 42);
     const uint32_t rx  = rem - ry * uint32_t(R.mx);
+    if (cz)
+      *cz = 2 * int32_t(rz) + R.pz; // the cell's layer along the last lattice direction
     return R.base + int32_t(rx) * L.sx + int32_t(ry) * L.sy + int32_t(rz) * L.sz;
   }
 
@@ -2219,6 +2221,20 @@ namespace mi
           return;
         cell = cell0 + local;
       }
+    if constexpr (LAT)
+      if (prm.sel_n > 0) // a launch over some layers of a slab: `cell` counts the selected cells, colour by colour
+        {
+          const int32_t l    = int32_t(cell - cell0);
+          int32_t       b    = prm.sel_begin[0], p0 = prm.sel_pos0[0];
+#pragma unroll
+          for (int c = 1; c < 8; ++c)
+            if (l >= prm.sel_begin[c])
+              {
+                b  = prm.sel_begin[c];
+                p0 = prm.sel_pos0[c];
+              }
+          cell = int64_t(p0) + (l - b);
+        }
     // diagnostic instantiation: shader-clock stamps at the stage boundaries, kept in LDS until the end (a global store
     // in the middle of the kernel makes the compiler give up the scalar registers of the 1D tables)
     __shared__ unsigned long long s_st[STAMP ? 8 : 1];

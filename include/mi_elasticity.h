@@ -297,6 +297,9 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *  DECOMPOSITION
  *  halo_overlap         1 | 0                      ghost planes exchanged on the communication stream next to the       MI_HALO_OVERLAP
  *                                                  interior rows | in line (same bits)
+ *  mf_halo_overlap      1 | 0                      a slab's matrix-free product in launches over cell layers: the       -
+ *                                                  layers away from the ghost planes while the halo travels | one
+ *                                                  launch after the exchange (same bits)
  *  halo_skip            1 | 0                      no exchange before a product whose operand's ghost planes are        -
  *                                                  current (first post-smoothing step) | always exchange (same bits)
  *  KERNEL A/B (timing, tests)

@@ -191,6 +191,32 @@ def test_halo_skip_is_bitwise_neutral(reps, slabs):
     assert runs[0][6] == (2 if reps[0] > 20 else 0)
 
 
+@pytest.mark.parametrize("reps,slabs,cut_axis", [((24, 24, 48), 2, 0), ((24, 24, 72), 3, 0), ((48, 24, 24), 2, 1)])
+def test_matrix_free_product_overlaps_its_halo_exchange_bitwise(reps, slabs, cut_axis):
+    """round 4: on a slab the smoother's matrix-free product runs in launches over cell LAYERS -- the layers that touch no
+    ghost plane of x while the halo exchange is in flight, the lowest layer and the ghost layer after it (a layer's cells are
+    one contiguous range of positions per colour: `sel_begin` / `sel_pos0`).  Every cell still writes its own slots, so the
+    product, and with it every iterate, is bit-identical with the single launch after the exchange ("mf_halo_overlap" 0).
+    Middle slabs have both kinds of boundary layer; the last case lies rotated over the box (cut along x)."""
+    runs = []
+    for overlap in (1, 0):
+        _, G = _setup(3, 2, reps, slabs, perturb_amp=0.0, cut_axis=cut_axis)
+        G.set_tuning("precond", 1)
+        G.set_tuning("cg_warm_start", 2)
+        G.set_tuning("mf_halo_overlap", overlap)
+        rows, u, v, a = _ramp_steps(G, 2)
+        assert G.get_tuning("smoother_operator_active") == 2
+        rng = np.random.default_rng(5)
+        x = rng.standard_normal(G.n)
+        G.set_tuning("spmv_variant", 4)  # the product itself through the same path
+        y = G.spmv(x)
+        runs.append((rows, u, v, a, y))
+        G.close()
+    assert runs[0][0] == runs[1][0]
+    for k in (1, 2, 3, 4):
+        assert np.array_equal(runs[0][k], runs[1][k])
+
+
 @pytest.mark.parametrize("slabs", [1, 3])
 def test_speculative_enqueue_does_not_change_the_solve(slabs):
     """round 4: from the second time step on, a multigrid-PCG solve enqueues the iterations the same solve needed one
