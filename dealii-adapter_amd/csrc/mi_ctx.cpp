@@ -1287,8 +1287,9 @@ namespace mi_detail
       constexpr int64_t W = mi::SELL_WPB; // one wavefront per slice, W wavefronts per workgroup ...
       // ... unless the launch is small: then one WORKGROUP per slice (sell_spmv_split), decided by the slice count alone
       const bool use_split = !(getenv("MI_SELL_SPLIT") && atoi(getenv("MI_SELL_SPLIT")) == 0);
-      c->split_int      = use_split && nin > 0 && nin <= mi::SELL_SPLIT_MAX_SLICES;
-      c->split_bnd      = use_split && nbd > 0 && nbd <= mi::SELL_SPLIT_MAX_SLICES;
+      const int  split_max = getenv("MI_SELL_SPLIT_MAX") ? atoi(getenv("MI_SELL_SPLIT_MAX")) : mi::SELL_SPLIT_MAX_SLICES; // A/B
+      c->split_int      = use_split && nin > 0 && nin <= split_max;
+      c->split_bnd      = use_split && nbd > 0 && nbd <= split_max;
       c->grid_spmv_bnd  = c->split_bnd ? int(nbd) : int(std::min<int64_t>(MAX_PART / 4, (nbd + W - 1) / W));
       c->grid_spmv_int  = c->split_int ? int(nin) : int(std::min<int64_t>(MAX_PART - c->grid_spmv_bnd, (nin + W - 1) / W));
       c->grid_spmv      = std::max(1, c->grid_spmv_int + c->grid_spmv_bnd);
