@@ -2861,14 +2861,23 @@ namespace mi
     const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
     const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
     double        srr = 0.0, srz = 0.0;
-    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
-      {
-        c.x[i] += alpha * c.p[i];
-        const double ri = c.r[i] - alpha * c.q[i];
-        c.r[i]          = ri;
-        srr += ri * ri;
-        srz += ri * ri * c.dinv[i];
-      }
+    if (c.z) // general preconditioner: r.z is formed after z = M^-1 r, the Jacobi diagonal is not read
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+        {
+          c.x[i] += alpha * c.p[i];
+          const double ri = c.r[i] - alpha * c.q[i];
+          c.r[i]          = ri;
+          srr += ri * ri;
+        }
+    else
+      for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+        {
+          c.x[i] += alpha * c.p[i];
+          const double ri = c.r[i] - alpha * c.q[i];
+          c.r[i]          = ri;
+          srr += ri * ri;
+          srz += ri * ri * c.dinv[i];
+        }
     srr = block_sum<256>(srr, s_red);
     srz = block_sum<256>(srz, s_red);
     if (threadIdx.x == 0)
