@@ -3509,6 +3509,26 @@ namespace mi
   // x = K^-1 b with K in `band` (overwritten by its factor).  b, x: vectors in the library's dof order (dof = D node + c);
   // bperm: node -> band position; work: n doubles.  flag[0] = 1 when a pivot is not positive (K not positive definite).
   // factor_only / solve_only split the two halves (the linear model factorises its constant matrix once).
+  // value of lane `lane` (uniform) in every lane: two v_readlane_b32 into scalar registers -- a few cycles, where __shfl goes
+  // through the LDS crossbar (ds_bpermute) and costs a hundred
+  __device__ __forceinline__ double lane_value(double v, int lane)
+  {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+  }
+  // 1 / sqrt(d): the hardware estimate (26 bits) and two Newton steps (sqrt and a division in double precision are two long
+  // dependent instruction chains, on the critical path of every pivot of a factorisation)
+  __device__ __forceinline__ double rsqrt_nr(double d)
+  {
+    double rd = __builtin_amdgcn_rsq(d);
+#pragma unroll
+    for (int nr = 0; nr < 2; ++nr)
+      {
+        const double e = fma(-d * rd, rd, 1.0);
+        rd             = fma(0.5 * rd, e, rd);
+      }
+    return rd;
+  }
   template <int D>
   __global__ __launch_bounds__(1024) void band_cholesky_solve(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
                                                              int nnodes, const double *__restrict__ b, double *x, double *work,
@@ -3698,6 +3718,302 @@ namespace mi
             for (int q = nb - 1; q >= 0; --q)
               {
                 const double xq = __shfl(w, q, 64) / sL[q][q];
+                if (tid == q)
+                  w = xq;
+                else if (tid < q)
+                  w -= sL[q][tid] * xq;
+              }
+            if (tid < nb)
+              work[j0 + tid] = w;
+          }
+        __syncthreads();
+      }
+    for (int i = tid; i < n; i += 1024)
+      {
+        const int node = i / D, c = i - node * D;
+        x[i]           = work[bperm[node] * D + c];
+      }
+  }
+
+  // ------------------------------------------------------------------ banded Cholesky, LDS-window form (round 4)
+  // The same factorisation K = L L^T + substitutions for half bandwidths hbw <= BAND_LDS_W - BAND_NB (the reference's 2D
+  // geometries: 67 dofs at the shipped degree 3): the ACTIVE part of the matrix -- the BAND_LDS_W rows below the current
+  // block column, i.e. everything a block column's panel and trailing update touch -- lives in LDS as a circular window
+  // (entry (r, c) at [(r mod W) * (W + 1) + (c mod W)]; the padded row stride keeps column walks conflict free), so a block
+  // column is: the diagonal block factorised by wave 0 in registers, the panel rows solved against it, the trailing update
+  // -- all LDS to LDS -- and two streams that nobody waits for: the finished columns go out to the band in memory, the NB
+  // rows that enter the window next come in (requested at the top of the iteration, stored at its end).  band_cholesky_solve
+  // above pays three dependent round trips to the L2 per block column for the same work: 23 us per block column on the
+  // shipped FSI3 case against ~4 here.  The forward substitution rides along (y is one more LDS vector, updated by the
+  // panel's threads); the backward substitution reads L back from memory.  Three workgroup barriers per block column.
+  constexpr int BAND_LDS_W = 128;
+  template <int D>
+  __global__ __launch_bounds__(1024) void band_cholesky_lds(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
+                                                            int nnodes, const double *__restrict__ b, double *x, double *work,
+                                                            int32_t *flag, int do_solve, unsigned long long *dbg)
+  {
+    constexpr int NB = BAND_NB, W = BAND_LDS_W, LD = W + 1;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0; // diagnostic (dbg != null): clocks per phase, thread 0
+#define BAND_STAMP(i_)                                             \
+  do                                                               \
+    {                                                              \
+      if (dbg && tid == 0)                                         \
+        {                                                          \
+          const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+          tacc[i_] += now_ - tlast;                                \
+          tlast = now_;                                            \
+        }                                                          \
+    }                                                              \
+  while (0)
+    static_assert(W % NB == 0, "a block column must not wrap inside the window");
+    __shared__ double S[W * LD];  // slot row (r mod W), slot column (c mod W); slots outside a row's band hold ZERO
+    __shared__ double yv[W];      // right-hand side / y of the rows in the window (circular)
+    __shared__ double sy[NB];     // y of the current block
+    __shared__ double srd[NB];    // 1 / L_cc of the current block
+    __shared__ double sL[NB][NB + 1];
+    const int tid = threadIdx.x, ld = hbw + 1;
+    // ---- right-hand side into band order (memory)
+    if (do_solve)
+      for (int i = tid; i < n; i += 1024)
+        {
+          const int node = i / D, c = i - node * D;
+          work[bperm[node] * D + c] = b[i];
+        }
+    // ---- the first window: rows [0, W); every slot gets its band entry or zero (slot cs of row r holds column
+    // c = r - ((r - cs) mod W), the one column of (r - W, r] with that residue)
+    for (int idx = tid; idx < W * W; idx += 1024)
+      {
+        const int r = idx >> 7, cs = idx & (W - 1), c = r - ((r - cs) & (W - 1)), k = r - c;
+        S[r * LD + cs] = (r < n && c >= 0 && k <= hbw) ? band[int64_t(c) * ld + k] : 0.0;
+      }
+    __syncthreads();
+    if (do_solve && tid < W)
+      yv[tid] = tid < n ? work[tid] : 0.0;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += NB)
+      {
+        const int nb = min(NB, n - j0), jc = j0 & (W - 1); // the block's columns are the slots jc .. jc + NB - 1
+        if (dbg && tid == 0 && j0 == 0)
+          tlast = __builtin_amdgcn_s_memtime();
+        // the rows that enter the window when this block column is done: requested now, stored at the end
+        double pre[2], prey = 0.0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          {
+            const int idx = tid + u * 1024, rr = idx >> 7, cs = idx & (W - 1), rn = j0 + W + rr;
+            const int c = rn - ((rn - cs) & (W - 1)), k = rn - c;
+            pre[u] = (rn < n && k <= hbw) ? band[int64_t(c) * ld + k] : 0.0; // (c >= 0: rn >= W)
+          }
+        if (do_solve && tid < NB && j0 + W + tid < n)
+          prey = work[j0 + W + tid];
+        // (1) diagonal block: wave 0, lane = row, the block in registers, other rows' entries by lane reads.  Straight-line
+        // code on purpose (no lane or block-size conditions): entries above the diagonal are computed and never used, a
+        // short last block is padded with the identity -- so the scheduler can fill the latency of one pivot's chain
+        // (lane read, 1 / sqrt, two Newton steps) with the updates the previous pivot left behind
+        if (tid < 64)
+          {
+            double              row[NB];
+            const int           lr = tid < NB ? tid : NB - 1;
+            const double *const rp = &S[((j0 + lr) & (W - 1)) * LD + jc];
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              row[c] = (lr < nb && c <= lr && c < nb) ? rp[c] : (lr == c ? 1.0 : 0.0);
+            double rdl = 1.0; // 1 / L_cc of this lane's own column
+            bool   bad = false;
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              {
+                const double d = lane_value(row[c], c);
+                bad            = bad || !(d > 0.0);
+                const double rd = rsqrt_nr(d);
+                rdl             = (tid == c) ? rd : rdl;
+                row[c] *= rd; // column c of L (the diagonal becomes sqrt(d))
+#pragma unroll
+                for (int c2 = c + 1; c2 < NB; ++c2)
+                  row[c2] = fma(-row[c], lane_value(row[c], c2), row[c2]); // - L[r][c] L[c2][c]
+              }
+            if (bad && tid == 0)
+              flag[0] = 1;
+            if (tid < NB)
+              {
+                double *const wp = &S[((j0 + tid) & (W - 1)) * LD + jc];
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                  {
+                    const double v = (tid < nb && c <= tid) ? row[c] : (tid == c ? 1.0 : 0.0);
+                    sL[tid][c]     = v;
+                    if (tid < nb && c <= tid)
+                      wp[c] = v;
+                  }
+                srd[tid] = rdl;
+              }
+          }
+        __syncthreads();
+        BAND_STAMP(0);
+        // (2) panel: the rows below the block that reach into its columns, one triangular solve per row; a slot outside
+        // the row's band holds zero and stays zero (L has the band of A)
+        const int r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        if (tid < m) // (m <= W - NB = 112: waves 0 and 1)
+          {
+            // right-looking in registers: a finished entry updates all later ones at once (independent multiply-adds; the
+            // dependent chain is one multiply per column, not a sum over the columns before it)
+            double *const rp = &S[((r0 + tid) & (W - 1)) * LD + jc];
+            double        xr[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              xr[c] = rp[c];
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              {
+                xr[c] *= srd[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < NB; ++c2)
+                  xr[c2] = fma(-xr[c], sL[c2][c], xr[c2]);
+              }
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              rp[c] = xr[c];
+          }
+        else if (do_solve && tid >= 128 && tid < 192)
+          {
+            // meanwhile wave 2: y of the block, column sweeps (lane = row of the block)
+            const int l = tid - 128;
+            double    w = l < nb ? yv[(j0 + l) & (W - 1)] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              {
+                const double yc = lane_value(w, c) * srd[c];
+                if (l == c)
+                  w = yc;
+                else if (l > c && l < NB)
+                  w -= sL[l][c] * yc;
+              }
+            if (l < NB)
+              {
+                sy[l] = l < nb ? w : 0.0;
+                if (l < nb)
+                  work[j0 + l] = w;
+              }
+          }
+        __syncthreads();
+        BAND_STAMP(1);
+        // (3) the finished columns leave the window: into registers now (their slots are reused at the end of the
+        // iteration), out to the band in memory as the iteration's LAST memory operation -- the memory counter retires in
+        // order, and the new rows' loads must not queue behind these stores
+        double wb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          {
+            const int idx = tid + u * 1024, cc = idx / ld, k = idx - cc * ld, r = j0 + cc + k;
+            wb[u]         = (cc < nb && r < n) ? S[(r & (W - 1)) * LD + jc + cc] : 0.0;
+          }
+        // (4) trailing update inside the window: A[s][t] -= sum_c L[s][c] L[t][c], t <= s, rows / columns of the panel
+        // in 2 x 2 register tiles (one LDS read per multiply-add instead of two: the update is LDS-bandwidth bound)
+        {
+          const int mt = (m + 1) >> 1, ntile = mt * (mt + 1) / 2; // tiles (si, ti), ti <= si: p = si (si + 1) / 2 + ti
+          for (int p = tid; p < ntile; p += 1024)
+            {
+              int si = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+              while ((si + 1) * (si + 2) / 2 <= p)
+                ++si;
+              while (si * (si + 1) / 2 > p)
+                --si;
+              const int ti = p - si * (si + 1) / 2;
+                {
+                  const int s0i = 2 * si, t0i = 2 * ti; // rows r0 + s0i, + 1 against columns r0 + t0i, + 1
+                  const bool s1 = s0i + 1 < m, t1 = t0i + 1 < m;
+                  const double *const ps0 = &S[((r0 + s0i) & (W - 1)) * LD + jc], *const ps1 = &S[((r0 + s0i + 1) & (W - 1)) * LD + jc];
+                  const double *const pt0 = &S[((r0 + t0i) & (W - 1)) * LD + jc], *const pt1 = &S[((r0 + t0i + 1) & (W - 1)) * LD + jc];
+                  double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+#pragma unroll 4
+                  for (int c = 0; c < NB; ++c)
+                    {
+                      const double x0 = ps0[c], x1 = s1 ? ps1[c] : 0.0, y0 = pt0[c], y1 = t1 ? pt1[c] : 0.0;
+                      a00 += x0 * y0;
+                      a01 += x0 * y1;
+                      a10 += x1 * y0;
+                      a11 += x1 * y1;
+                    }
+                  double *const o0 = &S[((r0 + s0i) & (W - 1)) * LD], *const o1 = &S[((r0 + s0i + 1) & (W - 1)) * LD];
+                  const int     c0 = (r0 + t0i) & (W - 1), c1 = (r0 + t0i + 1) & (W - 1);
+                  o0[c0] -= a00; // t0 <= s0
+                  if (t1 && t0i + 1 <= s0i)
+                    o0[c1] -= a01;
+                  if (s1)
+                    o1[c0] -= a10;
+                  if (s1 && t1)
+                    o1[c1] -= a11;
+                }
+            }
+        }
+        if (do_solve && tid >= 896 && tid - 896 < m) // ... and y of the panel's rows: y_r -= L[r][block] . y_block
+          {
+            const int           r  = r0 + tid - 896;
+            const double *const rp = &S[(r & (W - 1)) * LD + jc];
+            double              dy = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+              dy += rp[c] * sy[c];
+            yv[r & (W - 1)] -= dy;
+          }
+        __syncthreads();
+        BAND_STAMP(2);
+        // (5) the new rows take the slots of the block's rows (whole slot rows: band entries and zeros)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          {
+            const int idx = tid + u * 1024, rr = idx >> 7, cs = idx & (W - 1);
+            S[((j0 + W + rr) & (W - 1)) * LD + cs] = pre[u];
+          }
+        if (do_solve && tid < NB)
+          yv[(j0 + W + tid) & (W - 1)] = prey;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          {
+            const int idx = tid + u * 1024, cc = idx / ld, k = idx - cc * ld, r = j0 + cc + k;
+            if (cc < nb && r < n)
+              band[int64_t(j0 + cc) * ld + k] = wb[u];
+          }
+        // (no barrier here: the next diagonal block and the new rows are different slots, and the barrier behind the
+        // next block's factorisation comes before any panel thread reads them)
+        BAND_STAMP(3);
+      }
+    if (dbg && tid == 0)
+      for (int i = 0; i < 4; ++i)
+        dbg[i] = tacc[i];
+#undef BAND_STAMP
+    if (!do_solve || do_solve == 3) // (3: timing-only, MI_BAND_DBG)
+      return;
+    __syncthreads();
+    // ---- backward substitution L^T x = y (L from memory), as in band_cholesky_solve
+    auto A = [&](int r, int c) -> double & { return band[int64_t(c) * ld + (r - c)]; };
+    for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB)
+      {
+        const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        {
+          const int c = tid >> 6, l = tid & 63;
+          double    sacc = 0.0;
+          if (c < nb)
+            for (int t = l; t < m; t += 64)
+              if (r0 + t - (j0 + c) <= hbw)
+                sacc += A(r0 + t, j0 + c) * work[r0 + t];
+          sacc = wave_sum(sacc);
+          if (l == 0 && c < NB)
+            sy[c] = sacc;
+          if (tid < NB * NB)
+            {
+              const int r = tid / NB, cc = tid % NB;
+              sL[r][cc]   = (r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
+            }
+        }
+        __syncthreads();
+        if (tid < 64)
+          {
+            double       w  = tid < nb ? work[j0 + tid] - sy[tid] : 0.0;
+            const double ri = tid < nb ? 1.0 / sL[tid][tid] : 1.0; // all reciprocals at once, off the sweep's chain
+            for (int q = nb - 1; q >= 0; --q)
+              {
+                const double xq = lane_value(w, q) * lane_value(ri, q);
                 if (tid == q)
                   w = xq;
                 else if (tid < q)
@@ -4306,6 +4622,33 @@ namespace mi
   {
     if (hbw >= BAND_MAXH)
       return -1;
+    // factorisations of narrow bands (the reference's 2D geometries) run on the LDS-window kernel; MI_BAND_LDS=0: never (A/B)
+    static const bool lds_ok = !(getenv("MI_BAND_LDS") && atoi(getenv("MI_BAND_LDS")) == 0);
+    if (factor && lds_ok && hbw + BAND_NB <= BAND_LDS_W)
+      {
+        // MI_BAND_DBG (diagnostic): phase clocks of thread 0, printed after a synchronisation; no backward substitution
+        static const bool   dbg_on = getenv("MI_BAND_DBG") != nullptr;
+        static unsigned long long *d_dbg = nullptr;
+        if (dbg_on && !d_dbg)
+          hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long));
+        if (dim == 3)
+          hipLaunchKernelGGL((band_cholesky_lds<3>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
+                             (solve && dbg_on) ? 3 : int(solve), d_dbg);
+        else
+          hipLaunchKernelGGL((band_cholesky_lds<2>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
+                             (solve && dbg_on) ? 3 : int(solve), d_dbg);
+        if (dbg_on)
+          {
+            unsigned long long h[4];
+            hipStreamSynchronize(s);
+            hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
+            static int shown = 0;
+            if (shown++ < 2)
+              fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: diagonal block %llu, panel + y %llu, write-back regs + "
+                              "trailing %llu, new rows + stores %llu\n", n, hbw, h[0], h[1], h[2], h[3]);
+          }
+        return 0;
+      }
     if (dim == 3)
       hipLaunchKernelGGL((band_cholesky_solve<3>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
                          int(factor), int(solve));
