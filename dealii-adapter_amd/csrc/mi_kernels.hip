@@ -3790,11 +3790,62 @@ namespace mi
     if (do_solve && tid < W)
       yv[tid] = tid < n ? work[tid] : 0.0;
     __syncthreads();
+    // diagonal block at j0: wave 0, lane = row, the block in registers, other rows' entries by lane reads.  Straight-line
+    // code on purpose (no lane or block-size conditions): entries above the diagonal are computed and never used, a short
+    // last block is padded with the identity -- so the scheduler can fill the latency of one pivot's chain (lane read,
+    // 1 / sqrt, two Newton steps) with the updates the previous pivot left behind
+    auto diagonal_block = [&](int j0) {
+      const int           nb = min(NB, n - j0), jc = j0 & (W - 1);
+      double              row[NB];
+      const int           lr = tid < NB ? tid : NB - 1;
+      const double *const rp = &S[((j0 + lr) & (W - 1)) * LD + jc];
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        row[c] = (lr < nb && c <= lr && c < nb) ? rp[c] : (lr == c ? 1.0 : 0.0);
+      double rdl = 1.0; // 1 / L_cc of this lane's own column
+      bool   bad = false;
+#pragma unroll
+      for (int c = 0; c < NB; ++c)
+        {
+          const double d  = lane_value(row[c], c);
+          bad             = bad || !(d > 0.0);
+          const double rd = rsqrt_nr(d);
+          rdl             = (tid == c) ? rd : rdl;
+          row[c] *= rd; // column c of L (the diagonal becomes sqrt(d))
+#pragma unroll
+          for (int c2 = c + 1; c2 < NB; ++c2)
+            row[c2] = fma(-row[c], lane_value(row[c], c2), row[c2]); // - L[r][c] L[c2][c]
+        }
+      if (bad && tid == 0)
+        flag[0] = 1;
+      if (tid < NB)
+        {
+          double *const wp = &S[((j0 + tid) & (W - 1)) * LD + jc];
+#pragma unroll
+          for (int c = 0; c < NB; ++c)
+            {
+              const double v = (tid < nb && c <= tid) ? row[c] : (tid == c ? 1.0 : 0.0);
+              sL[tid][c]     = v;
+              if (tid < nb && c <= tid)
+                wp[c] = v;
+            }
+          srd[tid] = rdl;
+        }
+    };
+    // Look-ahead (a block column's dependent chain is diagonal block -> panel -> update of the NEXT block column -> next
+    // diagonal block; the rest of the trailing update and the row streaming run beside the next diagonal block):
+    //   P   panel rows solved against the diagonal block (waves 0-1), y of the block (wave 2)
+    //   T1  the finished columns into registers; y of the panel rows; trailing update of the next block's 16 columns
+    //   T2  wave 0: next diagonal block  |  waves 1-15: trailing update of the other columns
+    //       everybody: the new rows into the slots of the block's rows, the finished columns out to memory
+    if (tid < 64)
+      diagonal_block(0);
+    __syncthreads();
+    if (dbg && tid == 0)
+      tlast = __builtin_amdgcn_s_memtime();
     for (int j0 = 0; j0 < n; j0 += NB)
       {
         const int nb = min(NB, n - j0), jc = j0 & (W - 1); // the block's columns are the slots jc .. jc + NB - 1
-        if (dbg && tid == 0 && j0 == 0)
-          tlast = __builtin_amdgcn_s_memtime();
         // the rows that enter the window when this block column is done: requested now, stored at the end
         double pre[2], prey = 0.0;
 #pragma unroll
@@ -3806,52 +3857,8 @@ namespace mi
           }
         if (do_solve && tid < NB && j0 + W + tid < n)
           prey = work[j0 + W + tid];
-        // (1) diagonal block: wave 0, lane = row, the block in registers, other rows' entries by lane reads.  Straight-line
-        // code on purpose (no lane or block-size conditions): entries above the diagonal are computed and never used, a
-        // short last block is padded with the identity -- so the scheduler can fill the latency of one pivot's chain
-        // (lane read, 1 / sqrt, two Newton steps) with the updates the previous pivot left behind
-        if (tid < 64)
-          {
-            double              row[NB];
-            const int           lr = tid < NB ? tid : NB - 1;
-            const double *const rp = &S[((j0 + lr) & (W - 1)) * LD + jc];
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-              row[c] = (lr < nb && c <= lr && c < nb) ? rp[c] : (lr == c ? 1.0 : 0.0);
-            double rdl = 1.0; // 1 / L_cc of this lane's own column
-            bool   bad = false;
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-              {
-                const double d = lane_value(row[c], c);
-                bad            = bad || !(d > 0.0);
-                const double rd = rsqrt_nr(d);
-                rdl             = (tid == c) ? rd : rdl;
-                row[c] *= rd; // column c of L (the diagonal becomes sqrt(d))
-#pragma unroll
-                for (int c2 = c + 1; c2 < NB; ++c2)
-                  row[c2] = fma(-row[c], lane_value(row[c], c2), row[c2]); // - L[r][c] L[c2][c]
-              }
-            if (bad && tid == 0)
-              flag[0] = 1;
-            if (tid < NB)
-              {
-                double *const wp = &S[((j0 + tid) & (W - 1)) * LD + jc];
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                  {
-                    const double v = (tid < nb && c <= tid) ? row[c] : (tid == c ? 1.0 : 0.0);
-                    sL[tid][c]     = v;
-                    if (tid < nb && c <= tid)
-                      wp[c] = v;
-                  }
-                srd[tid] = rdl;
-              }
-          }
-        __syncthreads();
-        BAND_STAMP(0);
-        // (2) panel: the rows below the block that reach into its columns, one triangular solve per row; a slot outside
-        // the row's band holds zero and stays zero (L has the band of A)
+        // ---- P: the rows below the block that reach into its columns, one triangular solve per row; a slot outside the
+        // row's band holds zero and stays zero (L has the band of A)
         const int r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
         if (tid < m) // (m <= W - NB = 112: waves 0 and 1)
           {
@@ -3896,10 +3903,10 @@ namespace mi
               }
           }
         __syncthreads();
-        BAND_STAMP(1);
-        // (3) the finished columns leave the window: into registers now (their slots are reused at the end of the
-        // iteration), out to the band in memory as the iteration's LAST memory operation -- the memory counter retires in
-        // order, and the new rows' loads must not queue behind these stores
+        BAND_STAMP(0);
+        // ---- T1: the finished columns leave the window: into registers now (their slots are reused below), out to the band
+        // in memory as the iteration's LAST memory operation -- the memory counter retires in order, and the new rows'
+        // loads must not queue behind these stores
         double wb[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -3907,58 +3914,79 @@ namespace mi
             const int idx = tid + u * 1024, cc = idx / ld, k = idx - cc * ld, r = j0 + cc + k;
             wb[u]         = (cc < nb && r < n) ? S[(r & (W - 1)) * LD + jc + cc] : 0.0;
           }
-        // (4) trailing update inside the window: A[s][t] -= sum_c L[s][c] L[t][c], t <= s, rows / columns of the panel
-        // in 2 x 2 register tiles (one LDS read per multiply-add instead of two: the update is LDS-bandwidth bound)
-        {
-          const int mt = (m + 1) >> 1, ntile = mt * (mt + 1) / 2; // tiles (si, ti), ti <= si: p = si (si + 1) / 2 + ti
-          for (int p = tid; p < ntile; p += 1024)
-            {
-              int si = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
-              while ((si + 1) * (si + 2) / 2 <= p)
-                ++si;
-              while (si * (si + 1) / 2 > p)
-                --si;
-              const int ti = p - si * (si + 1) / 2;
-                {
-                  const int s0i = 2 * si, t0i = 2 * ti; // rows r0 + s0i, + 1 against columns r0 + t0i, + 1
-                  const bool s1 = s0i + 1 < m, t1 = t0i + 1 < m;
-                  const double *const ps0 = &S[((r0 + s0i) & (W - 1)) * LD + jc], *const ps1 = &S[((r0 + s0i + 1) & (W - 1)) * LD + jc];
-                  const double *const pt0 = &S[((r0 + t0i) & (W - 1)) * LD + jc], *const pt1 = &S[((r0 + t0i + 1) & (W - 1)) * LD + jc];
-                  double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-#pragma unroll 4
-                  for (int c = 0; c < NB; ++c)
-                    {
-                      const double x0 = ps0[c], x1 = s1 ? ps1[c] : 0.0, y0 = pt0[c], y1 = t1 ? pt1[c] : 0.0;
-                      a00 += x0 * y0;
-                      a01 += x0 * y1;
-                      a10 += x1 * y0;
-                      a11 += x1 * y1;
-                    }
-                  double *const o0 = &S[((r0 + s0i) & (W - 1)) * LD], *const o1 = &S[((r0 + s0i + 1) & (W - 1)) * LD];
-                  const int     c0 = (r0 + t0i) & (W - 1), c1 = (r0 + t0i + 1) & (W - 1);
-                  o0[c0] -= a00; // t0 <= s0
-                  if (t1 && t0i + 1 <= s0i)
-                    o0[c1] -= a01;
-                  if (s1)
-                    o1[c0] -= a10;
-                  if (s1 && t1)
-                    o1[c1] -= a11;
-                }
-            }
-        }
-        if (do_solve && tid >= 896 && tid - 896 < m) // ... and y of the panel's rows: y_r -= L[r][block] . y_block
+        // the next DIAGONAL block first (what the next factorisation waits for): A[s][t] -= sum_c L[s][c] L[t][c], t <= s < NB
+        if (tid >= 512 && tid < 512 + NB * NB)
           {
-            const int           r  = r0 + tid - 896;
-            const double *const rp = &S[(r & (W - 1)) * LD + jc];
-            double              dy = 0.0;
+            const int t = (tid - 512) >> 4, sidx = (tid - 512) & (NB - 1);
+            if (t <= sidx && sidx < m)
+              {
+                const double *const ps = &S[((r0 + sidx) & (W - 1)) * LD + jc], *const pt = &S[((r0 + t) & (W - 1)) * LD + jc];
+                double              acc = 0.0;
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
-              dy += rp[c] * sy[c];
-            yv[r & (W - 1)] -= dy;
+                for (int c = 0; c < NB; ++c)
+                  acc += ps[c] * pt[c];
+                S[((r0 + sidx) & (W - 1)) * LD + ((r0 + t) & (W - 1))] -= acc;
+              }
           }
         __syncthreads();
-        BAND_STAMP(2);
-        // (5) the new rows take the slots of the block's rows (whole slot rows: band entries and zeros)
+        BAND_STAMP(1);
+        // ---- T2: the next diagonal block (wave 0) beside the rest of the trailing update (2 x 2 register tiles: one LDS read
+        // per multiply-add instead of two -- the update is LDS-bandwidth bound)
+        if (tid < 64)
+          {
+            if (r0 < n)
+              diagonal_block(r0);
+          }
+        else
+          {
+            // tiles (si, ti) of panel rows 2 si, 2 si + 1 against panel columns 2 ti, 2 ti + 1, ti <= si, all but the
+            // NB / 2 (NB / 2 + 1) / 2 tiles of the next diagonal block (si < NB / 2), which are done
+            constexpr int skip = (NB / 2) * (NB / 2 + 1) / 2;
+            const int     mt = (m + 1) >> 1, ntile = mt * (mt + 1) / 2 - skip;
+            for (int p = tid - 64 + skip; p < ntile + skip; p += 960)
+              {
+                int si = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+                while ((si + 1) * (si + 2) / 2 <= p)
+                  ++si;
+                while (si * (si + 1) / 2 > p)
+                  --si;
+                const int  ti = p - si * (si + 1) / 2;
+                const int  s0i = 2 * si, t0i = 2 * ti;
+                const bool s1 = s0i + 1 < m, t1 = t0i + 1 < m;
+                const double *const ps0 = &S[((r0 + s0i) & (W - 1)) * LD + jc], *const ps1 = &S[((r0 + s0i + 1) & (W - 1)) * LD + jc];
+                const double *const pt0 = &S[((r0 + t0i) & (W - 1)) * LD + jc], *const pt1 = &S[((r0 + t0i + 1) & (W - 1)) * LD + jc];
+                double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+#pragma unroll 4
+                for (int c = 0; c < NB; ++c)
+                  {
+                    const double x0 = ps0[c], x1 = s1 ? ps1[c] : 0.0, y0 = pt0[c], y1 = t1 ? pt1[c] : 0.0;
+                    a00 += x0 * y0;
+                    a01 += x0 * y1;
+                    a10 += x1 * y0;
+                    a11 += x1 * y1;
+                  }
+                double *const o0 = &S[((r0 + s0i) & (W - 1)) * LD], *const o1 = &S[((r0 + s0i + 1) & (W - 1)) * LD];
+                const int     c0 = (r0 + t0i) & (W - 1), c1 = (r0 + t0i + 1) & (W - 1);
+                o0[c0] -= a00; // t0 <= s0
+                if (t1 && t0i + 1 <= s0i)
+                  o0[c1] -= a01;
+                if (s1)
+                  o1[c0] -= a10;
+                if (s1 && t1)
+                  o1[c1] -= a11;
+              }
+            if (do_solve && tid >= 896 && tid - 896 < m) // y of the panel's rows: y_r -= L[r][block] . y_block
+              {
+                const int           r  = r0 + tid - 896;
+                const double *const rp = &S[(r & (W - 1)) * LD + jc];
+                double              dy = 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                  dy += rp[c] * sy[c];
+                yv[r & (W - 1)] -= dy;
+              }
+          }
+        // the new rows take the slots of the block's rows (whole slot rows: band entries and zeros) ...
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
@@ -3967,6 +3995,7 @@ namespace mi
           }
         if (do_solve && tid < NB)
           yv[(j0 + W + tid) & (W - 1)] = prey;
+        // ... and the finished columns go out
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
@@ -3974,12 +4003,11 @@ namespace mi
             if (cc < nb && r < n)
               band[int64_t(j0 + cc) * ld + k] = wb[u];
           }
-        // (no barrier here: the next diagonal block and the new rows are different slots, and the barrier behind the
-        // next block's factorisation comes before any panel thread reads them)
-        BAND_STAMP(3);
+        __syncthreads();
+        BAND_STAMP(2);
       }
     if (dbg && tid == 0)
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 3; ++i)
         dbg[i] = tacc[i];
 #undef BAND_STAMP
     if (!do_solve || do_solve == 3) // (3: timing-only, MI_BAND_DBG)
@@ -4644,8 +4672,8 @@ namespace mi
             hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
             static int shown = 0;
             if (shown++ < 2)
-              fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: diagonal block %llu, panel + y %llu, write-back regs + "
-                              "trailing %llu, new rows + stores %llu\n", n, hbw, h[0], h[1], h[2], h[3]);
+              fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: panel + y %llu, next block's columns %llu, next "
+                              "diagonal block beside the trailing update %llu\n", n, hbw, h[0], h[1], h[2]);
           }
         return 0;
       }
