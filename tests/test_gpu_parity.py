@@ -671,6 +671,33 @@ def _scenario_pair(scenario, dim, p):
     return P, G
 
 
+@pytest.mark.parametrize("dim,p,reps", [(2, 3, (6, 5)), (2, 4, (5, 3)), (2, 2, (40, 9)), (2, 1, (60, 25)), (2, 3, (3, 1)), (2, 1, (2, 2)),
+                                        (3, 1, (9, 3, 2)), (3, 1, (5, 4, 4)), (2, 3, (4, 7)), (2, 1, (100, 54)), (2, 1, (30, 55))])
+def test_direct_solver_over_band_widths(dim, p, reps):
+    """round 4: factorisations of bands up to 112 dofs wide run with the active window of the matrix in LDS (band_cholesky_lds: a
+    circular window of 128 rows, look-ahead, streamed rows), wider ones on the general kernel.  Meshes on both sides of the
+    limit, windows that wrap many times (11 k dofs), last blocks and panels shorter than a block column, systems smaller than
+    the window: the direct solution against the PCG at 1e-13 [REF nonlinear_elasticity.cc:1192-1200]."""
+    import ctypes as C
+    L = M.lib()
+    L.mi_direct_solve.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    G = M.Context(dim=dim, degree=p, reps=reps, hi=tuple(0.1 * r for r in reps))
+    G.set_tuning("precond", 0)
+    rng = np.random.default_rng(3)
+    G.set(M.V_U, 0.01 * 0.1 / p * rng.standard_normal(G.n) * ~G.constrained)
+    G.set_interface_traction(tuple([0.0, -2e3, 0.0][:dim]))
+    G.update_acceleration()
+    G.assemble()
+    res = C.c_double(0)
+    assert L.mi_direct_solve(G.h, C.byref(res)) == 0, L.mi_last_error(G.h)
+    xd = G.get(M.V_NEWTON)
+    G.set(M.V_NEWTON, np.zeros(G.n))
+    rc, its, _ = G.cg_solve(1e-13, 50 * G.n)
+    assert rc == 0
+    assert _relmax(xd, G.get(M.V_NEWTON)) < 1e-9
+    G.close()
+
+
 @pytest.mark.parametrize("scenario,dim,p", DIRECT_CASES)
 def test_direct_solver_matches_the_oracle_direct_solve(scenario, dim, p):
     """the reference's shipped default (parameters.prm:43, nonlinear_elasticity.cc:1192-1200) on its own geometries: one
