@@ -3662,10 +3662,11 @@ namespace mi
         __syncthreads();
         if (tid < 64) // lane r = row r of the block: column sweeps, the finished y_c broadcast from lane c
           {
-            double w = tid < nb ? work[j0 + tid] : 0.0;
+            double       w  = tid < nb ? work[j0 + tid] : 0.0;
+            const double ri = tid < nb ? 1.0 / sL[tid][tid] : 1.0; // all reciprocals at once, off the sweep's chain
             for (int c = 0; c < nb; ++c)
               {
-                const double yc = __shfl(w, c, 64) / sL[c][c];
+                const double yc = lane_value(w, c) * lane_value(ri, c); // (scalar lane reads: round 4)
                 if (tid == c)
                   w = yc;
                 else if (tid > c && tid < nb)
@@ -3714,10 +3715,11 @@ namespace mi
         __syncthreads();
         if (tid < 64) // lane c = column c of the block, swept from the last row upwards
           {
-            double w = tid < nb ? work[j0 + tid] - sy[tid] : 0.0;
+            double       w  = tid < nb ? work[j0 + tid] - sy[tid] : 0.0;
+            const double ri = tid < nb ? 1.0 / sL[tid][tid] : 1.0;
             for (int q = nb - 1; q >= 0; --q)
               {
-                const double xq = __shfl(w, q, 64) / sL[q][q];
+                const double xq = lane_value(w, q) * lane_value(ri, q);
                 if (tid == q)
                   w = xq;
                 else if (tid < q)
