@@ -302,11 +302,19 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))  # nothing has touched the GPU in this process
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The CPU leg runs FIRST, in child processes started while this process has not touched the GPU (no torch import, no
+    # HIP context): a fork + exec out of a process that holds a HIP context is the fragile order.  It needs no GPU.
+    cpu_leg = None
+    if rank == 0 and world == 1 and args.cpu_cells > 0:
+        its_a, its_b = (int(x) for x in args.cpu_its.split(","))
+        budget = float(os.environ.get("MI_BENCH_CPU_BUDGET_S", "900"))
+        cpu_leg = cpu_baseline(args.cpu_cells, its_a, its_b, budget, not args.no_cpu_config4 and args.cells == 59)
+
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
@@ -643,7 +651,6 @@ def main():
             del S
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         # the GPU on the CPU sample's own configuration, beside it
-        its_a, its_b = (int(x) for x in args.cpu_its.split(","))
         if args.cpu_cells != n or args.slabs != 1:
             S = measure("strong", args.cpu_cells, 3, 1, None)
             gpu_same = {"value": S["G"].n * 3 / S["elapsed"], "ms_per_step": 1e3 * S["elapsed"] / 3, "n_dofs": S["G"].n,
@@ -651,8 +658,7 @@ def main():
             del S
         else:
             gpu_same = {"value": out["value"], "ms_per_step": out["ms_per_step"], "n_dofs": out["config"]["n_dofs"]}
-        budget = float(os.environ.get("MI_BENCH_CPU_BUDGET_S", "900"))
-        out["cpu_baseline"] = cpu_baseline(args.cpu_cells, its_a, its_b, budget, not args.no_cpu_config4 and n == 59)
+        out["cpu_baseline"] = cpu_leg  # measured before the first GPU call of this process (top of main)
         out["cpu_baseline"]["gpu_same_config"] = gpu_same
         c4 = out["cpu_baseline"].get("config4_one_newton_iteration")
         if c4 and c4.get("live") and "t_assembly_s" in c4:

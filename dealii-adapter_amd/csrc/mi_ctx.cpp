@@ -52,6 +52,8 @@ namespace mi_detail
     return c->team ? c->team->size : 1;
   }
 
+  void set_create_error(const char *msg) { g_create_error = msg; } // for the context-free entry points (mi_partition.cpp)
+
   int fail(mi_ctx *c, int code, const char *fmt, ...)
   {
     char    buf[512];
@@ -423,13 +425,16 @@ namespace mi_detail
         // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
         // profiler reports them), class MI_T_EBE_LAUNCH
         mi_ctx    *c0     = c->team->members[0];
-        const bool sample = c0->profiling && (c->ebe_products++ % 6 == 0);
+        // (a product that runs in two parts around a halo exchange counts once -- with its second part -- and the
+        // launch that holds the bulk of the cells, part 1, is the one that is timed)
+        const bool counts = !(mf_split && part == 1);
+        const bool sample = c0->profiling && (counts ? c->ebe_products++ % 6 == 0 : c->ebe_products % 6 == 0);
         if (one_launch) // all cells at once (no two cells share a slot), then the sum over the slots of every node
           {
             if (mf_split)
               {
                 // layers [za, zb) of the slab's cells: one contiguous range of positions per colour (z slowest)
-                auto layers = [&](int za, int zb) {
+                auto layers = [&](int za, int zb, bool timed) {
                   mi::MfParams g = f;
                   int32_t      n = 0;
                   for (int col = 0; col < 8; ++col)
@@ -448,17 +453,21 @@ namespace mi_detail
                   g.sel_begin[8] = n;
                   g.sel_n        = n;
                   if (n > 0)
-                    mi::launch_mf_spmv(g, 0, n, c->stream);
+                    {
+                      const int t = timed ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
+                      mi::launch_mf_spmv(g, 0, n, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                         t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+                    }
                 };
                 const int nzl = c->mesh.reps[2];
                 const int zlo = c->slab.rank > 0 ? 1 : 0, zhi = c->slab.rank + 1 < c->team->size ? nzl - 1 : nzl;
                 if (part == 1)
                   {
-                    layers(zlo, zhi); // no ghost plane of x in reach: while the halo is in flight
+                    layers(zlo, zhi, sample); // no ghost plane of x in reach: while the halo is in flight
                     return;           // (the slot sum follows the other layers)
                   }
-                layers(0, zlo);
-                layers(zhi, nzl);
+                layers(0, zlo, false);
+                layers(zhi, nzl, false);
               }
             else
               {
@@ -706,7 +715,7 @@ namespace mi_detail
         return MI_OK;
       }
     c->ke_valid = (c->d_ke || c->d_qrec) &&
-                  !(c->dim == 3 && c->degree == 2 && c->asm_variant >= 6 && c->asm_variant <= 8); // timing-only ablations
+                  !(c->dim == 3 && c->degree == 2 && c->asm_variant >= 100); // timing-only ablations
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -2399,7 +2408,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->small_cg = value;
       else if (k == "halo_overlap" && (value == 0 || value == 1))
         c->team->overlap = value;
-      else if (k == "asm_variant" && value >= 0 && value <= 9)
+      else if (k == "asm_variant" && ((value >= 0 && value <= 9) || (value >= 100 && value < 228)))
         m->asm_variant = value;
       else if (k == "mg_refresh_every" && value >= 1 && value <= 1000)
         m->mg_refresh_every = value;
@@ -2610,117 +2619,46 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_assembly = double(ms) / std::max(1, reps);
-  if (getenv("MI_ASM_STAMPS") && c->dim == 3 && c->degree == 2 && c->asm_variant == 0)
+  if (getenv("MI_ASM_STAMPS") && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 7) || c->asm_variant >= 100))
     {
       // diagnostic: where a workgroup of the sum-factorised element kernel spends its life (shader-clock stamps of one
       // tangent wave at the phase boundaries), averaged over the cells of the first colour
       const int64_t       ncell = c->mesh.colour_begin[1] - c->mesh.colour_begin[0];
       unsigned long long *d_st  = nullptr;
-      HIPCHK(c, hipMalloc((void **)&d_st, size_t(ncell) * 8 * sizeof(unsigned long long)));
-      HIPCHK(c, hipMemsetAsync(d_st, 0, size_t(ncell) * 8 * sizeof(unsigned long long), c->stream));
+      HIPCHK(c, hipMalloc((void **)&d_st, size_t(ncell) * 16 * sizeof(unsigned long long)));
+      HIPCHK(c, hipMemsetAsync(d_st, 0, size_t(ncell) * 16 * sizeof(unsigned long long), c->stream));
       mi::AsmParams p = asm_params(c);
       p.cell_begin    = c->mesh.colour_begin[0];
       p.cell_count    = int32_t(ncell);
       p.stamps        = d_st;
       mi::launch_assemble_cells(c->dim, c->degree, p, c->stream);
-      std::vector<unsigned long long> st(size_t(ncell) * 8);
+      std::vector<unsigned long long> st(size_t(ncell) * 16);
       HIPCHK(c, hipStreamSynchronize(c->stream));
       HIPCHK(c, hipMemcpy(st.data(), d_st, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
       hipFree(d_st);
-      double             sum[7] = {0, 0, 0, 0, 0, 0, 0};
-      unsigned long long tmin = ~0ull, tmax = 0;
+      double sum[7] = {0, 0, 0, 0, 0, 0, 0}, pro[5] = {0, 0, 0, 0, 0};
       for (int64_t e = 0; e < ncell; ++e)
         {
+          const unsigned long long *t = &st[size_t(e) * 16];
           for (int i = 0; i < 6; ++i)
-            sum[i] += double(st[size_t(e) * 8 + i + 1] - st[size_t(e) * 8 + i]);
-          tmin = std::min(tmin, st[size_t(e) * 8]);
-          tmax = std::max(tmax, st[size_t(e) * 8 + 6]);
+            sum[i] += double(t[i + 1] - t[i]);
+          for (int i = 0; i < 5; ++i) // stamps of the working waves inside the prologue, relative to the workgroup's start
+            pro[i] += t[8 + i] ? double(t[8 + i] - t[0]) : 0.0;
         }
       const char *name[6] = {"prologue (wave 0; tangent waves wait)", "contractions", "wait at barrier (2)", "image",
                              "block table", "scatter"};
       double      tot     = 0;
       for (int i = 0; i < 6; ++i)
         tot += sum[i];
-      fprintf(stderr, "assemble_q2sf phases, first colour (%lld cells; launch spans %.0f ticks):\n", (long long)ncell,
-              double(tmax - tmin));
+      fprintf(stderr, "assemble_q2sf phases, first colour (%lld cells):\n", (long long)ncell);
       for (int i = 0; i < 6; ++i)
         fprintf(stderr, "  %-40s %8.0f ticks  %5.1f %%\n", name[i], sum[i] / double(ncell), 100.0 * sum[i] / tot);
+      fprintf(stderr, "  inside the prologue, ticks since the start: gradients %0.f, material %.0f, fields %.0f (wave 0); "
+                      "row info %.0f, block table %.0f (wave 3)\n",
+              pro[0] / double(ncell), pro[1] / double(ncell), pro[2] / double(ncell), pro[3] / double(ncell),
+              pro[4] / double(ncell));
     }
   return sync(c);
-}
-
-// host-only description of slab `rank` of `size` (no device needed): z-range, owned node range, halo ranges
-int mi_partition_describe(const mi_mesh_desc *md, int rank, int size, mi_partition_info *out)
-{
-  if (!md || !out)
-    return fail(nullptr, MI_EINVAL, "null argument");
-  try
-    {
-      const mi::SlabPartition s =
-        mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, size);
-      out->z0            = s.z0;
-      out->z1            = s.z1;
-      out->local_layers  = s.local_layers;
-      out->plane_nodes   = s.plane_nodes;
-      out->node_offset   = s.node_offset;
-      out->nnodes_global = s.nnodes_global;
-      out->nnodes_local  = s.nnodes_local;
-      out->own_begin     = s.own_begin;
-      out->own_end       = s.own_end;
-      out->up_send       = s.up_send;
-      out->up_send_n     = s.up_send_n;
-      out->up_recv       = s.up_recv;
-      out->up_recv_n     = s.up_recv_n;
-      out->down_send     = s.down_send;
-      out->down_send_n   = s.down_send_n;
-      out->down_recv     = s.down_recv;
-      out->down_recv_n   = s.down_recv_n;
-      for (int d = 0; d < 3; ++d)
-        {
-          out->local_reps[d] = s.local_reps[d];
-          out->local_lo[d]   = s.local_lo[d];
-          out->local_hi[d]   = s.local_hi[d];
-        }
-      for (int f = 0; f < 6; ++f)
-        out->local_face_role[f] = s.local_face_role[f];
-    }
-  catch (const std::exception &e)
-    {
-      return fail(nullptr, MI_EINVAL, "%s", e.what());
-    }
-  return MI_OK;
-}
-
-int mi_partition_spmv_rows(const mi_mesh_desc *md, int rank, int size, int64_t *n_slices, int64_t *n_interior_slices,
-                           int32_t *rows, int64_t capacity)
-{
-  if (!md || !n_slices || !n_interior_slices)
-    return fail(nullptr, MI_EINVAL, "null argument");
-  try
-    {
-      const mi::SlabPartition s =
-        mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, size);
-      mi::HostMesh m;
-      if (size == 1)
-        m.build(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, nullptr);
-      else
-        m.build(md->dim, md->degree, s.local_reps, md->lo, md->hi, s.local_face_role, nullptr, s.z0,
-                md->reps[md->dim - 1], s.own_begin, s.own_end);
-      *n_slices          = m.sell_nslices;
-      *n_interior_slices = m.sell_nslices_interior;
-      if (rows)
-        {
-          if (capacity < int64_t(m.sell_perm.size()))
-            return fail(nullptr, MI_EINVAL, "rows[] holds %lld entries, %lld needed", (long long)capacity,
-                        (long long)m.sell_perm.size());
-          std::copy(m.sell_perm.begin(), m.sell_perm.end(), rows);
-        }
-    }
-  catch (const std::exception &e)
-    {
-      return fail(nullptr, MI_EINVAL, "%s", e.what());
-    }
-  return MI_OK;
 }
 
 } // extern "C"

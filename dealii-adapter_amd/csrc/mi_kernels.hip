@@ -725,24 +725,55 @@ namespace mi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                        \
       }                                                                                                               \
     while (0)
-  // XV (A/B experiments of round 4, "asm_variant" 3-5): bit 0 = the role of "wave 0" rotates over the four waves of the
-  // workgroup with the cell index (where wave w of a workgroup always runs on SIMD w, the serial prologues of the
-  // three workgroups of a CU otherwise share one SIMD); bit 1 = later touches of a block are added by no-return
-  // atomics in the L2 instead of load / add / store (colour launches keep the order of the additions: same bits)
+  // XV (round 5, "asm_variant" 3-7 for A/B; the default instantiation carries the adopted bits): bit 0 = the contraction
+  // waves run a software pipeline over their 160 (qz, kl, qy) steps -- the LDS reads of step s + 4 are issued as soon
+  // as step s has consumed its ring slot -- and the (kl) loop is ordered by accumulator group (k == z, l == z), each
+  // group contracted along z as soon as it is complete (3 live accumulators instead of 12: the registers the ring
+  // needs); same additions in the same order, i.e. the same bits.  bit 1 = wave 0 runs its prologue, which the other
+  // three waves of the workgroup wait for, at raised priority.  bit 2 = 45 coefficient fields instead of 81 by the
+  // major symmetry C^{ij}_{kl} = C^{ji}_{lk} (the tangent changes at rounding level).  Timing-only ablations (wrong
+  // results, "asm_variant" 100 + XV): bit 3 = the scatter without its loads and stores, bit 4 = without its loads,
+  // bit 5 = no contractions.
+  // assemble_q2sf, pipelined contraction: (kl) in the order of the accumulator groups (k == z, l == z) = (0,0): 0 1 3 4 and the
+  // mass field 9, (0,1): 2 5, (1,0): 6 7, (1,1): 8 -- within a group ascending, the groups in the order the unpipelined
+  // loop adds them into the tangent entries
+  __device__ __forceinline__ constexpr int q2sf_kl_order(const int pos)
+  {
+    return pos == 0 ? 0 : pos == 1 ? 1 : pos == 2 ? 3 : pos == 3 ? 4 : pos == 4 ? 9 : pos == 5 ? 2 : pos == 6 ? 5 : pos == 7 ? 6 : pos == 8 ? 7 : 8;
+  }
+
+  // 45-field storage (major symmetry): pairs (i <= j) in the order 00 01 02 11 12 22; a diagonal pair holds the 6 fields
+  // k <= l, an off-diagonal one all 9
+  __device__ __forceinline__ constexpr int q2sf_sym6(const int k, const int l) // k <= l
+  {
+    return k == 0 ? l : k == 1 ? 2 + l : 5;
+  }
+  __device__ __forceinline__ constexpr int q2sf_pair_base(const int i, const int j) // i <= j
+  {
+    return i == 0 ? (j == 0 ? 0 : j == 1 ? 6 : 15) : i == 1 ? (j == 1 ? 24 : 30) : 39;
+  }
+  __device__ __forceinline__ constexpr int q2sf_field(const int i, const int j, const int k, const int l) // i <= j; i == j: k <= l
+  {
+    return q2sf_pair_base(i, j) + (i == j ? q2sf_sym6(k, l) : k * 3 + l);
+  }
+
   template <bool RES_ONLY, int XV = 0>
   __global__ __launch_bounds__(RES_ONLY ? 64 : 256, RES_ONLY ? 4 : 3) void assemble_q2sf(AsmParams prm)
   {
-    constexpr int NPC = 27, FS = 66, NF = 82; // field stride (padded: fields of different ij on different banks), fields
+    constexpr bool V2 = !RES_ONLY && (XV & 4) != 0;
+    constexpr int NPC = 27, FS = 66, NF = V2 ? 46 : 82; // field stride (padded: fields of different ij on different banks), fields
     constexpr int PS = 20, PW = 9 * PS, AO = 552;
-    __shared__ __attribute__((aligned(16))) double s_C[RES_ONLY ? 2 : NF * FS]; // later the element tangent [9][378]
+    constexpr int MASSF = NF - 1;                       // the mass field
+    __shared__ __attribute__((aligned(16))) double s_C[RES_ONLY ? 2 : (NF * FS > 9 * EBE_NBLK ? NF * FS : 9 * EBE_NBLK)]; // later the element tangent [9][378]
     __shared__ __attribute__((aligned(16))) double s_w[768 + 216];              // wave 0's scratch (as in mf_spmv)
+    __shared__ uint64_t s_tab[V2 ? NPC * NPC : 1];                              // V2: the block table (wave 3 builds it during the prologue)
     __shared__ int  s_conn[NPC];
     __shared__ int2 s_ri[RES_ONLY ? 1 : NPC]; // rowinfo of the cell's nodes (where their rows are in the global matrix)
     __shared__ int  s_cm[RES_ONLY ? 1 : NPC]; // their constraint bits
     __shared__ int  s_plain;                  // 1: no node of the cell is constrained and every node has a row here (the
                                               // scatter then skips the per-entry masking: all but the boundary cells)
     typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
-    const int     tid  = (XV & 1) ? int((((threadIdx.x >> 6) + blockIdx.x) & 3) << 6 | (threadIdx.x & 63)) : int(threadIdx.x);
+    const int     tid  = int(threadIdx.x);
     const int64_t cell = prm.cell_begin + blockIdx.x;
     // 1D tables (uniform)
     double S[4][3], D[4][3];
@@ -760,7 +791,15 @@ namespace mi
   do                                                                                                   \
     {                                                                                                  \
       if (prm.stamps && tid == (RES_ONLY ? 0 : 64))                                                    \
-        prm.stamps[int64_t(blockIdx.x) * 8 + (i_)] = __builtin_amdgcn_s_memtime();                    \
+        prm.stamps[int64_t(blockIdx.x) * 16 + (i_)] = __builtin_amdgcn_s_memtime();                   \
+    }                                                                                                  \
+  while (0)
+    // stamps 8-15: inside the prologue, by the wave that does the work (tid_ = 0: wave 0, 192: wave 3)
+#define MI_STAMPW(i_, tid_)                                                                            \
+  do                                                                                                   \
+    {                                                                                                  \
+      if (!RES_ONLY && prm.stamps && tid == (tid_))                                                    \
+        prm.stamps[int64_t(blockIdx.x) * 16 + (i_)] = __builtin_amdgcn_s_memtime();                   \
     }                                                                                                  \
   while (0)
     MI_STAMP(0);
@@ -770,6 +809,7 @@ namespace mi
     const lds_cvp v0 = (lds_cvp)s0, vE = (lds_cvp)sE;
     const int     q16 = lane & 15, pck = lane >> 2, pqx = lane & 3;
     double        M[9], tau[6], w = 0.0, accq[3] = {0.0, 0.0, 0.0};
+    double        Sz[3] = {0.0, 0.0, 0.0}, Dz[3] = {0.0, 0.0, 0.0}, accn[3] = {0.0, 0.0, 0.0}, gxi[3][3];
     // state of waves 1-3 (lane = (ij, a1 >= b1, a2)) across barrier (1); unused in wave 0
     const int  it     = tid - 64;
     const bool active = tid >= 64 && it < 162;
@@ -778,11 +818,124 @@ namespace mi
     const int  ci = ij / 3, cj = ij - 3 * ci;
     double     P1[4][4], phi2[2][4], mflag = 0.0;
 
+    // wave 0: interpolation of the 81 nodal values at s0[c * 27 + a] to the points by sum factorisation
+    auto interp = [&](const int pass) __attribute__((always_inline)) {
+        MI_WAVE_SYNC();
+        if (lane < 27) // contract i
+          {
+            const double x0 = v0[lane * 3], x1 = v0[lane * 3 + 1], x2 = v0[lane * 3 + 2];
+#pragma unroll
+            for (int qx = 0; qx < 4; ++qx)
+              {
+                s0[AO + qx * 27 + lane] = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
+                if (pass == 0)
+                  s0[AO + 108 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
+              }
+          }
+        MI_WAVE_SYNC();
+        if (lane < 36) // contract j
+          {
+            const int    ia  = AO + pqx * 27 + pck * 3;
+            const double as0 = v0[ia], as1 = v0[ia + 1], as2 = v0[ia + 2];
+            double       ad0 = 0.0, ad1 = 0.0, ad2 = 0.0;
+            if (pass == 0)
+              {
+                ad0 = v0[108 + ia];
+                ad1 = v0[108 + ia + 1];
+                ad2 = v0[108 + ia + 2];
+              }
+#pragma unroll
+            for (int qy = 0; qy < 4; ++qy)
+              {
+                const int o = pck * PS + qy * 4 + pqx;
+                if (pass == 0)
+                  {
+                    s0[o]      = S[qy][0] * ad0 + S[qy][1] * ad1 + S[qy][2] * ad2;
+                    s0[o + PW] = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2;
+                  }
+                s0[o + 2 * PW] = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2;
+              }
+          }
+        MI_WAVE_SYNC();
+#pragma unroll
+        for (int c = 0; c < 3; ++c) // contract k
+          {
+            double h0 = 0.0, h1 = 0.0, h2 = 0.0, vv = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              {
+                const int    o   = (c * 3 + k) * PS + q16;
+                const double bss = v0[o + 2 * PW];
+                if (pass == 0)
+                  {
+                    h0 = fma(Sz[k], v0[o], h0);
+                    h1 = fma(Sz[k], v0[o + PW], h1);
+                    h2 = fma(Dz[k], bss, h2);
+                  }
+                else
+                  vv = fma(Sz[k], bss, vv);
+              }
+            if (pass == 0)
+              {
+                gxi[c][0] = h0;
+                gxi[c][1] = h1;
+                gxi[c][2] = h2;
+              }
+            else
+              accq[c] = vv;
+          }
+    };
+    auto stage_acc = [&]() __attribute__((always_inline)) {
+      MI_WAVE_SYNC();
+      if (lane < NPC)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          s0[c * NPC + lane] = accn[c];
+    };
+
+    // ---- while the tangent waves contract: where the 729 node-pair blocks of this cell go.  One 64-bit word per
+    // block (a, b) in wave 0's own scratch, which the residual no longer needs: bits 0-31 position of the block in
+    // the global matrix (base + g * gstride + kx, mi_mesh.hpp; 0xffffffff: the node has no row here), 32-40 its place
+    // in the lower-triangle image of the element tangent, 41 a >= b (else: the transposed block of (b, a)),
+    // 42 first touch in processing order (plain store), 43 a == b, 44-46 / 47-49 constraint bits of A / B.
+    auto build_table = [&](uint64_t *const tab) __attribute__((always_inline)) {
+    {
+      const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
+      {
+        const bool special = lane < NPC && (s_cm[lane] != 0 || s_ri[lane].x < 0);
+        const bool any     = __builtin_amdgcn_ballot_w64(special) != 0;
+        if (lane == 0)
+          s_plain = any ? 0 : 1;
+      }
+      uint16_t        o[12];
+#pragma unroll
+      for (int r = 0; r < 12; ++r) // all twelve (coalesced) loads in flight at once
+        o[r] = (r * 64 + lane < NPC * NPC) ? offc[r * 64 + lane] : uint16_t(0);
+#pragma unroll
+      for (int r = 0; r < 12; ++r)
+        {
+          const int blk = r * 64 + lane;
+          if (blk < NPC * NPC)
+            {
+              const int      a = blk / NPC, b = blk - NPC * a;
+              const int2     ri = s_ri[a];
+              const uint32_t pos = ri.x >= 0 ? uint32_t(ri.x + int32_t((o[r] >> 4) & 0x7ff) * ri.y + int32_t(o[r] & 15)) : 0xffffffffu;
+              const bool     low = a >= b;
+              const int      hi = low ? a : b, lo = low ? b : a;
+              tab[blk] = uint64_t(pos) | (uint64_t(hi * (hi + 1) / 2 + lo) << 32) | (uint64_t(low) << 41) |
+                         (uint64_t(o[r] >> 15) << 42) | (uint64_t(a == b) << 43) | (uint64_t(s_cm[a]) << 44) |
+                         (uint64_t(s_cm[b]) << 47);
+            }
+        }
+    }
+    };
+
     if (tid < 64)
       {
         // ================================================================= wave 0: quadrature points
+        if constexpr (!RES_ONLY && (XV & 2) != 0)
+          __builtin_amdgcn_s_setprio(3);
         const int     qz = lane >> 4;
-        double        Sz[3], Dz[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           {
@@ -792,7 +945,6 @@ namespace mi
         const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
         double       xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
         int32_t      node = 0;
-        double       accn[3] = {0.0, 0.0, 0.0};
         // the cell's nodes: by arithmetic on a lattice (mi::CellLattice; the gathers below are then the wave's first
         // memory accesses) or from the connectivity
         const int32_t node0 = prm.lat.ncol > 0 ? lattice_node0(prm.lat, cell) : 0;
@@ -806,11 +958,12 @@ namespace mi
             else
               node = prm.conn[cell * NPC + lane];
             s_conn[lane] = node;
-            if constexpr (!RES_ONLY)
+            if constexpr (!RES_ONLY && !V2)
               {
                 s_ri[lane] = prm.rowinfo[node];
                 s_cm[lane] = prm.cmask[node] & 7;
               }
+            if constexpr (!(XV & 64))
 #pragma unroll
             for (int c = 0; c < 3; ++c)
               {
@@ -819,84 +972,26 @@ namespace mi
                 accn[c]            = prm.acc[g];
               }
           }
-        // ---- two interpolations to the points: pass 0 = u (gradients), pass 1 = acceleration (values)
-        double gxi[3][3];
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass)
+        // ---- two interpolations to the points: pass 0 = u (gradients), pass 1 = acceleration (values; V2: after barrier
+        // (1), beside the contractions -- only the residual needs it)
+        if constexpr ((XV & 64) != 0) // timing-only ablation: no gather, no interpolation, no residual
           {
-            MI_WAVE_SYNC();
-            if (lane < 27) // contract i
-              {
-                const double x0 = v0[lane * 3], x1 = v0[lane * 3 + 1], x2 = v0[lane * 3 + 2];
 #pragma unroll
-                for (int qx = 0; qx < 4; ++qx)
-                  {
-                    s0[AO + qx * 27 + lane] = S[qx][0] * x0 + S[qx][1] * x1 + S[qx][2] * x2;
-                    if (pass == 0)
-                      s0[AO + 108 + qx * 27 + lane] = D[qx][0] * x0 + D[qx][1] * x1 + D[qx][2] * x2;
-                  }
-              }
-            MI_WAVE_SYNC();
-            if (lane < 36) // contract j
-              {
-                const int    ia  = AO + pqx * 27 + pck * 3;
-                const double as0 = v0[ia], as1 = v0[ia + 1], as2 = v0[ia + 2];
-                double       ad0 = 0.0, ad1 = 0.0, ad2 = 0.0;
-                if (pass == 0)
-                  {
-                    ad0 = v0[108 + ia];
-                    ad1 = v0[108 + ia + 1];
-                    ad2 = v0[108 + ia + 2];
-                  }
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int qy = 0; qy < 4; ++qy)
-                  {
-                    const int o = pck * PS + qy * 4 + pqx;
-                    if (pass == 0)
-                      {
-                        s0[o]      = S[qy][0] * ad0 + S[qy][1] * ad1 + S[qy][2] * ad2;
-                        s0[o + PW] = D[qy][0] * as0 + D[qy][1] * as1 + D[qy][2] * as2;
-                      }
-                    s0[o + 2 * PW] = S[qy][0] * as0 + S[qy][1] * as1 + S[qy][2] * as2;
-                  }
-              }
-            MI_WAVE_SYNC();
-#pragma unroll
-            for (int c = 0; c < 3; ++c) // contract k
-              {
-                double h0 = 0.0, h1 = 0.0, h2 = 0.0, vv = 0.0;
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                  {
-                    const int    o   = (c * 3 + k) * PS + q16;
-                    const double bss = v0[o + 2 * PW];
-                    if (pass == 0)
-                      {
-                        h0 = fma(Sz[k], v0[o], h0);
-                        h1 = fma(Sz[k], v0[o + PW], h1);
-                        h2 = fma(Dz[k], bss, h2);
-                      }
-                    else
-                      vv = fma(Sz[k], bss, vv);
-                  }
-                if (pass == 0)
-                  {
-                    gxi[c][0] = h0;
-                    gxi[c][1] = h1;
-                    gxi[c][2] = h2;
-                  }
-                else
-                  accq[c] = vv;
-              }
-            if (pass == 0)
-              {
-                MI_WAVE_SYNC();
-                if (lane < NPC)
-#pragma unroll
-                  for (int c = 0; c < 3; ++c)
-                    s0[c * NPC + lane] = accn[c];
-              }
+              for (int k = 0; k < 3; ++k)
+                gxi[c][k] = 1e-7 * double((lane + 3 * c + k) & 7) * prm.rho;
           }
+        else
+          {
+        interp(0);
+        if constexpr (!V2)
+          {
+            stage_acc();
+            interp(1);
+          }
+          }
+        MI_STAMPW(8, 0); // gradients at the points
         // ---- geometry, kinematics, material at this point (nonlinear_elasticity.cc:927-934)
         double tiso[6], cII, cS;
         {
@@ -933,6 +1028,7 @@ namespace mi
                 g[10 * 64] = rJq;
               }
         }
+        MI_STAMPW(9, 0); // material
         const double T[3][3]  = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
         // ---- coefficient fields for the tangent waves
         if constexpr (!RES_ONLY)
@@ -972,13 +1068,17 @@ namespace mi
 #pragma unroll
                   for (int l = 0; l < 3; ++l)
                     {
+                      // V2: C^{ij}_{kl} = C^{ji}_{lk}, so only i <= j is stored, and for i == j only k <= l (45 fields)
+                      if (V2 && (i > j || (i == j && k > l)))
+                        continue;
                       double c = A[k][i] * M[l * 3 + j] + B[k][i] * Tm[l][j] + E[k][j] * M[l * 3 + i];
                       if (i == j)
                         c += Sk[k][l];
-                      s_C[((i * 3 + j) * 9 + k * 3 + l) * FS + lane] = c;
+                      s_C[(V2 ? q2sf_field(i, j, k, l) : (i * 3 + j) * 9 + k * 3 + l) * FS + lane] = c;
                     }
-            s_C[81 * FS + lane] = prm.alpha1 * prm.rho * w;
+            s_C[MASSF * FS + lane] = prm.alpha1 * prm.rho * w;
           }
+        MI_STAMPW(10, 0); // fields stored
       }
     else if constexpr (!RES_ONLY)
       {
@@ -997,13 +1097,42 @@ namespace mi
             phi2[1][q]      = prm.tab1d[12 + q * 3 + a2];
           }
         mflag = (ci == cj) ? 1.0 : 0.0;
+        if constexpr (V2)
+          if (tid >= 192) // wave 3, idle until barrier (1) otherwise: where the 729 node-pair blocks of this cell go
+            {
+              int32_t node;
+              if (prm.lat.ncol > 0)
+                {
+                  const int32_t node0 = lattice_node0(prm.lat, cell);
+                  const int     k9 = lane / 9, r9 = lane - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
+                  node               = node0 + i3 + j3 * prm.lat.nn0 + k9 * prm.lat.nn01;
+                }
+              else
+                node = lane < NPC ? prm.conn[cell * NPC + lane] : 0;
+              if (lane < NPC)
+                {
+                  s_ri[lane] = prm.rowinfo[node];
+                  s_cm[lane] = prm.cmask[node] & 7;
+                }
+              MI_WAVE_SYNC();
+              MI_STAMPW(11, 192); // wave 3: rowinfo there
+              build_table(s_tab);
+              MI_STAMPW(12, 192); // wave 3: table built
+            }
       }
+    if constexpr (!RES_ONLY && (XV & 2) != 0)
+      __builtin_amdgcn_s_setprio(0);
     if constexpr (!RES_ONLY)
       __syncthreads(); // (1) fields complete -- the one barrier every wave of the workgroup passes, outside the role branches
     MI_STAMP(1);
-    if (tid < 64)
+    if (tid < 64 && !((XV & 64) && prm.alpha1 != 1.2345678e300))
       {
         const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
+        if constexpr (V2 && !(XV & 64))
+          {
+            stage_acc();
+            interp(1);
+          }
         // ---- residual: Q[i][k] = w sum_j tau_ij M_kj, V[i] = rho w (acc - b)_i, integrated against grad N_a / N_a
         MI_WAVE_SYNC();
 #pragma unroll
@@ -1102,42 +1231,11 @@ namespace mi
           }
         if constexpr (RES_ONLY)
           return;
-        // ---- while the tangent waves contract: where the 729 node-pair blocks of this cell go.  One 64-bit word per
-        // block (a, b) in wave 0's own scratch, which the residual no longer needs: bits 0-31 position of the block in
-        // the global matrix (base + g * gstride + kx, mi_mesh.hpp; 0xffffffff: the node has no row here), 32-40 its place
-        // in the lower-triangle image of the element tangent, 41 a >= b (else: the transposed block of (b, a)),
-        // 42 first touch in processing order (plain store), 43 a == b, 44-46 / 47-49 constraint bits of A / B.
-        MI_WAVE_SYNC();
-        {
-          const uint16_t *__restrict__ offc = prm.off + cell * (NPC * NPC);
-          uint64_t *const tab = reinterpret_cast<uint64_t *>(s_w);
+        if constexpr (!V2)
           {
-            const bool special = lane < NPC && (s_cm[lane] != 0 || s_ri[lane].x < 0);
-            const bool any     = __builtin_amdgcn_ballot_w64(special) != 0;
-            if (lane == 0)
-              s_plain = any ? 0 : 1;
+            MI_WAVE_SYNC();
+            build_table(reinterpret_cast<uint64_t *>(s_w));
           }
-          uint16_t        o[12];
-#pragma unroll
-          for (int r = 0; r < 12; ++r) // all twelve (coalesced) loads in flight at once
-            o[r] = (r * 64 + lane < NPC * NPC) ? offc[r * 64 + lane] : uint16_t(0);
-#pragma unroll
-          for (int r = 0; r < 12; ++r)
-            {
-              const int blk = r * 64 + lane;
-              if (blk < NPC * NPC)
-                {
-                  const int      a = blk / NPC, b = blk - NPC * a;
-                  const int2     ri = s_ri[a];
-                  const uint32_t pos = ri.x >= 0 ? uint32_t(ri.x + int32_t((o[r] >> 4) & 0x7ff) * ri.y + int32_t(o[r] & 15)) : 0xffffffffu;
-                  const bool     low = a >= b;
-                  const int      hi = low ? a : b, lo = low ? b : a;
-                  tab[blk] = uint64_t(pos) | (uint64_t(hi * (hi + 1) / 2 + lo) << 32) | (uint64_t(low) << 41) |
-                             (uint64_t(o[r] >> 15) << 42) | (uint64_t(a == b) << 43) | (uint64_t(s_cm[a]) << 44) |
-                             (uint64_t(s_cm[b]) << 47);
-                }
-            }
-        }
       }
     if constexpr (!RES_ONLY)
       {
@@ -1150,9 +1248,93 @@ namespace mi
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2)
               Kacc[a3][b3][b2] = 0.0;
-        if (tid >= 64)
+        if (tid >= 64 && !((XV & 32) && prm.alpha1 != 1.2345678e300)) // (XV & 32: timing-only ablation without the contractions)
           {
             const double *__restrict__ cb = s_C + ij * 9 * FS;
+            // V2 (45 fields): field of (kl) for this lane's (ci, cj): (ci, cj, k, l) for ci < cj, (cj, ci, l, k) for ci > cj,
+            // (ci, ci, min, max) on the diagonal
+            const int  pbase = q2sf_pair_base(ci < cj ? ci : cj, ci < cj ? cj : ci);
+            const bool fdiag = ci == cj, fswap = ci > cj;
+            auto       fld   = [&](const int kl) __attribute__((always_inline)) -> const double * {
+              if (kl == 9)
+                return s_C + MASSF * FS;
+              if constexpr (V2)
+                {
+                  const int k = kl / 3, l = kl - 3 * k;
+                  return s_C + (pbase + (fdiag ? q2sf_sym6(k < l ? k : l, k < l ? l : k) : fswap ? l * 3 + k : kl)) * FS;
+                }
+              else
+                return cb + kl * FS;
+            };
+            if constexpr ((XV & 1) != 0)
+              {
+                // step (qz, pos = position of kl in the group order, qy); ring slot qy: the values of step (qz, pos, qy) are
+                // requested by step (qz, pos - 1, qy)
+                double2 ring[4][2];
+                double  acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+                for (int qy = 0; qy < 4; ++qy)
+                  {
+                    const double *__restrict__ f_ = fld(q2sf_kl_order(0)) + qy * 4;
+                    ring[qy][0]                   = *reinterpret_cast<const double2 *>(f_);
+                    ring[qy][1]                   = *reinterpret_cast<const double2 *>(f_ + 2);
+                  }
+#pragma unroll
+                for (int qz = 0; qz < 4; ++qz)
+#pragma unroll
+                  for (int pos = 0; pos < 10; ++pos)
+                    {
+                      const int  kl = q2sf_kl_order(pos), k = kl / 3, l = kl - 3 * k;
+                      const bool mass = kl == 9;
+                      const int  kx = (!mass && k == 0), lx = (!mass && l == 0), ky = (!mass && k == 1), ly = (!mass && l == 1),
+                                kz = (!mass && k == 2), lz = (!mass && l == 2);
+                      // the step after this one in the same ring slot
+                      const int  npos = pos == 9 ? 0 : pos + 1, nqz = pos == 9 ? qz + 1 : qz, nkl = q2sf_kl_order(npos);
+                      const double *__restrict__ fn = fld(nkl) + nqz * 16;
+#pragma unroll
+                      for (int qy = 0; qy < 4; ++qy)
+                        {
+                          const double2 c01 = ring[qy][0], c23 = ring[qy][1];
+                          double        t   = P1[kx * 2 + lx][0] * c01.x;
+                          t                 = fma(P1[kx * 2 + lx][1], c01.y, t);
+                          t                 = fma(P1[kx * 2 + lx][2], c23.x, t);
+                          t                 = fma(P1[kx * 2 + lx][3], c23.y, t);
+                          if (nqz < 4) // the slot is free again: its next occupant has three steps to arrive
+                            {
+                              ring[qy][0] = *reinterpret_cast<const double2 *>(fn + qy * 4);
+                              ring[qy][1] = *reinterpret_cast<const double2 *>(fn + qy * 4 + 2);
+                            }
+                          if (mass)
+                            t *= mflag;
+                          const double ta = t * phi2[ky][qy];
+#pragma unroll
+                          for (int b2 = 0; b2 < 3; ++b2)
+                            acc[b2] = fma(ta, ly ? D[qy][b2] : S[qy][b2], acc[b2]);
+                          if ((qy & 1) == 1)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                      // last field of an accumulator group (kz, lz): positions 4 (kl = 9), 6 (5), 8 (7), 9 (8)
+                      if (pos == 4 || pos == 6 || pos == 8 || pos == 9)
+                        {
+#pragma unroll
+                          for (int b2 = 0; b2 < 3; ++b2)
+                            {
+                              const double v = acc[b2];
+                              acc[b2]        = 0.0;
+#pragma unroll
+                              for (int a3 = 0; a3 < 3; ++a3)
+                                {
+                                  const double va = v * (kz ? D[qz][a3] : S[qz][a3]);
+#pragma unroll
+                                  for (int b3 = 0; b3 < 3; ++b3)
+                                    Kacc[a3][b3][b2] = fma(va, lz ? D[qz][b3] : S[qz][b3], Kacc[a3][b3][b2]);
+                                }
+                            }
+                        }
+                    }
+              }
+            else
+              {
 #pragma unroll
             for (int qz = 0; qz < 4; ++qz)
               {
@@ -1167,7 +1349,7 @@ namespace mi
                     const bool mass = kl == 9;
                     const int  kx = (!mass && k == 0), lx = (!mass && l == 0), ky = (!mass && k == 1),
                               ly = (!mass && l == 1), kz = (!mass && k == 2), lz = (!mass && l == 2);
-                    const double *__restrict__ f = mass ? s_C + 81 * FS : cb + kl * FS;
+                    const double *__restrict__ f = fld(kl);
 #pragma unroll
                     for (int qy = 0; qy < 4; ++qy)
                       {
@@ -1203,6 +1385,7 @@ namespace mi
                           }
                       }
               }
+              }
           }
         MI_STAMP(2);
         __syncthreads(); // (2) fields consumed: the element tangent image goes on top of them
@@ -1237,7 +1420,7 @@ namespace mi
         // instruction).  Everything that depends on the block comes out of wave 0's table in one LDS read; what depends
         // on the entry is constant per thread.
         {
-          const uint64_t *const tab = reinterpret_cast<const uint64_t *>(s_w);
+          const uint64_t *const tab = V2 ? s_tab : reinterpret_cast<const uint64_t *>(s_w);
           const int      tq = tid / 9, e = tid - 9 * tq, ei = e / 3, ej = e - 3 * ei;
           const int      src_low = e * EBE_NBLK, src_tr = (ej * 3 + ei) * EBE_NBLK; // image rows of the entry / its transpose
           const uint32_t cm      = (1u << ei) | (8u << ej);                          // constraint bits that kill this entry
@@ -1262,7 +1445,7 @@ namespace mi
               for (int u = 0; u < 9; ++u)
                 {
                   const int  blk = (bb + u) * 28 + tq;
-                  const bool rd  = !(XV & 2) && tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu) && !((t[u] >> 42) & 1);
+                  const bool rd  = !(XV & 24) && tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu) && !((t[u] >> 42) & 1);
                   old[bb + u]    = rd ? vbase[int64_t(uint32_t(t[u])) * 9] : 0.0;
                 }
             }
@@ -1294,9 +1477,7 @@ namespace mi
                     w_ = (((fl >> 11) & 1) && on_diag) ? fabs(w_) : 0.0;
                   if (tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu))
                     {
-                      if ((XV & 2) && !((t[u] >> 42) & 1))
-                        unsafeAtomicAdd(&vbase[int64_t(uint32_t(t[u])) * 9], w_);
-                      else
+                      if (!(XV & 8) || w_ == 1.2345678e300) // (XV & 8: timing-only ablation without the scatter's memory traffic)
                         vbase[int64_t(uint32_t(t[u])) * 9] = w_ + old[bb + u];
                     }
                 }
@@ -1322,6 +1503,7 @@ namespace mi
         }
         MI_STAMP(6);
 #undef MI_STAMP
+#undef MI_STAMPW
         if (prm.ke)
           {
             __syncthreads();
@@ -4012,7 +4194,7 @@ namespace mi
       for (int i = 0; i < 3; ++i)
         dbg[i] = tacc[i];
 #undef BAND_STAMP
-    if (!do_solve || do_solve == 3) // (3: timing-only, MI_BAND_DBG)
+    if (!do_solve)
       return;
     __syncthreads();
     // ---- backward substitution L^T x = y (L from memory), as in band_cholesky_solve
@@ -4429,14 +4611,41 @@ namespace mi
               else
                 hipLaunchKernelGGL((assemble_q2sf<false, 0>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 3: // A/B (round 4): the prologue's wave rotates with the cell index
+            case 3: // A/B (round 5): pipelined contraction
               hipLaunchKernelGGL((assemble_q2sf<false, 1>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 4: // A/B (round 4): later touches by L2 atomics
+            case 4: // A/B (round 5): wave 0's prologue at raised priority
               hipLaunchKernelGGL((assemble_q2sf<false, 2>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 5: // A/B (round 4): both
+            case 5: // A/B (round 5): both
               hipLaunchKernelGGL((assemble_q2sf<false, 3>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 6: // A/B (round 5): 45 fields, block table by wave 3, acceleration interpolated beside the contractions
+              hipLaunchKernelGGL((assemble_q2sf<false, 4>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 7: // A/B (round 5): 6 + pipelined contraction
+              hipLaunchKernelGGL((assemble_q2sf<false, 5>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 169:
+              hipLaunchKernelGGL((assemble_q2sf<false, 69>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 168:
+              hipLaunchKernelGGL((assemble_q2sf<false, 68>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 108:
+              hipLaunchKernelGGL((assemble_q2sf<false, 8>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 109:
+              hipLaunchKernelGGL((assemble_q2sf<false, 9>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 116:
+              hipLaunchKernelGGL((assemble_q2sf<false, 16>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 132:
+              hipLaunchKernelGGL((assemble_q2sf<false, 32>), dim3(p.cell_count), dim3(256), 0, s, p);
+              break;
+            case 140:
+              hipLaunchKernelGGL((assemble_q2sf<false, 40>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
             case 9: // node-pair form (the default until round 2): 16.4 ms per assembly at 5 M DoFs
               launch_asm_sel<3, 2, 2, 256, 8>(p, s);
@@ -4446,15 +4655,6 @@ namespace mi
               break;
             case 2:
               launch_asm<3, 2, 2, 256, 4>(p, s); // 27 kB LDS: no faster than QC = 8 (register limited)
-              break;
-            case 6:
-              launch_asm<3, 2, 2, 256, 8, 1, 1>(p, s); // timing only: no tangent scatter
-              break;
-            case 7:
-              launch_asm<3, 2, 2, 256, 8, 1, 2>(p, s); // timing only: phases A/B + residual
-              break;
-            case 8:
-              launch_asm<3, 2, 2, 256, 8, 1, 3>(p, s); // timing only: phases A/B + residual + scatter
               break;
             default:
               launch_asm_sel<3, 2, 2, 256, 8>(p, s); // 36 kB LDS, 3 workgroups per CU: 19.5 ms
@@ -4656,26 +4856,28 @@ namespace mi
     static const bool lds_ok = !(getenv("MI_BAND_LDS") && atoi(getenv("MI_BAND_LDS")) == 0);
     if (factor && lds_ok && hbw + BAND_NB <= BAND_LDS_W)
       {
-        // MI_BAND_DBG (diagnostic): phase clocks of thread 0, printed after a synchronisation; no backward substitution
+        // MI_BAND_DBG (diagnostic): phase clocks of thread 0 of the first two factorisations, printed after a
+        // synchronisation; the solve itself is the production one (stamps only), the buffer lives for the call
         static const bool   dbg_on = getenv("MI_BAND_DBG") != nullptr;
-        static unsigned long long *d_dbg = nullptr;
-        if (dbg_on && !d_dbg)
-          hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long));
+        static int          shown  = 0;
+        unsigned long long *d_dbg  = nullptr;
+        if (dbg_on && shown < 2 && hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
+          d_dbg = nullptr;
         if (dim == 3)
           hipLaunchKernelGGL((band_cholesky_lds<3>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
-                             (solve && dbg_on) ? 3 : int(solve), d_dbg);
+                             int(solve), d_dbg);
         else
           hipLaunchKernelGGL((band_cholesky_lds<2>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
-                             (solve && dbg_on) ? 3 : int(solve), d_dbg);
-        if (dbg_on)
+                             int(solve), d_dbg);
+        if (d_dbg)
           {
             unsigned long long h[4];
             hipStreamSynchronize(s);
             hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
-            static int shown = 0;
-            if (shown++ < 2)
-              fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: panel + y %llu, next block's columns %llu, next "
-                              "diagonal block beside the trailing update %llu\n", n, hbw, h[0], h[1], h[2]);
+            hipFree(d_dbg);
+            ++shown;
+            fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: panel + y %llu, next block's columns %llu, next "
+                            "diagonal block beside the trailing update %llu\n", n, hbw, h[0], h[1], h[2]);
           }
         return 0;
       }

@@ -7,6 +7,9 @@
 #include <functional>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <unistd.h>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -117,6 +120,13 @@ end
 
 int main()
 {
+  // every file the tests write goes into a scratch directory of their own (under $TMPDIR), removed at the end
+  std::string scratch = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/mi_test_host_XXXXXX";
+  if (!mkdtemp(scratch.data()) || chdir(scratch.c_str()) != 0)
+    {
+      std::perror("test_host: scratch directory");
+      return 2;
+    }
   // ---------------- Adapter::Time (time_handler.h:21-84)
   {
     Adapter::Time t(10.0, 0.005);
@@ -394,6 +404,45 @@ int main()
     while (std::getline(log, line))
       rows += (!line.empty() && line[0] != '#');
     CHECK(rows == 2); // one participant, one row per completed window
+    // an error of the coupling library on rank 0 (here: a per-vertex trace that misses a vertex, thrown by
+    // setMeshVertices) ends BOTH ranks at the next collective instead of leaving rank 1 blocked in it
+    {
+      write_file("t_ranks_bad.txt", "0.01 0 1 10\n0.01 1 2 20\n");
+      write_file("t_ranks_bad.xml", R"(<precice-configuration dimensions="2">
+  <!-- replay: read-data = vertex-trace t_ranks_bad.txt -->
+  <coupling-scheme:serial-explicit><max-time-windows value="1" /><time-window-size value="0.01" /></coupling-scheme:serial-explicit>
+</precice-configuration>)");
+      struct PB
+      {
+        std::string participant_name = "Solid", config_file = "t_ranks_bad.xml", mesh_name = "m", read_data_name = "Stress",
+                    write_data_name = "Displacement";
+      };
+      std::vector<std::string> what(2);
+      auto failing_rank = [&](int r) {
+        try
+          {
+            mi::thread_identity() = mi::RankIdentity{r, 2, nullptr, 0};
+            PB                                  par;
+            Adapter::Adapter<2, MockVector, PB> ad(par, 7);
+            MockVector                          u;
+            RankDofs                            dofs;
+            dofs.sh   = &sh;
+            dofs.rank = r;
+            ad.initialize(dofs, u);
+            what[size_t(r)] = "no exception";
+          }
+        catch (std::exception &e)
+          {
+            what[size_t(r)] = e.what();
+          }
+        mi::thread_identity() = mi::RankIdentity{};
+      };
+      std::thread t2(failing_rank, 1);
+      failing_rank(0);
+      t2.join();
+      CHECK(what[0].find("every vertex exactly once") != std::string::npos);
+      CHECK(what[1].find("rank 0") != std::string::npos && what[1].find("rank 1 stops") != std::string::npos);
+    }
     // several ranks but no broadcast bound: refused, not silently wrong
     mi::thread_identity() = mi::RankIdentity{1, 2, nullptr, 0};
     {
@@ -442,5 +491,7 @@ int main()
     CHECK(throws([&] { bad.setMeshVertices("m", pos, ids); }, "every vertex exactly once"));
   }
   std::printf(g_fail ? "HOST TESTS FAILED (%d)\n" : "HOST TESTS OK\n", g_fail);
+  if (chdir("/") == 0)
+    std::filesystem::remove_all(scratch);
   return g_fail ? 1 : 0;
 }

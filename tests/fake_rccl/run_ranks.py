@@ -123,7 +123,13 @@ def main():
     rep = {"ok": True, "world": world, "its_ranks": [results[r]["its0"] + results[r]["its1"] for r in range(world)],
            "its_single": single["its0"] + single["its1"], "its_emulated": emu["its0"] + emu["its1"]}
     ref = np.concatenate([[0.0, 1e300, -3.5], np.arange(results[0]["bcast"].size - 3, dtype=np.float64)])
-    rep["broadcast_ok"] = bool(all(np.array_equal(results[r]["bcast"], ref) for r in range(world)))
+    # bit patterns, not values: the -0.0 that rank 0 sent arrives as +0.0 on every rank of a team of several (x + 0 + ... + 0
+    # in the all-reduce; documented at mi_comm_broadcast) and stays -0.0 where the call is a no-op (one rank)
+    ref_bits = ref.view(np.uint64).copy()
+    if world == 1:
+        ref_bits[0] = np.float64(-0.0).view(np.uint64)
+    rep["broadcast_ok"] = bool(all(np.array_equal(np.asarray(results[r]["bcast"], dtype=np.float64).view(np.uint64), ref_bits)
+                                   for r in range(world)))
     keys = ("u0", "u1", "if0", "if1", "Kx", "restored", "lin_d", "lin_v")
     rep["rank_spread"] = max(rel(results[r][k], results[0][k]) for r in range(1, world) for k in keys) if world > 1 else 0.0
     rep["vs_single"] = {k: rel(results[0][k], single[k]) for k in keys}

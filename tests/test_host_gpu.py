@@ -201,6 +201,29 @@ def test_multi_rank_coupling_goes_through_rank_zero(tmp_path, name):
     assert (tmp_path / "ranks" / "out" / "solution-000.vtk").exists()
 
 
+def test_rank_threads_stop_together_when_the_coupling_library_fails(tmp_path):
+    """an error of the coupling library on the ONE preCICE-facing rank [REF adapter.h:213-225, 324-341] must end every rank:
+    rank 0 catches it and the next collective call (mi_comm_broadcast behind Adapter::RankZeroParticipant) carries a status
+    word, so the other ranks leave with an exception of their own instead of waiting in the all-reduce for ever.  Four rank
+    threads against the RCCL test double; the replayed force trace misses vertices, which the participant reports from
+    setMeshVertices on rank 0.  The harness must come back (its barrier would time out otherwise) with exit code 1, the
+    original message from rank 0 and one 'stops with it' per other rank."""
+    frccl = os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "dealii-adapter_amd"), "-j4", "all"])
+    subprocess.check_call(["make", "-C", frccl, "libmi_elasticity_fakerccl.so", "ranks"])
+    name = "fsi3_neo_3d_q3"
+    (tmp_path / "parameters.prm").write_text(open(os.path.join(CASES, name, "parameters.prm")).read())
+    (tmp_path / "forces.txt").write_text("# t vertex fx fy fz\n0.01 0 0 -40 0\n0.01 1 0 -40 0\n")  # two of many vertices
+    (tmp_path / "precice-config.xml").write_text(
+        open(os.path.join(CASES, name, "precice-config.xml")).read().replace(
+            "read-data = constant 0 -40 0", "read-data = vertex-trace forces.txt"))
+    r = subprocess.run([os.path.join(frccl, "elasticity_ranks3d"), "4"], cwd=tmp_path, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 1, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stderr.count("Exception on processing") == 4
+    assert r.stderr.count("every vertex exactly once") == 1 and r.stderr.count("stops with it") == 3
+
+
 def test_executable_nonlinear_implicit_checkpointing(tmp_path):
     """implicit coupling: 3 coupling iterations per window with save/reload of the 6 state vectors on the device"""
     name = "fsi3_neo_2d_implicit"
