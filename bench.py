@@ -391,7 +391,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         lin_its_last = [int(info.lin_its[i]) for i in range(min(info.newton_iterations, 16))]
-        cnt = {k: G.get_tuning("count_" + k) for k in ("scalar_allreduce", "vector_allreduce", "halo_exchange", "cg_host_sync",
+        cnt = {k: G.get_tuning("count_" + k) for k in ("scalar_allreduce", "scalar_allreduce_cg", "vector_allreduce", "halo_exchange", "cg_host_sync",
                                                         "cg_iterations", "cg_solves", "mg_refresh")}
         cnt["mg_refresh_every"] = G.get_tuning("mg_refresh_every")
         r = {"G": G, "elapsed": elapsed, "lin_its_last": lin_its_last, "counts": cnt, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
@@ -457,8 +457,12 @@ def main():
                 # latency-bound events of the linear solves per CG iteration / per solve.  Complete for a decomposed run
                 # (N ranks or --slabs N); on ONE slab the scalar all-reduce sites are still counted (they are no-ops there)
                 # while halo exchanges and the V-cycle's vector all-reduce are skipped before their counters
+                # scalar_allreduce counts every one of a step (the Newton loop's residual and update norms included, seven per
+                # step), scalar_allreduce_in_solver those made inside the linear solves
+                "cg_recurrence": "single reduction (r.z, z.Az, ||r||^2 in one all-reduce per iteration)" if G.get_tuning("cg_single_reduction_active") else "standard (p.Ap between the two updates)",
                 "collectives_per_iteration": {
                     "scalar_allreduce": R["counts"]["scalar_allreduce"] / max(R["counts"]["cg_iterations"], 1),
+                    "scalar_allreduce_in_solver": R["counts"]["scalar_allreduce_cg"] / max(R["counts"]["cg_iterations"], 1),
                     "vector_allreduce": R["counts"]["vector_allreduce"] / max(R["counts"]["cg_iterations"], 1),
                     "halo_exchange": R["counts"]["halo_exchange"] / max(R["counts"]["cg_iterations"], 1)},
                 "host_syncs_per_solve": R["counts"]["cg_host_sync"] / max(R["counts"]["cg_solves"], 1),

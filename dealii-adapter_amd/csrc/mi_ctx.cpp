@@ -210,6 +210,8 @@ namespace mi_detail
     p.stress = c->vec(MI_V_EXTERNAL_STRESS);
     p.rhs    = c->vec(MI_V_SYSTEM_RHS);
     p.vals   = c->d_vals;
+    p.zero_blk  = uint32_t(c->mesh.nvalblocks() + 1);
+    p.trash_blk = uint32_t(c->mesh.nvalblocks() + 2);
     p.mu     = c->mat.mu;
     p.kappa  = c->kappa;
     p.rho    = c->mat.rho;
@@ -714,8 +716,7 @@ namespace mi_detail
         HIPCHK(c, hipGetLastError());
         return MI_OK;
       }
-    c->ke_valid = (c->d_ke || c->d_qrec) &&
-                  !(c->dim == 3 && c->degree == 2 && c->asm_variant >= 100); // timing-only ablations
+    c->ke_valid = c->d_ke || c->d_qrec;
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -840,6 +841,12 @@ namespace mi_detail
     Team      &T    = *c->team;
     mi_ctx    *c0   = T.members[0];
     const bool dist = T.size > 1;
+    struct CountCg // the scalar all-reduces made between here and any return belong to the solve
+    {
+      Team   &T;
+      int64_t at;
+      ~CountCg() { T.n_scalar_allreduce_cg += T.n_scalar_allreduce - at; }
+    } count_cg{T, T.n_scalar_allreduce};
     for (mi_ctx *m : T.members) // outside the timed SpMV launches
       refresh_vals32(m);
     const int  tt   = tic(c0, MI_T_CG_TOTAL);
@@ -992,12 +999,18 @@ namespace mi_detail
                                         m->stream);
           }
       }
+    // Single-reduction form of the multigrid-PCG (Chronopoulos & Gear): the product is applied to
+    // z = M^-1 r instead of p, A p follows by recurrence, and r.z, z.Az and ||r||^2 travel in ONE all-reduce per iteration
+    // (the standard recurrence needs p.Ap between its two updates: two to three).  Default on teams of several slabs, where
+    // an all-reduce is a latency the ranks wait out together; one GPU keeps the standard form ("cg_single_reduction" 0 / 1).
+    const bool single = use_mg && (c0->cg_single_reduction == 1 || (c0->cg_single_reduction < 0 && dist));
     if (!use_mg && (rc = team_allreduce(T, SC_TOT, 4)))
       return rc;
-    if (use_mg && (rc = precondition(true, true)))
+    if (use_mg && !single && (rc = precondition(true, true)))
       return rc;
-    for (size_t k = 0; k < R; ++k)
-      mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
+    if (!single || !dist) // (single-reduction form on a team: |b|^2 arrives with the first iteration's all-reduce)
+      for (size_t k = 0; k < R; ++k)
+        mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
 
     int64_t  it      = 0;
     bool     done    = false;
@@ -1018,7 +1031,74 @@ namespace mi_detail
     // the flag turns every later CG kernel into a no-op and the V-cycles in the queue are wasted work, nothing else:
     // iterates, iteration count and residual are those of the polled loop bit by bit.  Saves expected_its - 2 host
     // synchronisations and as many scalar all-reduces per solve (||r||^2 then travels with r.z).
-    const int64_t speculate_to = (use_mg && c0->cg_speculate) ? std::min<int64_t>(max_it - 1, int64_t(expected_its) - 2) : 0;
+    // (margin: how many of the expected iterations are left to polled ones; a team pays an all-reduce for every poll)
+    const int64_t margin       = c0->cg_speculate_margin > 0 ? c0->cg_speculate_margin : ((single && dist) ? 1 : 2);
+    const int64_t speculate_to = (use_mg && c0->cg_speculate) ? std::min<int64_t>(max_it - 1, int64_t(expected_its) - margin) : 0;
+    if (single)
+      {
+        auto z_of = [](mi_ctx *m) { return m->work(W_Z); };
+        std::vector<SpmvFusion> zfusion; // w = K z with the partials of z.w
+        for (size_t k = 0; k < R; ++k)
+          {
+            cgs[k].s = T.members[k]->work(W_S) + T.members[k]->own0;
+            zfusion.push_back(SpmvFusion{T.members[k]->work(W_Z), cgs[k].part_pq, cgs[k].flags});
+          }
+        if (dist) // the flags of the previous solve must not switch this one's first product off
+          for (mi_ctx *m : T.members)
+            HIPCHK(m, hipMemsetAsync(m->d_flags, 0, 2 * sizeof(int32_t), m->stream));
+        while (!done && it < max_it)
+          {
+            ++it;
+            if ((rc = mg_apply(T))) // z = M^-1 r
+              return rc;
+            for (size_t k = 0; k < R; ++k)
+              mi::launch_dot_partials(cgs[k].r, cgs[k].z, T.members[k]->own_n, cgs[k].part_rz, T.members[k]->grid_vec,
+                                      T.members[k]->stream);
+            int t = tic(c0, MI_T_SPMV);
+            if ((rc = team_spmv(T, self, z_of, q_of, c0->cg_fused_dot ? zfusion.data() : nullptr))) // w = K z, z.w
+              return rc;
+            toc(c0, t);
+            if (!c0->cg_fused_dot)
+              for (size_t k = 0; k < R; ++k)
+                mi::launch_dot_partials(cgs[k].z, cgs[k].q, T.members[k]->own_n, cgs[k].part_pq, T.members[k]->grid_vec,
+                                        T.members[k]->stream);
+            if (dist)
+              {
+                for (size_t k = 0; k < R; ++k)
+                  {
+                    mi_ctx *m = T.members[k];
+                    mi::launch_reduce_to_totals(cgs[k].part_rr, m->grid_vec, m->d_sc + SC_TOT, cgs[k].part_rz, m->grid_vec,
+                                                m->d_sc + SC_TOT + 1, it == 1 ? nullptr : cgs[k].flags, m->stream);
+                    mi::launch_reduce_to_totals(cgs[k].part_pq, cgs[k].npart_pq, m->d_sc + SC_TOT + 2, nullptr, 0, nullptr,
+                                                it == 1 ? nullptr : cgs[k].flags, m->stream);
+                  }
+                if ((rc = team_allreduce(T, SC_TOT, it == 1 ? 4 : 3))) // THE reduction of the iteration
+                  return rc;
+                if (it == 1)
+                  for (size_t k = 0; k < R; ++k)
+                    mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
+              }
+            t = tic(c0, MI_T_CG_VECTOR);
+            for (size_t k = 0; k < R; ++k)
+              mi::launch_cg_update_single(cgs[k], int(it), T.members[k]->grid_vec, T.members[k]->stream);
+            toc(c0, t);
+            if (it <= speculate_to) // no test, no poll: the next update takes the decision
+              continue;
+            if (dist)
+              {
+                for (size_t k = 0; k < R; ++k)
+                  mi::launch_reduce_to_totals(cgs[k].part_rr, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT, nullptr, 0,
+                                              nullptr, cgs[k].flags, T.members[k]->stream);
+                if ((rc = team_allreduce(T, SC_TOT, 1)))
+                  return rc;
+              }
+            for (size_t k = 0; k < R; ++k)
+              mi::launch_cg_final_check(cgs[k], int(it), T.members[k]->stream);
+            if ((rc = poll()))
+              return rc;
+          }
+      }
+    else
     while (!done && it < max_it)
       {
         const int64_t stop = std::min<int64_t>(max_it, it + batch);
@@ -1267,7 +1347,8 @@ namespace mi_detail
     // the tangent: ONE array, written by the element scatter, read by the SpMV (padding rows of the last slice of a
     // length class included: they are zeroed once and never written)
     const size_t nvals = std::max<size_t>(1, size_t(m.nvalblocks()) * dd);
-    HIPCHK(c, hipMalloc((void **)&c->d_vals, (nvals + 2) * sizeof(double)));
+    // (+ the ZERO and TRASH blocks of the element kernel's branch-free scatter: blocks nvalblocks + 1 and + 2)
+    HIPCHK(c, hipMalloc((void **)&c->d_vals, (nvals + 2 + 4 * dd) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_vecs, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_work, size_t(W_COUNT) * size_t(c->n) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_saved, size_t(6) * size_t(c->n) * sizeof(double)));
@@ -1278,7 +1359,7 @@ namespace mi_detail
     HIPCHK(c, hipMalloc((void **)&c->d_iface_buf, nif * sizeof(double)));
     c->h_pinned_doubles = std::max(nif, T.iface_global.size() * size_t(c->dim)) + 64;
     HIPCHK(c, hipHostMalloc((void **)&c->h_pinned, c->h_pinned_doubles * sizeof(double), hipHostMallocDefault));
-    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, nvals * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, (nvals + 2 + 4 * dd) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_work, 0, size_t(W_COUNT) * size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sc, 0, 16 * sizeof(double), c->stream));
@@ -2408,7 +2489,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->small_cg = value;
       else if (k == "halo_overlap" && (value == 0 || value == 1))
         c->team->overlap = value;
-      else if (k == "asm_variant" && ((value >= 0 && value <= 9) || (value >= 100 && value < 228)))
+      else if (k == "asm_variant" && value >= 0 && value <= 9)
         m->asm_variant = value;
       else if (k == "mg_refresh_every" && value >= 1 && value <= 1000)
         m->mg_refresh_every = value;
@@ -2426,6 +2507,10 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_r0_unassembled = value;
       else if (k == "cg_speculate" && (value == 0 || value == 1))
         m->cg_speculate = value;
+      else if (k == "cg_single_reduction" && value >= -1 && value <= 1)
+        m->cg_single_reduction = value;
+      else if (k == "cg_speculate_margin" && value >= 0 && value <= 16)
+        m->cg_speculate_margin = value;
       else if (k == "halo_skip" && (value == 0 || value == 1))
         c->team->halo_skip = value;
       else if (k == "mf_halo_overlap" && (value == 0 || value == 1))
@@ -2482,6 +2567,12 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = c->team->size > 1 ? c->team->amap.ext_axis[c->team->dim - 1] + 1 : 0;
   else if (k == "cg_speculate")
     *value = m->cg_speculate;
+  else if (k == "cg_single_reduction")
+    *value = m->cg_single_reduction;
+  else if (k == "cg_single_reduction_active") // what cg_run will do with a multigrid-preconditioned solve
+    *value = (m->cg_single_reduction == 1 || (m->cg_single_reduction < 0 && c->team->size > 1)) ? 1 : 0;
+  else if (k == "cg_speculate_margin")
+    *value = m->cg_speculate_margin;
   else if (k == "halo_skip")
     *value = c->team->halo_skip;
   else if (k == "precond")
@@ -2490,6 +2581,8 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = m->spmv_variant;
   else if (k == "count_scalar_allreduce")
     *value = int(c->team->n_scalar_allreduce);
+  else if (k == "count_scalar_allreduce_cg")
+    *value = int(c->team->n_scalar_allreduce_cg);
   else if (k == "count_vector_allreduce")
     *value = int(c->team->n_vector_allreduce);
   else if (k == "count_halo_exchange")
@@ -2519,6 +2612,7 @@ int mi_reset_timings(mi_ctx *c)
   int rc = sync(c);
   Team &T = *c->team;
   T.n_scalar_allreduce = T.n_vector_allreduce = T.n_halo = T.n_cg_sync = T.n_cg_its = T.n_cg_solves = 0;
+  T.n_scalar_allreduce_cg = 0;
   T.members[0]->n_mg_refresh = 0;
   std::memset(&c->team->members[0]->timings, 0, sizeof(mi_timings));
   return rc;
@@ -2619,7 +2713,7 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_assembly = double(ms) / std::max(1, reps);
-  if (getenv("MI_ASM_STAMPS") && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 7) || c->asm_variant >= 100))
+  if (getenv("MI_ASM_STAMPS") && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 8)))
     {
       // diagnostic: where a workgroup of the sum-factorised element kernel spends its life (shader-clock stamps of one
       // tangent wave at the phase boundaries), averaged over the cells of the first colour

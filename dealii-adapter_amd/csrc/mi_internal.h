@@ -24,6 +24,7 @@ namespace mi_detail
     W_Q,     // CG A*p
     W_DINV,  // Jacobi
     W_Z,     // preconditioned residual (multigrid)
+    W_S,     // single-reduction CG: A*p by recurrence
     W_COUNT
   };
   // what an SpMV launch fuses on top of y = K x: partials of dotv . y, skipped altogether when *done != 0
@@ -89,6 +90,7 @@ namespace mi_detail
     // halo exchanges (complete for a decomposed team; a single slab skips the last two before their counters), host
     // synchronisations and iterations inside cg_run
     int64_t n_scalar_allreduce = 0, n_vector_allreduce = 0, n_halo = 0, n_cg_sync = 0, n_cg_its = 0, n_cg_solves = 0;
+    int64_t n_scalar_allreduce_cg = 0; // those of n_scalar_allreduce made inside cg_run (the rest: Newton-level norms)
   };
 } // namespace mi_detail
 
@@ -148,6 +150,9 @@ struct mi_ctx
   int       correct_face_F = 0; // tuning "correct_face_F": the Neumann pull-back with F at the face point (default: the reference's quirk)
   int       cg_r0_unassembled = 1; // A h of a predicted start vector by the matrix-free product where available ("cg_r0_operator")
   bool      unassembled_now = false; // (set around that one product)
+  int       cg_single_reduction = -1; // multigrid-PCG in the single-reduction form (one all-reduce per iteration): -1 = on
+                                      // teams of several slabs, 0 never, 1 always (cg_run)
+  int       cg_speculate_margin = 0;  // expected iterations left to polled ones: 0 = 2, or 1 for the single-reduction form on a team
   int       cg_speculate = 1; // multigrid-PCG: enqueue the iterations the previous step's same solve needed (minus two)
                               // without polling the convergence flag in between (tuning "cg_speculate" 0: poll every one)
   int       pred_its[NPRED] = {}; // iterations of the j-th solve of the previous time step (0: unknown)

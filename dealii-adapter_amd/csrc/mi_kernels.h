@@ -43,6 +43,8 @@ namespace mi
     const double   *u, *du, *acc, *stress;
     double         *rhs;
     double         *vals;   // tangent, slice-interleaved block rows (mi_mesh.hpp) -- the layout the SpMV reads
+    uint32_t        zero_blk, trash_blk; // two blocks behind the matrix: one that stays zero (what a first touch "reads"), one that
+                                         // takes the stores of nodes without a row here (assemble_q2sf's branch-free scatter)
     double          mu, kappa, rho, alpha1;
     double          body[3];
     int64_t         cell_begin;
@@ -179,6 +181,7 @@ namespace mi
   struct CgParams
   {
     double       *x, *r, *p, *q;
+    double       *s;     // single-reduction form: s = A p by recurrence (q then holds w = A z)
     const double *dinv;
     double       *part_rr, *part_rz, *part_pq;
     double       *sc;    // [8] device scalars
@@ -278,6 +281,7 @@ namespace mi
                                const uint8_t *cmask_coarse, hipStream_t s);
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s);
   void launch_cg_update_xr(const CgParams &c, int it, int grid, hipStream_t s);
+  void launch_cg_update_single(const CgParams &c, int it, int grid, hipStream_t s);
   void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s);
   void launch_cg_set_tolerance(const CgParams &c, const double *part_bb, double rel_tol, hipStream_t s);
   void launch_cg_final_check(const CgParams &c, int it, hipStream_t s);

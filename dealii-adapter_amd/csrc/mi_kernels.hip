@@ -725,15 +725,20 @@ namespace mi
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                        \
       }                                                                                                               \
     while (0)
-  // XV (round 5, "asm_variant" 3-7 for A/B; the default instantiation carries the adopted bits): bit 0 = the contraction
-  // waves run a software pipeline over their 160 (qz, kl, qy) steps -- the LDS reads of step s + 4 are issued as soon
-  // as step s has consumed its ring slot -- and the (kl) loop is ordered by accumulator group (k == z, l == z), each
-  // group contracted along z as soon as it is complete (3 live accumulators instead of 12: the registers the ring
-  // needs); same additions in the same order, i.e. the same bits.  bit 1 = wave 0 runs its prologue, which the other
-  // three waves of the workgroup wait for, at raised priority.  bit 2 = 45 coefficient fields instead of 81 by the
-  // major symmetry C^{ij}_{kl} = C^{ji}_{lk} (the tangent changes at rounding level).  Timing-only ablations (wrong
-  // results, "asm_variant" 100 + XV): bit 3 = the scatter without its loads and stores, bit 4 = without its loads,
-  // bit 5 = no contractions.
+  // XV (round 5; "asm_variant" 3-8 select the combinations for A/B, profiles/r05/asm_ab_*.txt).  The default is 4 | 128.
+  //   bit 2 (adopted): 45 coefficient fields instead of 81 by the major symmetry C^{ij}_{kl} = C^{ji}_{lk} (the tangent
+  //     changes at rounding level); the block table is built by wave 3 while it would otherwise wait for the prologue,
+  //     in LDS of its own (the 45 fields leave room); the acceleration is interpolated behind barrier (1), beside the
+  //     contractions (only the residual needs it).
+  //   bit 7 (adopted): branch-free scatter (see there): 381 instead of 836 vector and 50 instead of 810 scalar
+  //     instructions per wave, the scatter phase 5.0 k instead of 9.9 k clocks of a workgroup's life.
+  //   bit 0 (measured, not adopted): the contraction waves run a software pipeline over their 160 (qz, kl, qy) steps --
+  //     the LDS reads of step s + 4 are issued as soon as step s has consumed its ring slot -- with the (kl) loop ordered
+  //     by accumulator group (k == z, l == z), each group contracted along z as soon as it is complete (3 live
+  //     accumulators instead of 12); same bits.  The contraction phase shrinks (18.9 k -> 14.4 k clocks) and the other
+  //     phases of the three workgroups of a CU grow by as much: 7.68 against 7.67 ms per assembly.
+  //   bit 1 (measured, not adopted): wave 0 runs its prologue at raised priority: prologue 19.6 k -> 14.3 k clocks, the
+  //     contractions 18.9 k -> 22.2 k, 8.2 against 7.7 ms.
   // assemble_q2sf, pipelined contraction: (kl) in the order of the accumulator groups (k == z, l == z) = (0,0): 0 1 3 4 and the
   // mass field 9, (0,1): 2 5, (1,0): 6 7, (1,1): 8 -- within a group ascending, the groups in the order the unpipelined
   // loop adds them into the tangent entries
@@ -760,7 +765,7 @@ namespace mi
   template <bool RES_ONLY, int XV = 0>
   __global__ __launch_bounds__(RES_ONLY ? 64 : 256, RES_ONLY ? 4 : 3) void assemble_q2sf(AsmParams prm)
   {
-    constexpr bool V2 = !RES_ONLY && (XV & 4) != 0;
+    constexpr bool V2 = !RES_ONLY && (XV & 4) != 0, SLIM = !RES_ONLY && (XV & 128) != 0;
     constexpr int NPC = 27, FS = 66, NF = V2 ? 46 : 82; // field stride (padded: fields of different ij on different banks), fields
     constexpr int PS = 20, PW = 9 * PS, AO = 552;
     constexpr int MASSF = NF - 1;                       // the mass field
@@ -919,7 +924,8 @@ namespace mi
             {
               const int      a = blk / NPC, b = blk - NPC * a;
               const int2     ri = s_ri[a];
-              const uint32_t pos = ri.x >= 0 ? uint32_t(ri.x + int32_t((o[r] >> 4) & 0x7ff) * ri.y + int32_t(o[r] & 15)) : 0xffffffffu;
+              const uint32_t pos = ri.x >= 0 ? uint32_t(ri.x + int32_t((o[r] >> 4) & 0x7ff) * ri.y + int32_t(o[r] & 15)) :
+                                               (SLIM ? prm.trash_blk : 0xffffffffu);
               const bool     low = a >= b;
               const int      hi = low ? a : b, lo = low ? b : a;
               tab[blk] = uint64_t(pos) | (uint64_t(hi * (hi + 1) / 2 + lo) << 32) | (uint64_t(low) << 41) |
@@ -963,7 +969,6 @@ namespace mi
                 s_ri[lane] = prm.rowinfo[node];
                 s_cm[lane] = prm.cmask[node] & 7;
               }
-            if constexpr (!(XV & 64))
 #pragma unroll
             for (int c = 0; c < 3; ++c)
               {
@@ -974,22 +979,11 @@ namespace mi
           }
         // ---- two interpolations to the points: pass 0 = u (gradients), pass 1 = acceleration (values; V2: after barrier
         // (1), beside the contractions -- only the residual needs it)
-        if constexpr ((XV & 64) != 0) // timing-only ablation: no gather, no interpolation, no residual
-          {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-              for (int k = 0; k < 3; ++k)
-                gxi[c][k] = 1e-7 * double((lane + 3 * c + k) & 7) * prm.rho;
-          }
-        else
-          {
         interp(0);
         if constexpr (!V2)
           {
             stage_acc();
             interp(1);
-          }
           }
         MI_STAMPW(8, 0); // gradients at the points
         // ---- geometry, kinematics, material at this point (nonlinear_elasticity.cc:927-934)
@@ -1125,10 +1119,10 @@ namespace mi
     if constexpr (!RES_ONLY)
       __syncthreads(); // (1) fields complete -- the one barrier every wave of the workgroup passes, outside the role branches
     MI_STAMP(1);
-    if (tid < 64 && !((XV & 64) && prm.alpha1 != 1.2345678e300))
+    if (tid < 64)
       {
         const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
-        if constexpr (V2 && !(XV & 64))
+        if constexpr (V2)
           {
             stage_acc();
             interp(1);
@@ -1248,7 +1242,7 @@ namespace mi
 #pragma unroll
             for (int b2 = 0; b2 < 3; ++b2)
               Kacc[a3][b3][b2] = 0.0;
-        if (tid >= 64 && !((XV & 32) && prm.alpha1 != 1.2345678e300)) // (XV & 32: timing-only ablation without the contractions)
+        if (tid >= 64)
           {
             const double *__restrict__ cb = s_C + ij * 9 * FS;
             // V2 (45 fields): field of (kl) for this lane's (ci, cj): (ci, cj, k, l) for ci < cj, (cj, ci, l, k) for ci > cj,
@@ -1427,6 +1421,51 @@ namespace mi
           const bool     on_diag = ei == ej;
           double *const  vbase   = prm.vals + e;
           const bool     plain   = s_plain != 0; // uniform: the table is complete since barrier (2)
+          if constexpr (SLIM)
+            {
+              // Branch-free form (round 5): a first touch loads the ZERO block behind the matrix instead of skipping its load, a
+              // node without a row here (ghost node of a slab) has the TRASH block as its position, so every lane runs the
+              // same straight-line code: per entry one table read with an immediate offset, a select, an address, a load; then
+              // the image value, an add, a store.  Threads 252-255 own no entry; of round 26 only block 728 exists (thread
+              // group 0).  The masking of constrained entries is a second instantiation for the few cells that need it.
+              if (tq < 28)
+                {
+                  const uint64_t *const tb = tab + tq;
+                  auto rounds = [&](auto plain_c) __attribute__((always_inline)) {
+                    constexpr bool PLAIN = decltype(plain_c)::value;
+                    double         old[27];
+#pragma unroll
+                    for (int r = 0; r < 27; ++r)
+                      {
+                        old[r] = 0.0;
+                        if (r < 26 || tq == 0)
+                          {
+                            const uint64_t t  = tb[r * 28];
+                            const uint32_t ld = ((t >> 42) & 1) ? prm.zero_blk : uint32_t(t);
+                            old[r]            = vbase[int64_t(ld) * 9];
+                          }
+                      }
+#pragma unroll
+                    for (int r = 0; r < 27; ++r)
+                      if (r < 26 || tq == 0)
+                        {
+                          const uint64_t t  = tb[r * 28];
+                          const uint32_t fl = uint32_t(t >> 32);
+                          double         w_ = s_C[((fl >> 9) & 1 ? src_low : src_tr) + int(fl & 511)];
+                          if constexpr (!PLAIN)
+                            if ((fl >> 12) & cm)
+                              w_ = (((fl >> 11) & 1) && on_diag) ? fabs(w_) : 0.0;
+                          vbase[int64_t(uint32_t(t)) * 9] = w_ + old[r];
+                        }
+                  };
+                  if (plain)
+                    rounds(std::true_type{});
+                  else
+                    rounds(std::false_type{});
+                }
+            }
+          else
+            {
           // phase A: the old values of every entry that is not a first touch, all requested before anything is stored
           // (loads and stores share the wave's memory counter: a load issued after a store waits for that store).
           // Batches of nine: the table words of a batch in one LDS round trip, then its nine loads.
@@ -1445,7 +1484,7 @@ namespace mi
               for (int u = 0; u < 9; ++u)
                 {
                   const int  blk = (bb + u) * 28 + tq;
-                  const bool rd  = !(XV & 24) && tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu) && !((t[u] >> 42) & 1);
+                  const bool rd  = tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu) && !((t[u] >> 42) & 1);
                   old[bb + u]    = rd ? vbase[int64_t(uint32_t(t[u])) * 9] : 0.0;
                 }
             }
@@ -1477,10 +1516,10 @@ namespace mi
                     w_ = (((fl >> 11) & 1) && on_diag) ? fabs(w_) : 0.0;
                   if (tq < 28 && blk < NPC * NPC && (plain || uint32_t(t[u]) != 0xffffffffu))
                     {
-                      if (!(XV & 8) || w_ == 1.2345678e300) // (XV & 8: timing-only ablation without the scatter's memory traffic)
-                        vbase[int64_t(uint32_t(t[u])) * 9] = w_ + old[bb + u];
+                      vbase[int64_t(uint32_t(t[u])) * 9] = w_ + old[bb + u];
                     }
                 }
+            }
             }
           if (prm.ke) // the cell's own masked blocks (what entered the global matrix) for the element-tangent product: the
             {         // image is masked in place, in a pass of its own so that nothing above waits for LDS stores
@@ -3070,6 +3109,86 @@ namespace mi
       }
   }
 
+  // cg_update_single (iteration it >= 1 of the single-reduction form of the preconditioned CG, Chronopoulos & Gear 1989):
+  // with z = M^-1 r and w = A z at hand and ONE reduction {||r||^2, gamma = r.z, delta = z.w} behind them,
+  //   beta = gamma / gamma_old,  alpha = gamma / (delta - beta gamma / alpha_old)        (it == 1: beta = 0, alpha = gamma / delta)
+  //   p = z + beta p,  s = w + beta s  (= A p by recurrence),  x += alpha p,  r -= alpha s,
+  // the same iterates as cg_update_p / cg_update_xr in exact arithmetic.  The convergence test of the residual the
+  // iteration started from is taken first, as in cg_update_p.  Scalars: sc[0..1] gamma ping-pong, sc[5..6] alpha ping-pong.
+  __global__ __launch_bounds__(256) void cg_update_single(CgParams c, int it)
+  {
+    __shared__ double s_red[4];
+    if (c.flags[0])
+      return;
+    const double rr  = c.totals ? c.totals[0] : reduce_partials<256>(c.part_rr, c.npart, s_red);
+    const double rz  = c.totals ? c.totals[1] : reduce_partials<256>(c.part_rz, c.npart, s_red);
+    const double zw  = c.totals ? c.totals[2] : reduce_partials<256>(c.part_pq, c.npart_pq, s_red);
+    const double res = sqrt(rr);
+    if (!(rr == rr) || !(rz == rz) || rr > 1.79e308 || fabs(rz) > 1.79e308)
+      {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+          {
+            c.flags[0] = 2;
+            c.flags[1] = it - 1;
+            c.sc[3]    = res;
+          }
+        return;
+      }
+    if (res <= c.sc[2])
+      {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+          {
+            c.flags[0] = 1;
+            c.flags[1] = it - 1;
+            c.sc[3]    = res;
+          }
+        return;
+      }
+    const double beta  = (it == 1) ? 0.0 : rz / c.sc[(it - 1) & 1];
+    const double denom = (it == 1) ? zw : zw - beta * rz / c.sc[5 + ((it - 1) & 1)]; // p.Ap of the standard recurrence
+    if (!(denom > 0.0) || denom > 1.79e308)
+      {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+          {
+            c.flags[0] = 2;
+            c.flags[1] = it - 1;
+            c.sc[3]    = res;
+          }
+        return;
+      }
+    const double alpha = rz / denom;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+      {
+        c.sc[it & 1]       = rz;
+        c.sc[5 + (it & 1)] = alpha;
+        c.sc[3]            = res;
+        c.flags[1]         = it - 1;
+        if (c.hist)
+          {
+            c.hist[2 * (it - 1)]     = alpha;
+            c.hist[2 * (it - 1) + 1] = beta;
+          }
+      }
+    const int64_t per = (c.n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = blockIdx.x * per, i1 = imin64(c.n, i0 + per);
+    double        srr = 0.0;
+    // (it == 1: the old p and s are not read)
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256)
+      {
+        const double pi = c.z[i] + (it == 1 ? 0.0 : beta * c.p[i]);
+        const double si = c.q[i] + (it == 1 ? 0.0 : beta * c.s[i]);
+        c.p[i]          = pi;
+        c.s[i]          = si;
+        c.x[i] += alpha * pi;
+        const double ri = c.r[i] - alpha * si;
+        c.r[i]          = ri;
+        srr += ri * ri;
+      }
+    srr = block_sum<256>(srr, s_red);
+    if (threadIdx.x == 0)
+      c.part_rr[blockIdx.x] = srr;
+  }
+
   // partials of a . b over [0,n)
   __global__ __launch_bounds__(256) void dot_partials(const double *__restrict__ a, const double *__restrict__ b,
                                                       int64_t n, double *part)
@@ -4605,47 +4724,29 @@ namespace mi
         // 105 tiles x 2 lanes, 64 quadrature points in chunks of QC; variants for A/B timing (mi_set_tuning "asm_variant")
         switch ((p.variant == 9 || !p.residual_only) ? p.variant : 0)
           {
-            case 0: // sum factorised (default): 4 waves per cell, 51 kB LDS
+            case 0: // sum factorised (default): 4 waves per cell, 41 kB LDS
               if (p.residual_only)
                 hipLaunchKernelGGL((assemble_q2sf<true, 0>), dim3(p.cell_count), dim3(64), 0, s, p);
               else
-                hipLaunchKernelGGL((assemble_q2sf<false, 0>), dim3(p.cell_count), dim3(256), 0, s, p);
+                hipLaunchKernelGGL((assemble_q2sf<false, 132>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 3: // A/B (round 5): pipelined contraction
-              hipLaunchKernelGGL((assemble_q2sf<false, 1>), dim3(p.cell_count), dim3(256), 0, s, p);
+            case 3: // A/B: the kernel of round 4 (81 fields, block table by wave 0 behind the residual, branching scatter)
+              hipLaunchKernelGGL((assemble_q2sf<false, 0>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 4: // A/B (round 5): wave 0's prologue at raised priority
-              hipLaunchKernelGGL((assemble_q2sf<false, 2>), dim3(p.cell_count), dim3(256), 0, s, p);
+            case 4: // A/B: default + pipelined contraction
+              hipLaunchKernelGGL((assemble_q2sf<false, 133>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 5: // A/B (round 5): both
-              hipLaunchKernelGGL((assemble_q2sf<false, 3>), dim3(p.cell_count), dim3(256), 0, s, p);
+            case 5: // A/B: default + prologue at raised priority
+              hipLaunchKernelGGL((assemble_q2sf<false, 134>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 6: // A/B (round 5): 45 fields, block table by wave 3, acceleration interpolated beside the contractions
+            case 6: // A/B: 45 fields + block table by wave 3 alone
               hipLaunchKernelGGL((assemble_q2sf<false, 4>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 7: // A/B (round 5): 6 + pipelined contraction
-              hipLaunchKernelGGL((assemble_q2sf<false, 5>), dim3(p.cell_count), dim3(256), 0, s, p);
+            case 7: // A/B: branch-free scatter alone
+              hipLaunchKernelGGL((assemble_q2sf<false, 128>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
-            case 169:
-              hipLaunchKernelGGL((assemble_q2sf<false, 69>), dim3(p.cell_count), dim3(256), 0, s, p);
-              break;
-            case 168:
-              hipLaunchKernelGGL((assemble_q2sf<false, 68>), dim3(p.cell_count), dim3(256), 0, s, p);
-              break;
-            case 108:
-              hipLaunchKernelGGL((assemble_q2sf<false, 8>), dim3(p.cell_count), dim3(256), 0, s, p);
-              break;
-            case 109:
-              hipLaunchKernelGGL((assemble_q2sf<false, 9>), dim3(p.cell_count), dim3(256), 0, s, p);
-              break;
-            case 116:
-              hipLaunchKernelGGL((assemble_q2sf<false, 16>), dim3(p.cell_count), dim3(256), 0, s, p);
-              break;
-            case 132:
-              hipLaunchKernelGGL((assemble_q2sf<false, 32>), dim3(p.cell_count), dim3(256), 0, s, p);
-              break;
-            case 140:
-              hipLaunchKernelGGL((assemble_q2sf<false, 40>), dim3(p.cell_count), dim3(256), 0, s, p);
+            case 8: // A/B: round 4 + pipelined contraction
+              hipLaunchKernelGGL((assemble_q2sf<false, 1>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
             case 9: // node-pair form (the default until round 2): 16.4 ms per assembly at 5 M DoFs
               launch_asm_sel<3, 2, 2, 256, 8>(p, s);
@@ -5065,6 +5166,10 @@ namespace mi
   void launch_cg_update_xr(const CgParams &c, int it, int grid, hipStream_t s)
   {
     hipLaunchKernelGGL(cg_update_xr, dim3(grid), dim3(256), 0, s, c, it);
+  }
+  void launch_cg_update_single(const CgParams &c, int it, int grid, hipStream_t s)
+  {
+    hipLaunchKernelGGL(cg_update_single, dim3(grid), dim3(256), 0, s, c, it);
   }
   void launch_cg_init_residual(const CgParams &c, const double *b, double *part_bb, int grid, hipStream_t s)
   {

@@ -311,9 +311,10 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *  cg_fused_dot         1 | 0                      p.q partials in the product's epilogue | separate reduction          MI_CG_FUSED_DOT
  *  small_cg             1 | 0                      matrices <= 1 MiB: whole Jacobi-PCG in one launch | three launches   MI_SMALL_CG
  *                                                  per iteration
- *  asm_variant          0 | 9 | 1,2 | 3,4,5 | 6-8  3D Q2 element kernel: sum factorised | node-pair form | its chunk    -
- *                                                  sizes | round-4 experiments (rotating prologue wave, L2 atomics:
- *                                                  no gain) | timing-only ablations
+ *  asm_variant          0 | 9 | 1,2 | 3 | 4-8      3D Q2 element kernel: sum factorised | node-pair form | its chunk    -
+ *                                                  sizes | the sum-factorised kernel as of round 4 | round-5 A/B
+ *                                                  combinations (pipelined contraction, prologue priority, parts of
+ *                                                  the default alone; profiles/r05/asm_ab_*.txt)
  *  mg_fuse              1 | 0 | 2                  smoother update fused into the product on small levels | never |     MI_MG_FUSE
  *                                                  always
  *  mg_scale_lmax_percent 10..400                   tests: spoil the eigenvalue estimates once                           -

@@ -248,6 +248,39 @@ def test_speculative_enqueue_does_not_change_the_solve(slabs):
         assert runs[0][5] <= runs[1][5] - 2 * solves  # and an all-reduce less for every iteration not polled
 
 
+@pytest.mark.parametrize("slabs", [1, 3])
+def test_single_reduction_pcg_is_the_same_solver(slabs):
+    """round 5: the multigrid-PCG in its single-reduction form (Chronopoulos & Gear; SURVEY.md sections 7, 8e): the product
+    is applied to z = M^-1 r, A p follows by recurrence, and r.z, z.Az, ||r||^2 share ONE all-reduce per iteration.  The
+    default on teams ("cg_single_reduction" -1); here forced on and off, on one slab and on three: the same Newton tables,
+    iteration counts within one per solve, the same states to the linear tolerance [REF nonlinear_elasticity.cc:1153-1191:
+    SolverCG's stopping rule is kept]; on a team at most one all-reduce per iteration plus one per polled iteration."""
+    runs = []
+    for single in (1, 0):
+        _, G = _setup(3, 2, (12, 12, 24), slabs, perturb_amp=0.0)
+        G.set_tuning("precond", 1)
+        G.set_tuning("cg_warm_start", 2)
+        G.set_tuning("cg_single_reduction", single)
+        _ramp_steps(G, 1, tol_lin=1e-10)
+        G.reset_timings()
+        rows, u, v, a = _ramp_steps(G, 3, tol_lin=1e-10)
+        runs.append((rows, u, v, a, G.get_tuning("count_scalar_allreduce_cg"), G.get_tuning("count_cg_solves"),
+                     G.get_tuning("count_cg_host_sync")))
+        G.close()
+    for (n1, a1, l1), (n0, a0, l0) in zip(runs[0][0], runs[1][0]):
+        assert (n1, a1) == (n0, a0) and abs(l1 - l0) <= n1  # within one iteration per solve
+    for k in (1, 2, 3):
+        assert np.abs(runs[0][k] - runs[1][k]).max() <= 1e-8 * np.abs(runs[1][k]).max()
+    its, solves = sum(r[2] for r in runs[0][0]), runs[0][5]
+    print("scalar all-reduces: single-reduction %d, standard %d over %d iterations in %d solves; host synchronisations %d / %d"
+          % (runs[0][4], runs[1][4], its, solves, runs[0][6], runs[1][6]))
+    if slabs > 1:
+        assert runs[0][4] <= its + 3 * solves   # one per iteration + per solve: the start vector's scaling, the polled ones
+        assert runs[0][4] < runs[1][4] - its // 2
+    else:  # (one slab: the calls are counted but nothing is exchanged)
+        assert runs[0][4] <= runs[1][4]
+
+
 @pytest.mark.parametrize("dim,p,reps,slabs", [(3, 1, (3, 3, 6), 3), (3, 2, (2, 2, 4), 2), (2, 3, (4, 6), 3)])
 def test_team_linear_model_steps(dim, p, reps, slabs):
     """the linear theta-model (linear_elasticity.cc:378-586) on a decomposed mesh: host assembly per slab, both

@@ -195,9 +195,11 @@ def test_spmv_matches_reference_matrix(dim, p, reps):
 
 
 def test_element_kernel_variants_agree():
-    """the 3D Q2 element kernels -- 0: the sum-factorised default (assemble_q2sf), 9: the node-pair kernel every other
-    element uses, 1 / 2: its quadrature chunk sizes -- assemble the same tangent and residual; so does the residual-only
-    pass of each family"""
+    """the 3D Q2 element kernels -- 0: the sum-factorised default (assemble_q2sf: 45 coefficient fields, branch-free scatter),
+    3: the same kernel as of round 4 (81 fields), 4-8: the A/B combinations of round 5 (pipelined contraction, prologue
+    priority, parts of the default alone), 9: the node-pair kernel every other element uses, 1 / 2: its quadrature chunk
+    sizes -- assemble the same tangent and residual; so does the residual-only pass of each family.  Constrained faces
+    and a perturbed mesh: the masking instantiation of the scatter runs beside the plain one."""
     reps = (3, 3, 2)
     nverts = int(np.prod([r + 1 for r in reps]))
     perturb = 0.02 * np.random.default_rng(3).standard_normal((nverts, 3))
@@ -209,7 +211,7 @@ def test_element_kernel_variants_agree():
     G.update_acceleration()
     x = rng.standard_normal(G.n)
     ref = None
-    for v in (0, 9, 1, 2):
+    for v in (0, 3, 4, 5, 6, 7, 8, 9, 1, 2):
         G.set_tuning("asm_variant", v)
         rn = G.assemble()
         y, r = G.spmv(x), G.get(M.V_RHS)
