@@ -652,6 +652,74 @@ namespace mi_detail
     return rc ? rc : team_halo_end(T);
   }
 
+  // Ghost planes -> owners, summed: the adjoint of the halo exchange.  A slab's top ghost planes (its up_recv range) are
+  // added to the planes the upper neighbour sends down in a halo exchange (its down_send range), its bottom ghost plane
+  // (down_recv) to the lower neighbour's up_send plane.  Used where slabs hold PARTIAL results on ghost planes: the
+  // restriction to / the state of a distributed multigrid level whose cuts do not coincide with the finer level's
+  // (mi_mg.cpp).  The owner adds what comes from below first, then what comes from above: a fixed order.
+  int team_halo_accumulate(Team &T, const std::function<double *(mi_ctx *)> &vec,
+                           const std::function<mi_ctx *(mi_ctx *)> &ctx_of)
+  {
+    ++T.n_halo;
+    if (T.size == 1)
+      return MI_OK;
+    const int D       = T.dim;
+    auto      slab_of = [&](mi_ctx *m) -> const mi::SlabPartition & { return (ctx_of ? ctx_of(m) : m)->slab; };
+    mi_ctx   *c       = T.members[0];
+    if (T.nccl)
+      {
+        const mi::SlabPartition &s = slab_of(c);
+        double                  *v = vec(c);
+        // what arrives: from below the lower neighbour's top ghost planes (as many as my down_send range), from above the
+        // upper neighbour's bottom ghost plane (as many as my up_send range)
+        const size_t n_lo = size_t(s.down_send_n) * D, n_hi = size_t(s.up_send_n) * D;
+        if (T.acc_cap < n_lo + n_hi)
+          {
+            if (T.d_acc)
+              hipFree(T.d_acc);
+            T.d_acc = nullptr;
+            HIPCHK(c, hipMalloc((void **)&T.d_acc, (n_lo + n_hi) * sizeof(double)));
+            T.acc_cap = n_lo + n_hi;
+          }
+        NCCLCHK(c, ncclGroupStart());
+        if (s.up_send_n)
+          {
+            NCCLCHK(c, ncclSend(v + s.up_recv * D, size_t(s.up_recv_n) * D, ncclDouble, s.rank + 1, TNCCL(T), T.stream));
+            NCCLCHK(c, ncclRecv(T.d_acc + n_lo, n_hi, ncclDouble, s.rank + 1, TNCCL(T), T.stream));
+          }
+        if (s.down_send_n)
+          {
+            NCCLCHK(c, ncclSend(v + s.down_recv * D, size_t(s.down_recv_n) * D, ncclDouble, s.rank - 1, TNCCL(T), T.stream));
+            NCCLCHK(c, ncclRecv(T.d_acc, n_lo, ncclDouble, s.rank - 1, TNCCL(T), T.stream));
+          }
+        NCCLCHK(c, ncclGroupEnd());
+        if (n_lo)
+          mi::launch_vec_add(v + s.down_send * D, T.d_acc, int64_t(n_lo), T.stream);
+        if (n_hi)
+          mi::launch_vec_add(v + s.up_send * D, T.d_acc + n_lo, int64_t(n_hi), T.stream);
+        return MI_OK;
+      }
+    // emulated slabs: for every slab first the contribution from below, then the one from above (the order of the RCCL branch)
+    for (size_t r = 0; r < T.members.size(); ++r)
+      {
+        mi_ctx                  *m = T.members[r];
+        const mi::SlabPartition &s = slab_of(m);
+        if (r > 0)
+          {
+            mi_ctx                  *b  = T.members[r - 1];
+            const mi::SlabPartition &sb = slab_of(b);
+            mi::launch_vec_add(vec(m) + s.down_send * D, vec(b) + sb.up_recv * D, int64_t(sb.up_recv_n) * D, T.stream);
+          }
+        if (r + 1 < T.members.size())
+          {
+            mi_ctx                  *a  = T.members[r + 1];
+            const mi::SlabPartition &sa = slab_of(a);
+            mi::launch_vec_add(vec(m) + s.up_send * D, vec(a) + sa.down_recv * D, int64_t(sa.down_recv_n) * D, T.stream);
+          }
+      }
+    return MI_OK;
+  }
+
   // sum over all slabs of a replicated vector (every slab holds all n entries): coarse multigrid residuals
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n)
   {
@@ -1248,7 +1316,8 @@ namespace mi_detail
     c->nm     = *nm;
     try
       {
-        c->slab = mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, T.size);
+        c->slab = mi::make_slab_partition(md->dim, md->degree, md->reps, md->lo, md->hi, md->face_role, rank, T.size,
+                                          T.cuts.empty() ? nullptr : T.cuts.data());
         const mi::SlabPartition &s = c->slab;
         const double *perturb = md->vertex_perturbation ? md->vertex_perturbation + s.vertex_offset * md->dim : nullptr;
         if (T.size == 1)
@@ -1412,7 +1481,7 @@ namespace mi_detail
       destroy_member(m);
     if (T->nccl)
       ncclCommDestroy(static_cast<ncclComm_t>(T->nccl));
-    for (void *p : {(void *)T->d_gbuf, (void *)T->d_ifbuf, (void *)T->d_sc_ptrs})
+    for (void *p : {(void *)T->d_gbuf, (void *)T->d_ifbuf, (void *)T->d_sc_ptrs, (void *)T->d_acc})
       if (p)
         hipFree(p);
     if (T->comm_stream)
@@ -2509,12 +2578,20 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_speculate = value;
       else if (k == "cg_single_reduction" && value >= -1 && value <= 1)
         m->cg_single_reduction = value;
+      else if (k == "mg_dist_nodes" && value >= -1) // before "precond" 1 builds the hierarchy
+        m->mg_dist_nodes = value;
       else if (k == "cg_speculate_margin" && value >= 0 && value <= 16)
         m->cg_speculate_margin = value;
       else if (k == "halo_skip" && (value == 0 || value == 1))
         c->team->halo_skip = value;
       else if (k == "mf_halo_overlap" && (value == 0 || value == 1))
         c->team->mf_overlap = value;
+      else if (k == "mg_restrict_fuse" && (value == 0 || value == 1))
+        {
+          const int rc = mg_set_restrict_fuse(m, value);
+          if (rc)
+            return fail(c, rc, "mg_restrict_fuse: no multigrid hierarchy (set \"precond\" 1 first)");
+        }
       else if (k == "mg_fuse" && value >= 0 && value <= 2)
         {
           const int rc = mg_set_fuse(m, value);
@@ -2569,6 +2646,8 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = m->cg_speculate;
   else if (k == "cg_single_reduction")
     *value = m->cg_single_reduction;
+  else if (k == "mg_distributed_levels") // levels of the multigrid hierarchy that are cut into slabs (0: no hierarchy)
+    *value = mg_distributed_levels(m);
   else if (k == "cg_single_reduction_active") // what cg_run will do with a multigrid-preconditioned solve
     *value = (m->cg_single_reduction == 1 || (m->cg_single_reduction < 0 && c->team->size > 1)) ? 1 : 0;
   else if (k == "cg_speculate_margin")

@@ -72,6 +72,9 @@ namespace mi_detail
                                                  // without an exchange; 0: every product exchanges (A/B, bitwise the same)
     int                   device   = 0;
     int                   dim      = 0;
+    std::vector<int>      cuts;                  // cell layers [cuts[r], cuts[r+1]) of slab r; empty: the balanced split
+    double               *d_acc    = nullptr;    // RCCL: receive scratch of team_halo_accumulate
+    size_t                acc_cap  = 0;
     int64_t               n_global = 0, nnodes_global = 0;
     std::vector<int64_t>  iface_global; // ascending global node ids
     std::vector<double>   iface_xyz;    // their coordinates
@@ -150,6 +153,8 @@ struct mi_ctx
   int       correct_face_F = 0; // tuning "correct_face_F": the Neumann pull-back with F at the face point (default: the reference's quirk)
   int       cg_r0_unassembled = 1; // A h of a predicted start vector by the matrix-free product where available ("cg_r0_operator")
   bool      unassembled_now = false; // (set around that one product)
+  int64_t   mg_dist_nodes = -1;       // multigrid: node count from which the first coarsened level of a team is distributed
+                                      // (-1: the default of mi_mg.cpp / MI_MG_DIST_NODES; read by mg_setup)
   int       cg_single_reduction = -1; // multigrid-PCG in the single-reduction form (one all-reduce per iteration): -1 = on
                                       // teams of several slabs, 0 never, 1 always (cg_run)
   int       cg_speculate_margin = 0;  // expected iterations left to polled ones: 0 = 2, or 1 for the single-reduction form on a team
@@ -259,6 +264,7 @@ namespace mi_detail
   void mg_scale_estimates(Team &T, double f); // tests: spoil the current estimates // build the level hierarchy of a slab (once)
   void mg_destroy(mi_ctx *c);
   int  mg_update(Team &T);  // re-assemble the coarse operators for the current state (team-wide)
+  int  mg_distributed_levels(const mi_ctx *c);
   int  mg_apply(Team &T);   // W_Z = V-cycle(W_R) on every slab of the team (team-wide, collective)
   bool mg_active(const mi_ctx *c);
   // team collectives (mi_ctx.cpp)
@@ -275,7 +281,11 @@ namespace mi_detail
                 bool ghosts_current = false);     // the ghost planes of x are up to date: no exchange (Team::halo_skip)
   int mg_set_storage(mi_ctx *c, int bits); // mi_mg.cpp: forwards to the level contexts
   int mg_set_fuse(mi_ctx *c, int fuse);
+  int mg_set_restrict_fuse(mi_ctx *c, int on);
   int team_allreduce_vectors(Team &T, const std::function<double *(mi_ctx *)> &vec, size_t n);
+  // the adjoint of team_halo: what every slab holds on its GHOST planes is added to the owner's copy of those planes
+  int team_halo_accumulate(Team &T, const std::function<double *(mi_ctx *)> &vec,
+                           const std::function<mi_ctx *(mi_ctx *)> &ctx_of);
 
 #define HIPCHK(ctx, call)                                                                                   \
   do                                                                                                        \

@@ -277,6 +277,9 @@ namespace mi
   void launch_copy_owned(double *y, const double *x, int64_t n, int64_t own0, int64_t own_n, hipStream_t s);
   void launch_lattice_interp(int dim, bool add, const LatticeParams &p, double *tgt, const double *src,
                              const uint8_t *cmask_tgt, hipStream_t s);
+  bool launch_lattice_restrict_first_step(int dim, const LatticeParams &p, double *coarse, const double *fine,
+                                          const uint8_t *cmask_coarse, double *x, double *d, const double *dinv_blk, double c2,
+                                          int64_t node0, int64_t nnodes, hipStream_t s);
   void launch_lattice_restrict(int dim, const LatticeParams &p, double *coarse, const double *fine,
                                const uint8_t *cmask_coarse, hipStream_t s);
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s);

@@ -3468,6 +3468,79 @@ namespace mi
     coarse[g]   = ((m >> c) & 1) ? 0.0 : acc;
   }
 
+  // The same restriction for 3 components with the FIRST step of the coarse level's Chebyshev smoother from a zero start in
+  // its epilogue (round 5: one launch per level and V-cycle fewer): b = R q as above, then on the nodes [node0, node0 + nnodes)
+  // d = x = c2 D^-1 b with the block-Jacobi diagonal -- the arithmetic of cheb_step_blk3 with c1 = 0 and no product, bit by
+  // bit.  192 threads = 64 nodes: a node's three components share their values through LDS.
+  template <int MAXR>
+  __global__ __launch_bounds__(192) void lattice_restrict_first_step3(LatticeParams p, double *coarse, const double *__restrict__ fine,
+                                                                      const uint8_t *__restrict__ cmask_coarse, double *x, double *d,
+                                                                      const double *__restrict__ dinv, double c2, int64_t node0,
+                                                                      int64_t nnodes)
+  {
+    constexpr int     D = 3;
+    __shared__ double s_b[192];
+    const int         ld = threadIdx.x;
+    const int64_t     g  = int64_t(blockIdx.x) * 192 + ld;
+    const bool        in = g < p.n_tgt * D;
+    const int64_t     I  = in ? g / D : 0;
+    const int         c  = int(g - I * D);
+    double            bv = 0.0;
+    if (in)
+      {
+        const int ci[3] = {int(I % p.nt[0]), int((I / p.nt[0]) % p.nt[1]), int(I / (int64_t(p.nt[0]) * p.nt[1]))};
+        int       cnt[3], fi[3][MAXR];
+        double    fw[3][MAXR];
+#pragma unroll
+        for (int dd = 0; dd < 3; ++dd)
+          {
+            const int b = p.rstart[dd][ci[dd]];
+            cnt[dd]     = p.rstart[dd][ci[dd] + 1] - b;
+#pragma unroll
+            for (int k = 0; k < MAXR; ++k)
+              {
+                fi[dd][k] = 0;
+                fw[dd][k] = 0.0;
+                if (k < cnt[dd])
+                  {
+                    fi[dd][k] = p.ri[dd][b + k];
+                    fw[dd][k] = p.rw[dd][b + k];
+                  }
+              }
+          }
+        double acc = 0.0;
+#pragma unroll
+        for (int kz = 0; kz < MAXR; ++kz)
+#pragma unroll
+          for (int ky = 0; ky < MAXR; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < MAXR; ++kx)
+              {
+                const double  wt = fw[0][kx] * (fw[1][ky] * fw[2][kz]);
+                const int64_t f  = fi[0][kx] + int64_t(p.ns[0]) * (fi[1][ky] + int64_t(p.ns[1]) * fi[2][kz]);
+                const double  v  = fine[f * D + c];
+                if (kx < cnt[0] && ky < cnt[1] && kz < cnt[2])
+                  acc += wt * v;
+              }
+        const int m = cmask_coarse ? cmask_coarse[I] : 0;
+        bv          = ((m >> c) & 1) ? 0.0 : acc;
+        coarse[g]   = bv;
+      }
+    s_b[ld] = bv;
+    __syncthreads();
+    if (!in || I < node0 || I >= node0 + nnodes)
+      return;
+    const int    r0 = (ld / 3) * 3;
+    const double a0 = dinv[g * 3], a1 = dinv[g * 3 + 1], a2 = dinv[g * 3 + 2];
+    double       s  = 0.0;
+    s += a0 * s_b[r0];
+    s += a1 * s_b[r0 + 1];
+    s += a2 * s_b[r0 + 2];
+    const double dn = 0.0 + c2 * s;
+    d[g]            = dn;
+    x[g]            = 0.0 + dn;
+  }
+
   // r = b - q (q = A x0), partials of ||r||^2, r.dinv.r and ||b||^2
   __global__ __launch_bounds__(256) void cg_init_residual(CgParams c, const double *__restrict__ b, double *part_bb)
   {
@@ -5157,6 +5230,23 @@ namespace mi
       hipLaunchKernelGGL((lattice_restrict<3>), dim3(grid), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
     else
       hipLaunchKernelGGL((lattice_restrict<2>), dim3(grid), dim3(256), 0, s, p, coarse, fine, cmask_coarse);
+  }
+
+  // restriction + first smoother step of the coarse level (3D, lists of at most 4); returns false where that form does not exist
+  bool launch_lattice_restrict_first_step(int dim, const LatticeParams &p, double *coarse, const double *fine,
+                                          const uint8_t *cmask_coarse, double *x, double *d, const double *dinv_blk, double c2,
+                                          int64_t node0, int64_t nnodes, hipStream_t s)
+  {
+    if (dim != 3 || p.rmax < 1 || p.rmax > 4 || (p.rmax == 4 && p.n_tgt > 100000))
+      return false;
+    const int g = int((p.n_tgt * 3 + 191) / 192);
+    if (p.rmax <= 3)
+      hipLaunchKernelGGL((lattice_restrict_first_step3<3>), dim3(g), dim3(192), 0, s, p, coarse, fine, cmask_coarse, x, d, dinv_blk, c2,
+                         node0, nnodes);
+    else
+      hipLaunchKernelGGL((lattice_restrict_first_step3<4>), dim3(g), dim3(192), 0, s, p, coarse, fine, cmask_coarse, x, d, dinv_blk, c2,
+                         node0, nnodes);
+    return true;
   }
 
   void launch_cg_update_p(const CgParams &c, int it, int grid, hipStream_t s)

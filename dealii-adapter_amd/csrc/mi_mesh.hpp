@@ -273,8 +273,11 @@ namespace mi
     int64_t vertex_offset = 0; // global vertex id of local vertex 0 (for the perturbation array)
   };
 
+  // cuts (optional, size + 1 entries, cuts[0] = 0, cuts[size] = reps[dim-1], strictly increasing): the cell layers of rank r
+  // are [cuts[r], cuts[r+1]) instead of the balanced split -- the first coarsened multigrid level of a team takes the cuts
+  // its finer level's cuts induce (mi_mg.cpp)
   inline SlabPartition make_slab_partition(int dim, int p, const int *reps, const double *lo, const double *hi,
-                                           const int *face_role, int rank, int size)
+                                           const int *face_role, int rank, int size, const int *cuts = nullptr)
   {
     if (size < 1 || rank < 0 || rank >= size)
       throw std::invalid_argument("bad rank/size");
@@ -289,6 +292,16 @@ namespace mi
     // balanced split of the layers
     s.z0 = int((int64_t(reps[zd]) * rank) / size);
     s.z1 = int((int64_t(reps[zd]) * (rank + 1)) / size);
+    if (cuts)
+      {
+        if (cuts[0] != 0 || cuts[size] != reps[zd])
+          throw std::invalid_argument("slab cuts do not span the cell layers");
+        for (int r = 0; r < size; ++r)
+          if (cuts[r + 1] <= cuts[r])
+            throw std::invalid_argument("a slab without cell layers");
+        s.z0 = cuts[rank];
+        s.z1 = cuts[rank + 1];
+      }
     const bool ghost_above = rank < size - 1;
     s.local_layers         = s.z1 - s.z0 + (ghost_above ? 1 : 0);
     s.plane_nodes          = 1;

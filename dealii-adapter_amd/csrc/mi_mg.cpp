@@ -59,9 +59,16 @@ namespace mi_detail
   {
     std::vector<MgLevel> levels;
     size_t n_dist        = 1;    // levels [0, n_dist) are distributed over the slabs of the team, the others replicated
+    size_t n_aligned     = 1;    // levels [0, n_aligned) share the cuts of the fine level (same cells): transfers between them
+                                 // stay inside a slab's local box.  A distributed level beyond (the first coarsened level of
+                                 // a team whose slabs are big enough, round 5) has the cuts the finer level's cuts induce, and
+                                 // its transfers go through partial results on ghost planes (team_halo_accumulate)
+    int64_t dist_nodes   = 65536; // distribute the first coarsened level when it has at least this many nodes (and every
+                                  // slab gets a cell layer of it); MI_MG_DIST_NODES / tuning "mg_dist_nodes"
     int    nu            = 3;    // Chebyshev degree of the pre- and post-smoother on the finest level
     int    nu_coarse     = 2;    // ... on the coarser levels
     int    nu_level1     = 0;    // ... on level 1 alone (0: nu_coarse; MI_MG_NU_L1, experiment of round 4)
+    int    restrict_fuse = 1;    // the restriction takes the first smoother step of the coarse level (MI_MG_RESTRICT_FUSE=0: never)
     int    fuse          = 1;    // Chebyshev update / residual in the epilogue of the product (one launch instead of two):
                                  // 0 never, 1 on the latency-bound levels (<= fuse_max_nodes), 2 on every level
     int64_t fuse_max_nodes = 100000;
@@ -84,6 +91,11 @@ namespace mi_detail
   static inline bool is_dist(const Team &T, size_t l)
   {
     return T.size > 1 && l < T.members[0]->mg->n_dist;
+  }
+
+  int mg_distributed_levels(const mi_ctx *c)
+  {
+    return c->mg ? (c->team->size > 1 ? int(c->mg->n_dist) : 0) : 0;
   }
 
   bool mg_active(const mi_ctx *c)
@@ -137,7 +149,12 @@ namespace mi_detail
     // the local planes [own_lo, own_hi).  Ownership keeps sums over slabs free of double counting:
     //   restriction lists only contain owned fine planes; the state transfer serves a coarse node only on the slab
     //   that owns its left source plane; prolongation fills every local fine plane (ghosts included).
-    int build_transfer(mi_ctx *fine, mi_ctx *coarse, MgTransfer &t, bool fine_is_slab)
+    // coarse_is_slab (with fine_is_slab): the coarse context is a slab of a distributed level whose cuts the fine level's
+    // cuts induce -- coarse indices along the cut direction are local to ITS box (global index minus its plane offset), a
+    // fine ghost plane whose prolongation would need a coarse plane outside that box is left alone (source index -1: the
+    // halo exchange that follows brings its value), restriction and state lists keep the ownership rule: what lands on
+    // a coarse GHOST plane is a partial result that team_halo_accumulate takes to its owner.
+    int build_transfer(mi_ctx *fine, mi_ctx *coarse, MgTransfer &t, bool fine_is_slab, bool coarse_is_slab = false)
     {
       const int dim = fine->dim, zd = dim - 1;
       int       rc;
@@ -160,16 +177,27 @@ namespace mi_detail
           const int  nf   = cut ? int(fine->slab.nnodes_global / fine->slab.plane_nodes) : nf_loc; // global extent
           const int  own_lo = cut ? int(fine->slab.own_begin / fine->slab.plane_nodes) : 0;
           const int  own_hi = cut ? int(fine->slab.own_end / fine->slab.plane_nodes) : nf_loc; // local, exclusive
+          // the coarse side: nc_g planes globally, this context holds planes [coff, coff + nc)
+          const bool ccut = cut && coarse_is_slab;
+          const int  coff = ccut ? int(coarse->slab.node_offset / coarse->slab.plane_nodes) : 0;
+          const int  nc_g = ccut ? int(coarse->slab.nnodes_global / coarse->slab.plane_nodes) : nc;
           std::vector<int32_t> gi0;
           std::vector<double>  gw;
-          interp_table(nf, nc, gi0, gw); // fine (global index) <- coarse
+          interp_table(nf, nc_g, gi0, gw); // fine (global index) <- coarse (global index)
           // prolongation: every local fine index
           std::vector<int32_t> i0((size_t)nf_loc);
           std::vector<double>  w((size_t)nf_loc);
           for (int k = 0; k < nf_loc; ++k)
             {
-              i0[size_t(k)] = gi0[size_t(k + zoff)];
+              i0[size_t(k)] = gi0[size_t(k + zoff)] - coff;
               w[size_t(k)]  = gw[size_t(k + zoff)];
+              if (ccut && (i0[size_t(k)] < 0 || i0[size_t(k)] + (w[size_t(k)] != 0.0 ? 1 : 0) >= nc))
+                {
+                  if (k >= own_lo && k < own_hi)
+                    return fail(fine, MI_EINVAL, "multigrid: prolongation of an owned plane needs a coarse plane outside the slab");
+                  i0[size_t(k)] = -1; // a ghost plane: left to the halo exchange
+                  w[size_t(k)]  = 0.0;
+                }
             }
           if ((rc = to_device(fine, t, i0, &t.prolong.i0[d])) || (rc = to_device(fine, t, w, &t.prolong.w[d])))
             return rc;
@@ -177,8 +205,10 @@ namespace mi_detail
           std::vector<std::vector<std::pair<int32_t, double>>> lists((size_t)nc);
           for (int k = own_lo; k < own_hi; ++k)
             {
-              const int    c0 = gi0[size_t(k + zoff)];
+              const int    c0 = gi0[size_t(k + zoff)] - coff;
               const double w1 = gw[size_t(k + zoff)];
+              if (c0 < 0 || c0 + (w1 != 0.0 ? 1 : 0) >= nc)
+                return fail(fine, MI_EINVAL, "multigrid: restriction of an owned plane lands outside the coarse slab");
               if (1.0 - w1 != 0.0)
                 lists[size_t(c0)].push_back({k, 1.0 - w1});
               if (w1 != 0.0)
@@ -200,17 +230,17 @@ namespace mi_detail
               (rc = to_device(fine, t, rw, &t.restrict_.rw[d])))
             return rc;
           // state transfer: coarse target <- fine source, served by the slab that owns the left source plane
-          interp_table(nc, nf, gi0, gw);
+          interp_table(nc_g, nf, gi0, gw);
           std::vector<int32_t> si0((size_t)nc);
           std::vector<double>  sw((size_t)nc);
           for (int tI = 0; tI < nc; ++tI)
             {
-              const int kl = gi0[size_t(tI)] - zoff; // local index of the left source plane
+              const int kl = gi0[size_t(tI + coff)] - zoff; // local index of the left source plane
               if (kl >= own_lo && kl < own_hi)
                 {
                   si0[size_t(tI)] = kl;
-                  sw[size_t(tI)]  = gw[size_t(tI)];
-                  if (kl + 1 >= nf_loc && gw[size_t(tI)] != 0.0)
+                  sw[size_t(tI)]  = gw[size_t(tI + coff)];
+                  if (kl + 1 >= nf_loc && gw[size_t(tI + coff)] != 0.0)
                     return fail(fine, MI_EINVAL, "multigrid: state transfer needs a plane outside the slab");
                 }
               else
@@ -385,6 +415,15 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // 1 (default): the restriction takes the first smoother step of the coarse level; 0: a launch of its own (A/B, same bits)
+  int mg_set_restrict_fuse(mi_ctx *c, int on)
+  {
+    if (!c->mg)
+      return MI_EINVAL;
+    c->mg->restrict_fuse = on;
+    return MI_OK;
+  }
+
   void mg_destroy(mi_ctx *c)
   {
     if (!c->mg)
@@ -442,6 +481,12 @@ namespace mi_detail
       mg->coarse_degree = std::max(1, atoi(e));
     if (const char *e = getenv("MI_MG_COARSE_RATIO"))
       mg->coarse_ratio = std::max(2.0, atof(e));
+    if (const char *e = getenv("MI_MG_RESTRICT_FUSE"))
+      mg->restrict_fuse = atoi(e) != 0;
+    if (const char *e = getenv("MI_MG_DIST_NODES"))
+      mg->dist_nodes = std::max<int64_t>(0, atoll(e));
+    if (c->mg_dist_nodes >= 0)
+      mg->dist_nodes = c->mg_dist_nodes;
     MgLevel L0;
     L0.ctx = c;
     mg->levels.push_back(L0);
@@ -451,10 +496,13 @@ namespace mi_detail
     const int dim = c->dim;
     for (int guard = 0; guard < 24; ++guard)
       {
+        const int prev_layers = reps[dim - 1];
+        bool      coarsened   = false;
         if (p > 1)
           p = 1;
         else
           {
+            coarsened = true;
             bool changed = false;
             for (int d = 0; d < dim; ++d)
               if (reps[d] > mg->coarsest_reps)
@@ -472,8 +520,32 @@ namespace mi_detail
         md.vertex_perturbation = nullptr;
         // the Q1 level on the same cells takes over the slab decomposition of the fine level
         const bool slab_level = c->team->size > 1 && mg->levels.size() == 1 && c->degree > 1;
+        // The first COARSENED level of a team (round 5): replicated on every slab while it is small -- a latency-bound level
+        // gains nothing from being cut --, distributed once it has dist_nodes nodes (weak scaling: the levels are levels of
+        // the GLOBAL box and grow with the team).  Its cuts are the ones the finer level's cuts induce: layer boundary
+        // floor(F[r] Lc / Lf) for the finer boundary F[r], so that every owned finer plane restricts into the slab's own box
+        // and every owned finer plane is prolongated from it (build_transfer, coarse_is_slab).
+        std::vector<int> induced;
+        if (c->team->size > 1 && coarsened && mg->levels.size() == mg->n_aligned && mg->n_dist == mg->n_aligned)
+          {
+            int64_t nodes = 1;
+            for (int d = 0; d < dim; ++d)
+              nodes *= int64_t(p) * reps[d] + 1;
+            const int size = c->team->size, Lf = prev_layers, Lc = reps[dim - 1];
+            bool      ok   = nodes >= mg->dist_nodes;
+            for (int r = 0; r <= size && ok; ++r)
+              {
+                const int F = c->team->cuts.empty() ? int((int64_t(Lf) * r) / size) : c->team->cuts[size_t(r)];
+                induced.push_back(r == size ? Lc : int((int64_t(F) * Lc) / Lf));
+                ok = r == 0 || induced[size_t(r)] > induced[size_t(r - 1)];
+              }
+            if (!ok)
+              induced.clear();
+          }
+        const bool dist_level = slab_level || !induced.empty();
         Team *T         = new Team;
-        T->size         = slab_level ? c->team->size : 1;
+        T->size         = dist_level ? c->team->size : 1;
+        T->cuts         = induced;
         T->device       = c->device;
         T->dim          = dim;
         T->stream       = c->stream;
@@ -483,9 +555,11 @@ namespace mi_detail
                                          // node ids never leave the library, so no permutation tables)
         T->iface_global = mi::global_interface_nodes(dim, p, md.reps, md.face_role);
         mi_ctx   *lc    = nullptr;
-        const int rc    = create_member(*T, &md, &c->mat, &c->nm, slab_level ? c->slab.rank : 0, &lc);
+        const int rc    = create_member(*T, &md, &c->mat, &c->nm, dist_level ? c->slab.rank : 0, &lc);
         if (slab_level)
-          mg->n_dist = 2;
+          mg->n_dist = mg->n_aligned = 2;
+        else if (!induced.empty())
+          mg->n_dist = mg->n_aligned + 1;
         T->members.push_back(lc);
         if (rc != MI_OK)
           {
@@ -506,9 +580,12 @@ namespace mi_detail
         HIPCHK(c, hipMemsetAsync(L.ws, 0, size_t(7) * size_t(L.ctx->n) * sizeof(double), c->stream));
         if (l + 1 < mg->levels.size())
           {
-            // slab -> replicated level: ownership-aware tables; slab -> slab and box -> box: plain local tables
-            const bool cut = c->team->size > 1 && l + 1 == mg->n_dist;
-            const int  rc  = build_transfer(L.ctx, mg->levels[l + 1].ctx, L.to_coarse, cut);
+            // slab -> replicated level and slab -> slab with induced cuts: ownership-aware tables; slab -> slab on the same
+            // cells and box -> box: plain local tables
+            const bool team  = c->team->size > 1;
+            const bool slabs = team && l + 1 >= mg->n_aligned && l + 1 < mg->n_dist;
+            const bool cut   = team && (l + 1 == mg->n_dist || slabs);
+            const int  rc    = build_transfer(L.ctx, mg->levels[l + 1].ctx, L.to_coarse, cut, slabs);
             if (rc)
               return rc;
           }
@@ -567,6 +644,15 @@ namespace mi_detail
                T, [l](mi_ctx *m) { return m->mg->levels[l].ctx->vec(MI_V_TOTAL_DISPLACEMENT); },
                size_t(c0->mg->levels[l].ctx->n))))
           return rc;
+        if (is_dist(T, l) && l >= c0->mg->n_aligned)
+          {
+            // induced cuts: a node was served by the slab that owns its left source plane -- possibly on one of that slab's
+            // ghost planes; to the owner, then to every ghost copy
+            auto u_of   = [l](mi_ctx *m) { return m->mg->levels[l].ctx->vec(MI_V_TOTAL_DISPLACEMENT); };
+            auto ctx_of = [l](mi_ctx *m) { return m->mg->levels[l].ctx; };
+            if ((rc = team_halo_accumulate(T, u_of, ctx_of)) || (rc = team_halo(T, u_of, ctx_of)))
+              return rc;
+          }
         for (mi_ctx *m : T.members)
           {
             MgLevel &C = m->mg->levels[l];
@@ -598,6 +684,11 @@ namespace mi_detail
 
   namespace
   {
+    bool L_restrict_lists_fit(const mi::LatticeParams &p)
+    {
+      return p.rmax >= 1 && p.rmax <= 4 && !(p.rmax == 4 && p.n_tgt > 100000);
+    }
+
     // whether level l runs its smoother steps and residual as fused products (see Multigrid::fuse)
     bool fuse_level(Team &T, size_t l)
     {
@@ -616,7 +707,8 @@ namespace mi_detail
     // k Chebyshev-Jacobi steps on level l for A x = b over [lmax/ratio, lmax]; zero_start: x = 0 on entry.
     // Level 0 runs on all slabs in lockstep (halo exchange of x before every SpMV, update on the owned dofs).
     // ghosts_current: the ghost planes of x are up to date, the first product needs no exchange
-    int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start, bool ghosts_current = false)
+    // first_done: the first step of a zero start (x = d = c2 D^-1 b) was taken by the restriction that produced b
+    int chebyshev(Team &T, size_t l, int k, double ratio, bool zero_start, bool ghosts_current = false, bool first_done = false)
     {
       const double b = T.members[0]->mg->levels[l].lmax, a = b / ratio;
       const double theta = 0.5 * (b + a), delta = 0.5 * (b - a), sigma = theta / delta;
@@ -626,6 +718,8 @@ namespace mi_detail
       for (int j = 0; j < k; ++j)
         {
           const bool first = (j == 0), skip_spmv = first && zero_start;
+          if (skip_spmv && first_done)
+            continue; // (the coefficients of step 0 leave no state behind)
           double c1, c2;
           if (first)
             {
@@ -757,13 +851,15 @@ namespace mi_detail
       return MI_OK;
     }
 
-    int smooth(Team &T, size_t l, int k, bool zero_start, bool ghosts_current = false)
+    int smooth(Team &T, size_t l, int k, bool zero_start, bool ghosts_current = false, bool first_done = false)
     {
       Multigrid &mg0 = *T.members[0]->mg;
-      return mg0.kind == 4 ? chebyshev4(T, l, k, zero_start) : chebyshev(T, l, k, mg0.smooth_ratio, zero_start, ghosts_current);
+      return mg0.kind == 4 ? chebyshev4(T, l, k, zero_start) :
+                             chebyshev(T, l, k, mg0.smooth_ratio, zero_start, ghosts_current, first_done);
     }
 
-    int vcycle(Team &T, size_t l)
+    // first_done: see chebyshev
+    int vcycle(Team &T, size_t l, bool first_done = false)
     {
       mi_ctx      *c0  = T.members[0];
       Multigrid   &mg0 = *c0->mg;
@@ -781,8 +877,9 @@ namespace mi_detail
           return MI_OK;
         }
       const bool dist_l = is_dist(T, l), dist_c = is_dist(T, l + 1);
+      const bool induced_c = dist_c && l + 1 >= mg0.n_aligned; // the coarser level has cuts of its own (see mg_setup)
       const int  nu     = (l == 0) ? mg0.nu : ((l == 1 && mg0.nu_level1 > 0) ? mg0.nu_level1 : mg0.nu_coarse);
-      if ((rc = smooth(T, l, nu, true)))
+      if ((rc = smooth(T, l, nu, true, false, first_done)))
         return rc;
       auto x_of   = [l](mi_ctx *m) { return m->mg->levels[l].x(); };
       auto q_of   = [l](mi_ctx *m) { return m->mg->levels[l].q(); };
@@ -822,18 +919,38 @@ namespace mi_detail
       // restriction.  distributed -> distributed (same slabs): the ghost planes of the residual come from the
       // neighbours, every owned coarse node then sums its complete fine neighbourhood.  distributed -> replicated:
       // every slab sums over its owned fine planes only and the partial sums are all-reduced.
-      if (dist_l && dist_c && (rc = team_halo(T, q_of, ctx_l)))
+      if (dist_l && dist_c && !induced_c && (rc = team_halo(T, q_of, ctx_l)))
         return rc;
+      // Where no collective completes the restricted residual afterwards, the restriction also takes the first step of the
+      // coarse level's smoother (x = d = c2 D^-1 b from a zero start: one launch per level fewer; "mg_restrict_fuse" 0: never)
+      bool fuse_first = mg0.restrict_fuse && mg0.kind == 1 && mg0.block && l + 2 < nl && !(dist_l && !dist_c) && !induced_c;
+      for (mi_ctx *m : T.members)
+        {
+          const MgLevel &C = m->mg->levels[l + 1];
+          fuse_first = fuse_first && C.ctx->dim == 3 && C.ctx->d_dinv_blk && C.lmax > 0.0 &&
+                       L_restrict_lists_fit(m->mg->levels[l].to_coarse.restrict_);
+        }
       for (mi_ctx *m : T.members)
         {
           MgLevel &L = m->mg->levels[l], &C = m->mg->levels[l + 1];
-          mi::launch_lattice_restrict(L.ctx->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, L.ctx->stream);
+          if (fuse_first)
+            {
+              const double bb = C.lmax, aa = bb / mg0.smooth_ratio, theta = 0.5 * (bb + aa);
+              mi::launch_lattice_restrict_first_step(L.ctx->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, C.x(), C.d(),
+                                                     C.ctx->d_dinv_blk, 1.0 / theta, C.ctx->own0 / C.ctx->dim,
+                                                     C.ctx->own_n / C.ctx->dim, L.ctx->stream);
+            }
+          else
+            mi::launch_lattice_restrict(L.ctx->dim, L.to_coarse.restrict_, C.b(), L.q(), C.ctx->d_cmask, L.ctx->stream);
         }
       if (dist_l && !dist_c &&
           (rc = team_allreduce_vectors(
              T, [l](mi_ctx *m) { return m->mg->levels[l + 1].b(); }, size_t(mg0.levels[l + 1].ctx->n))))
         return rc;
-      if ((rc = vcycle(T, l + 1)))
+      // induced cuts: every slab has restricted its OWNED planes; what landed on a coarse ghost plane belongs to a neighbour
+      if (induced_c && (rc = team_halo_accumulate(T, [l](mi_ctx *m) { return m->mg->levels[l + 1].b(); }, ctx_c)))
+        return rc;
+      if ((rc = vcycle(T, l + 1, fuse_first)))
         return rc;
       if (dist_c && (rc = team_halo(T, xc_of, ctx_c))) // prolongation reads the coarse ghost planes
         return rc;
@@ -847,7 +964,8 @@ namespace mi_detail
       // local planes -- from coarse values that are the same on both sides of a cut (replicated level, or ghost planes
       // exchanged two statements up) through tables that are functions of the global lattice index.  A ghost value is
       // therefore what its owner holds, bit by bit ("halo_skip" 0 exchanges anyway: test_halo_skip_is_bitwise_neutral).
-      return smooth(T, l, nu, false, dist_l);
+      // (induced cuts: a fine ghost plane may lie beyond the coarse slab's reach and was left alone -- exchange)
+      return smooth(T, l, nu, false, dist_l && !induced_c);
     }
   } // namespace
 

@@ -64,6 +64,8 @@ def scenario(G, M, kw, log):
             rc, info = G.newmark_step(tol_lin=1e-10, max_it_mult=2.0)
             assert rc == 0 and info.converged == 1, (rc, precond, step)
             its.append(int(info.lin_its_total))
+        if precond == 1:
+            out["mg_dist_levels"] = G.get_tuning("mg_distributed_levels")
         out["its%d" % precond] = its
         out["u%d" % precond] = G.get(M.V_U)
         out["if%d" % precond] = G.get_interface_displacement()
@@ -135,6 +137,7 @@ def main():
     rep["vs_single"] = {k: rel(results[0][k], single[k]) for k in keys}
     rep["vs_emulated"] = {k: rel(results[0][k], emu[k]) for k in keys}
     rep["rn"] = [results[r]["rn"] for r in range(world)] + [single["rn"], emu["rn"]]
+    rep["mg_dist_levels"] = [results[0]["mg_dist_levels"], emu["mg_dist_levels"], single["mg_dist_levels"]]
     print(json.dumps(rep))
 
 

@@ -74,13 +74,20 @@ def test_oracle_reproduces_config2_fixture():
         assert _rel(L.vec(O.L_V).reshape(-1, 3)[ids], g["cfg2_v"][s]) < 1e-11
 
 
-def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, slabs=1, cut_axis=0):
+def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, slabs=1, cut_axis=0, dist_nodes=None):
     g = _g()
     n = int(g[name + "_cells"])
     # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
     perturb = 0.08 / n * np.random.default_rng(77).standard_normal(((n + 1) ** 3, 3)) if distorted else None
-    G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb, slabs=slabs, cut_axis=cut_axis)
+    if dist_nodes is not None:  # read when the hierarchy is built (context creation above 75 k dofs)
+        os.environ["MI_MG_DIST_NODES"] = str(dist_nodes)
+    try:
+        G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb, slabs=slabs, cut_axis=cut_axis)
+    finally:
+        os.environ.pop("MI_MG_DIST_NODES", None)
     assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
+    if slabs > 1:  # levels cut into slabs: fine + Q1 on the same cells (+ the first coarsened level when forced / big enough)
+        assert G.get_tuning("mg_distributed_levels") == (2 if degree > 1 else 1) + (1 if dist_nodes == 0 else 0)
     G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
     ids = g[name + "_nodes"]
     for s, trac in enumerate(g[name + "_traction"]):
@@ -116,6 +123,16 @@ def test_gpu_24cube_block_decomposed_against_the_oracle(slabs, cut_axis):
     multigrid levels, halo exchanges and the matrix-free smoother on slabs against the oracle, not against the
     undecomposed run"""
     _nonlinear("blk24", 1e-8, 1e-6, 2, slabs=slabs, cut_axis=cut_axis)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slabs,cut_axis", [(3, 0), (4, 2), (2, 1)])
+def test_gpu_24cube_block_with_a_distributed_first_coarsened_level(slabs, cut_axis):
+    """round 5: past a size threshold the first COARSENED multigrid level (12^3 cells here, forced by MI_MG_DIST_NODES=0) is
+    cut into slabs of its own instead of being replicated on every slab: cuts induced by the finer level's, restriction and
+    coarse state through partial results on ghost planes (team_halo_accumulate), prolongation of the owned planes from
+    the slab's own box.  Same fixture, same tolerances as the replicated hierarchy: against the oracle."""
+    _nonlinear("blk24", 1e-8, 1e-6, 2, slabs=slabs, cut_axis=cut_axis, dist_nodes=0)
 
 
 @pytest.mark.gpu

@@ -217,6 +217,25 @@ def test_matrix_free_product_overlaps_its_halo_exchange_bitwise(reps, slabs, cut
         assert np.array_equal(runs[0][k], runs[1][k])
 
 
+@pytest.mark.parametrize("reps,slabs", [((10, 10, 24), 1), ((10, 10, 24), 3), ((24, 24, 48), 2)])
+def test_restriction_with_the_first_smoother_step_is_bitwise_neutral(reps, slabs):
+    """round 5: where no collective follows it, the restriction to a multigrid level takes the first step of that level's
+    Chebyshev smoother in its epilogue (x = d = c2 D^-1 b from a zero start): one launch per level and V-cycle fewer.
+    "mg_restrict_fuse" 0 runs the step as a launch of its own: the same bits -- Newton tables, iteration counts, states."""
+    runs = []
+    for fuse in (1, 0):
+        _, G = _setup(3, 2, reps, slabs, perturb_amp=0.0)
+        G.set_tuning("precond", 1)
+        G.set_tuning("cg_warm_start", 2)
+        G.set_tuning("mg_restrict_fuse", fuse)
+        rows, u, v, a = _ramp_steps(G, 2)
+        runs.append((rows, u, v, a))
+        G.close()
+    assert runs[0][0] == runs[1][0]
+    for k in (1, 2, 3):
+        assert np.array_equal(runs[0][k], runs[1][k])
+
+
 @pytest.mark.parametrize("slabs", [1, 3])
 def test_speculative_enqueue_does_not_change_the_solve(slabs):
     """round 4: from the second time step on, a multigrid-PCG solve enqueues the iterations the same solve needed one
