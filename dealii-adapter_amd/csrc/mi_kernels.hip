@@ -3840,6 +3840,74 @@ namespace mi
     x[i] = s;
   }
 
+  // The same for a coarsest level of up to DENSE_BIG_MAX dofs (round 5: 4^3 cells = 375 dofs in 3D, so that the hierarchy
+  // ends one level earlier): the dense array lives in device memory (1.1 MB: it stays in the L2), one workgroup of 1024
+  // threads, Gauss-Jordan without pivoting as above.  Runs when the coarse operators are rebuilt, not per V-cycle.
+  constexpr int DENSE_BIG_MAX = 384;
+  template <int D>
+  __global__ __launch_bounds__(1024) void dense_inverse_from_sell_big(SellParams prm, int n, double *A)
+  {
+    constexpr int DD = D * D;
+    const int     tid = threadIdx.x;
+    for (int i = tid; i < n * n; i += 1024)
+      A[i] = 0.0;
+    __syncthreads();
+    for (int r = tid; r < prm.nslices * 64; r += 1024) // (a row of the level matrix belongs to one thread: no races)
+      {
+        const int sl = r >> 6, lane = r & 63;
+        const int node = prm.perm[r];
+        if (node < 0)
+          continue;
+        const int     len = prm.len[sl], wx = prm.wx[sl];
+        const int64_t off = prm.off[sl];
+        for (int k = 0; k < len; ++k)
+          {
+            const int32_t c = prm.col[(off + k) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+              for (int j = 0; j < D; ++j)
+                A[(node * D + i) * n + c * D + j] +=
+                  prm.vals[(off * 64 + int64_t(k / wx) * (64 * wx) + lane * wx + k % wx) * DD + i * D + j];
+          }
+      }
+    __syncthreads();
+    for (int p = 0; p < n; ++p)
+      {
+        const double r = 1.0 / A[p * n + p];
+        __syncthreads();
+        for (int j = tid; j < n; j += 1024)
+          if (j != p)
+            A[p * n + j] *= r;
+        __syncthreads();
+        for (int e = tid; e < n * n; e += 1024)
+          {
+            const int i = e / n, j = e - i * n;
+            if (i != p && j != p)
+              A[e] -= A[i * n + p] * A[p * n + j];
+          }
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024)
+          A[i * n + p] = (i == p) ? r : -A[i * n + p] * r;
+        __syncthreads();
+      }
+  }
+  // x = Ainv b for n <= DENSE_BIG_MAX: 64 rows per workgroup, the inverse of a symmetric matrix read by columns
+  __global__ __launch_bounds__(64) void dense_apply_big(const double *__restrict__ inv, const double *__restrict__ b, double *x, int n)
+  {
+    __shared__ double s_b[DENSE_BIG_MAX];
+    for (int j = threadIdx.x; j < n; j += 64)
+      s_b[j] = b[j];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n)
+      return;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j)
+      s += inv[j * n + i] * s_b[j];
+    x[i] = s;
+  }
+
   // ------------------------------------------------------------------ banded Cholesky (direct solver for small systems)
   // "Solver type = Direct" (the reference's shipped default, parameters.prm:43: SparseDirectUMFPACK re-factorised in every
   // Newton iteration, nonlinear_elasticity.cc:1192-1200) for the sizes the reference's own geometries have: the tangent
@@ -5065,9 +5133,16 @@ namespace mi
   }
   int launch_dense_inverse_from_sell(int dim, const SellParams &p, int n, double *out, hipStream_t s)
   {
-    if (n > DENSE_MAX)
+    if (n > DENSE_BIG_MAX)
       return -1;
-    if (dim == 3)
+    if (n > DENSE_MAX)
+      {
+        if (dim == 3)
+          hipLaunchKernelGGL((dense_inverse_from_sell_big<3>), dim3(1), dim3(1024), 0, s, p, n, out);
+        else
+          hipLaunchKernelGGL((dense_inverse_from_sell_big<2>), dim3(1), dim3(1024), 0, s, p, n, out);
+      }
+    else if (dim == 3)
       hipLaunchKernelGGL((dense_inverse_from_sell<3>), dim3(1), dim3(256), 0, s, p, n, out);
     else
       hipLaunchKernelGGL((dense_inverse_from_sell<2>), dim3(1), dim3(256), 0, s, p, n, out);
@@ -5075,7 +5150,10 @@ namespace mi
   }
   void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s)
   {
-    hipLaunchKernelGGL(dense_apply, dim3(1), dim3(128), 0, s, inv, b, x, n);
+    if (n > DENSE_MAX)
+      hipLaunchKernelGGL(dense_apply_big, dim3((n + 63) / 64), dim3(64), 0, s, inv, b, x, n);
+    else
+      hipLaunchKernelGGL(dense_apply, dim3(1), dim3(128), 0, s, inv, b, x, n);
   }
 
   void launch_mf_gather_cheb(const MfParams &p, const double *b, const double *dinv, double *d, double *xio, double *yres,

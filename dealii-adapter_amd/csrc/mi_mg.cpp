@@ -77,10 +77,11 @@ namespace mi_detail
     int    kind          = 1;    // smoother polynomial: 1 = Chebyshev 1st kind on [lmax/ratio, lmax], 4 = 4th kind, optimised
     double smooth_ratio  = 20.0; // smoother targets [lmax/ratio, lmax]
     int    coarse_degree = 12;   // polynomial degree on the coarsest level
-    int    coarsest_reps = 2;    // stop coarsening once no direction has more cells than this (2^dim cells: 81 dofs in
-                                 // 3D, solved exactly by a dense inverse; MI_MG_COARSEST=1 + MI_MG_DENSE=0: round 1's
-                                 // one-cell level with a degree-12 polynomial)
-    int    dense         = 1;    // exact solve on the coarsest level when it has <= 96 dofs
+    int    coarsest_reps = 4;    // stop coarsening once no direction has more cells than this (round 5: 4^dim cells, 375 dofs
+                                 // in 3D, solved exactly by a dense inverse -- a level and its seven launches per V-cycle
+                                 // fewer than with 2^dim cells (MI_MG_COARSEST=2: rounds 2-4); MI_MG_COARSEST=1 + MI_MG_DENSE=0:
+                                 // round 1's one-cell level with a degree-12 polynomial)
+    int    dense         = 1;    // exact solve on the coarsest level when it has <= 384 dofs
     int    coarsen_factor = 2;   // cells per direction shrink by this factor from level to level
     double coarse_ratio  = 60.0;
     int    power_its     = 15;   // first estimate
@@ -590,7 +591,11 @@ namespace mi_detail
               return rc;
           }
       }
-    if (mg->dense && mg->levels.size() > 1 && mg->levels.back().ctx->n <= 96 && mg->levels.back().ctx->spmv_variant == 3)
+    // (a coarsest level that is cut into slabs -- a mesh of at most coarsest_reps cells per direction on a team -- has no
+    // matrix to invert on any one slab: it keeps the polynomial)
+    const bool coarsest_is_cut = c->team->size > 1 && mg->levels.size() - 1 < mg->n_dist;
+    if (mg->dense && mg->levels.size() > 1 && !coarsest_is_cut && mg->levels.back().ctx->n <= 384 &&
+        mg->levels.back().ctx->spmv_variant == 3)
       {
         MgLevel &L = mg->levels.back();
         HIPCHK(c, hipMalloc((void **)&L.dense_inv, size_t(L.ctx->n) * size_t(L.ctx->n) * sizeof(double)));
