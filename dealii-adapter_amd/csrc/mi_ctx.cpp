@@ -1467,6 +1467,8 @@ namespace mi_detail
       c->cg_warm_start = std::min(3, std::max(0, atoi(v)));
     if (const char *v = getenv("MI_SMALL_CG"))
       c->small_cg = atoi(v) != 0;
+    if (const char *v = getenv("MI_CG_SINGLE_REDUCTION"))
+      c->cg_single_reduction = std::min(1, std::max(-1, atoi(v)));
     return MI_OK;
   }
 
