@@ -3841,14 +3841,21 @@ namespace mi
   }
 
   // The same for a coarsest level of up to DENSE_BIG_MAX dofs (round 5: 4^3 cells = 375 dofs in 3D, so that the hierarchy
-  // ends one level earlier): the dense array lives in device memory (1.1 MB: it stays in the L2), one workgroup of 1024
-  // threads, Gauss-Jordan without pivoting as above.  Runs when the coarse operators are rebuilt, not per V-cycle.
-  constexpr int DENSE_BIG_MAX = 384;
+  // ends one level earlier).  The dense array (1.1 MB) lives in device memory and stays in the L2; ONE workgroup inverts it
+  // in place by BLOCKED Gauss-Jordan elimination without pivoting (the matrix is symmetric positive definite): per block
+  // of GJB pivots one pass over the array -- the scaled pivot rows R = D^-1 A[P,:] and the pivot columns C = A[:,P] are
+  // staged in LDS, every other entry takes a GJB-term update from them.  (An unblocked elimination makes one pass per
+  // pivot: 24 ms for 300 dofs, one CU's share of the L2 bandwidth; this form 24 passes in all.)  Runs when the coarse
+  // operators are rebuilt, not per V-cycle.
+  constexpr int DENSE_BIG_MAX = 384, GJB = 16;
   template <int D>
   __global__ __launch_bounds__(1024) void dense_inverse_from_sell_big(SellParams prm, int n, double *A)
   {
     constexpr int DD = D * D;
-    const int     tid = threadIdx.x;
+    __shared__ double sR[GJB][DENSE_BIG_MAX]; // D^-1 A[P, :]
+    __shared__ double sC[DENSE_BIG_MAX][GJB + 1]; // A[:, P]
+    __shared__ double sD[GJB][GJB + 1], sDi[GJB][GJB + 1];
+    const int tid = threadIdx.x;
     for (int i = tid; i < n * n; i += 1024)
       A[i] = 0.0;
     __syncthreads();
@@ -3872,40 +3879,120 @@ namespace mi
           }
       }
     __syncthreads();
-    for (int p = 0; p < n; ++p)
+    for (int p0 = 0; p0 < n; p0 += GJB)
       {
-        const double r = 1.0 / A[p * n + p];
+        const int nb = min(GJB, n - p0);
+        // the pivot block, its rows and its columns
+        for (int e = tid; e < GJB * GJB; e += 1024)
+          {
+            const int i = e / GJB, j = e - i * GJB;
+            sD[i][j]  = (i < nb && j < nb) ? A[(p0 + i) * n + p0 + j] : (i == j ? 1.0 : 0.0);
+            sDi[i][j] = (i == j) ? 1.0 : 0.0;
+          }
+        for (int e = tid; e < nb * n; e += 1024)
+          {
+            const int i = e / n, j = e - i * n;
+            sR[i][j] = A[(p0 + i) * n + j];
+            sC[j][i] = A[j * n + p0 + i];
+          }
         __syncthreads();
-        for (int j = tid; j < n; j += 1024)
-          if (j != p)
-            A[p * n + j] *= r;
+        // D^-1 by Gauss-Jordan on [D | I] in LDS: thread = (row, column of the augmented part), GJB pivots
+        for (int q = 0; q < GJB; ++q)
+          {
+            double piv = 0.0, mine = 0.0, minei = 0.0, rowq = 0.0, rowqi = 0.0, f = 0.0;
+            const int i = tid / GJB, j = tid - (tid / GJB) * GJB;
+            if (tid < GJB * GJB)
+              {
+                piv   = 1.0 / sD[q][q];
+                rowq  = sD[q][j] * piv;
+                rowqi = sDi[q][j] * piv;
+                f     = sD[i][q];
+                mine  = sD[i][j];
+                minei = sDi[i][j];
+              }
+            __syncthreads();
+            if (tid < GJB * GJB)
+              {
+                sD[i][j]  = (i == q) ? rowq : mine - f * rowq;
+                sDi[i][j] = (i == q) ? rowqi : minei - f * rowqi;
+              }
+            __syncthreads();
+          }
+        // R = D^-1 A[P, :]  (columns of the pivot block itself are not used below)
+        double rn[6]; // this thread's entries of the new R: e = tid + k * 1024 < GJB * DENSE_BIG_MAX = 6 * 1024
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          {
+            const int e = tid + k * 1024;
+            rn[k]       = 0.0;
+            if (e < nb * n)
+              {
+                const int i = e / n, j = e - i * n;
+                for (int m = 0; m < nb; ++m)
+                  rn[k] += sDi[i][m] * sR[m][j];
+              }
+          }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+          {
+            const int e = tid + k * 1024;
+            if (e < nb * n)
+              sR[e / n][e - (e / n) * n] = rn[k];
+          }
+        __syncthreads();
+        // one pass: every entry outside the pivot rows and columns; then the pivot rows, columns and block
         for (int e = tid; e < n * n; e += 1024)
           {
             const int i = e / n, j = e - i * n;
-            if (i != p && j != p)
-              A[e] -= A[i * n + p] * A[p * n + j];
+            const bool ip = i >= p0 && i < p0 + nb, jp = j >= p0 && j < p0 + nb;
+            double v;
+            if (ip && jp)
+              v = sDi[i - p0][j - p0];
+            else if (ip)
+              v = sR[i - p0][j];
+            else if (jp)
+              {
+                v = 0.0;
+                for (int m = 0; m < nb; ++m)
+                  v -= sC[i][m] * sDi[m][j - p0];
+              }
+            else
+              {
+                v = A[e];
+                for (int m = 0; m < nb; ++m)
+                  v -= sC[i][m] * sR[m][j];
+              }
+            A[e] = v;
           }
-        __syncthreads();
-        for (int i = tid; i < n; i += 1024)
-          A[i * n + p] = (i == p) ? r : -A[i * n + p] * r;
         __syncthreads();
       }
   }
-  // x = Ainv b for n <= DENSE_BIG_MAX: 64 rows per workgroup, the inverse of a symmetric matrix read by columns
-  __global__ __launch_bounds__(64) void dense_apply_big(const double *__restrict__ inv, const double *__restrict__ b, double *x, int n)
+  // x = Ainv b for n <= DENSE_BIG_MAX: 16 rows per workgroup, thread = (row, one of 16 chunks of the sum); the chunks are
+  // added in a fixed order.  The inverse of a symmetric matrix is read by columns.
+  __global__ __launch_bounds__(256) void dense_apply_big(const double *__restrict__ inv, const double *__restrict__ b, double *x, int n)
   {
     __shared__ double s_b[DENSE_BIG_MAX];
-    for (int j = threadIdx.x; j < n; j += 64)
+    __shared__ double s_p[16][17];
+    for (int j = threadIdx.x; j < n; j += 256)
       s_b[j] = b[j];
     __syncthreads();
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n)
-      return;
-    double s = 0.0;
-    for (int j = 0; j < n; ++j)
-      s += inv[j * n + i] * s_b[j];
-    x[i] = s;
+    const int c = threadIdx.x & 15, ch = threadIdx.x >> 4, i = blockIdx.x * 16 + c;
+    const int per = (n + 15) / 16, j0 = ch * per, j1 = min(n, j0 + per);
+    double    s = 0.0;
+    if (i < n)
+      for (int j = j0; j < j1; ++j)
+        s += inv[j * n + i] * s_b[j];
+    s_p[ch][c] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < n)
+      {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          t += s_p[k][threadIdx.x];
+        x[i] = t;
+      }
   }
 
   // ------------------------------------------------------------------ banded Cholesky (direct solver for small systems)
@@ -5151,7 +5238,7 @@ namespace mi
   void launch_dense_apply(const double *inv, const double *b, double *x, int n, hipStream_t s)
   {
     if (n > DENSE_MAX)
-      hipLaunchKernelGGL(dense_apply_big, dim3((n + 63) / 64), dim3(64), 0, s, inv, b, x, n);
+      hipLaunchKernelGGL(dense_apply_big, dim3((n + 15) / 16), dim3(256), 0, s, inv, b, x, n);
     else
       hipLaunchKernelGGL(dense_apply, dim3(1), dim3(128), 0, s, inv, b, x, n);
   }

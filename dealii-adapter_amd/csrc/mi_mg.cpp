@@ -504,15 +504,18 @@ namespace mi_detail
         else
           {
             coarsened = true;
-            bool changed = false;
+            // the hierarchy ends once NO direction has more than coarsest_reps cells; until then every direction with more
+            // than floor_reps cells is coarsened (a thin direction keeps coarsening beside the long ones: the cells of a
+            // plate-like mesh stay as isotropic as the coarsening factor allows)
+            bool more = false;
             for (int d = 0; d < dim; ++d)
-              if (reps[d] > mg->coarsest_reps)
-                {
-                  reps[d] = std::max(mg->coarsest_reps, (reps[d] + mg->coarsen_factor - 1) / mg->coarsen_factor);
-                  changed = true;
-                }
-            if (!changed)
+              more = more || reps[d] > mg->coarsest_reps;
+            if (!more)
               break;
+            const int floor_reps = std::min(2, mg->coarsest_reps);
+            for (int d = 0; d < dim; ++d)
+              if (reps[d] > floor_reps)
+                reps[d] = std::max(floor_reps, (reps[d] + mg->coarsen_factor - 1) / mg->coarsen_factor);
           }
         mi_mesh_desc md = g;
         md.degree       = p;
