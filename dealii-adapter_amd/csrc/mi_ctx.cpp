@@ -1099,8 +1099,10 @@ namespace mi_detail
     // the flag turns every later CG kernel into a no-op and the V-cycles in the queue are wasted work, nothing else:
     // iterates, iteration count and residual are those of the polled loop bit by bit.  Saves expected_its - 2 host
     // synchronisations and as many scalar all-reduces per solve (||r||^2 then travels with r.z).
-    // (margin: how many of the expected iterations are left to polled ones; a team pays an all-reduce for every poll)
-    const int64_t margin       = c0->cg_speculate_margin > 0 ? c0->cg_speculate_margin : ((single && dist) ? 1 : 2);
+    // (margin: how many of the expected iterations are left to polled ones.  One instead of two saves a poll and an
+    // all-reduce per solve and wastes a V-cycle + product whenever a solve ends one iteration early -- measured on 8
+    // emulated slabs: 0.2 halo exchanges per iteration more, i.e. a wasted V-cycle every third solve: two stays)
+    const int64_t margin       = c0->cg_speculate_margin > 0 ? c0->cg_speculate_margin : 2;
     const int64_t speculate_to = (use_mg && c0->cg_speculate) ? std::min<int64_t>(max_it - 1, int64_t(expected_its) - margin) : 0;
     if (single)
       {

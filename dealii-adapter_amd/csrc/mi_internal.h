@@ -157,7 +157,7 @@ struct mi_ctx
                                       // (-1: the default of mi_mg.cpp / MI_MG_DIST_NODES; read by mg_setup)
   int       cg_single_reduction = -1; // multigrid-PCG in the single-reduction form (one all-reduce per iteration): -1 = on
                                       // teams of several slabs, 0 never, 1 always (cg_run)
-  int       cg_speculate_margin = 0;  // expected iterations left to polled ones: 0 = 2, or 1 for the single-reduction form on a team
+  int       cg_speculate_margin = 0;  // expected iterations left to polled ones: 0 = the default (two)
   int       cg_speculate = 1; // multigrid-PCG: enqueue the iterations the previous step's same solve needed (minus two)
                               // without polling the convergence flag in between (tuning "cg_speculate" 0: poll every one)
   int       pred_its[NPRED] = {}; // iterations of the j-th solve of the previous time step (0: unknown)
