@@ -3960,8 +3960,15 @@ namespace mi
             else
               {
                 v = A[e];
-                for (int m = 0; m < nb; ++m)
-                  v -= sC[i][m] * sR[m][j];
+                if (nb == GJB) // (unrolled: the sixteen pairs of LDS reads travel together)
+                  {
+#pragma unroll
+                    for (int m = 0; m < GJB; ++m)
+                      v -= sC[i][m] * sR[m][j];
+                  }
+                else
+                  for (int m = 0; m < nb; ++m)
+                    v -= sC[i][m] * sR[m][j];
               }
             A[e] = v;
           }
