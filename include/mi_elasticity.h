@@ -302,6 +302,13 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  launch after the exchange (same bits)
  *  halo_skip            1 | 0                      no exchange before a product whose operand's ghost planes are        -
  *                                                  current (first post-smoothing step) | always exchange (same bits)
+ *  cg_single_reduction  -1 | 0 | 1                multigrid-PCG with ONE all-reduce per iteration (r.z, z.Az, ||r||^2;      MI_CG_SINGLE_REDUCTION
+ *                                                  Chronopoulos-Gear form): on teams of several slabs | never | always
+ *  cg_speculate_margin  0 | 1..16                  expected iterations of a solve left to polled ones (0: two)          -
+ *  mg_dist_nodes        -1 | n                     node count from which the first coarsened multigrid level of a team   MI_MG_DIST_NODES
+ *                                                  is cut into slabs of its own (default 65,536; set before "precond")
+ *  mg_restrict_fuse     1 | 0                      the restriction takes the coarse level's first smoother step | a     MI_MG_RESTRICT_FUSE
+ *                                                  launch of its own (same bits)
  *  KERNEL A/B (timing, tests)
  *  spmv_variant         3 | 1 | 4 | 11..14         sliced-ELL LDS-DMA product | row-per-wave cross-check | mi_spmv      MI_SPMV_VARIANT
  *                                                  through the unassembled form | streaming calibration kernels
@@ -326,12 +333,13 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  * and timing-only ablations of the two element kernels). */
 int mi_set_tuning(mi_ctx *ctx, const char *key, int value);
 /* Read back.  Counters since the last mi_reset_timings (what a solve costs in latency-bound events; counted on one slab
- * as well, where the collectives themselves are no-ops): "count_scalar_allreduce", "count_vector_allreduce",
- * "count_halo_exchange", "count_cg_host_sync", "count_cg_iterations", "count_cg_solves", "count_mg_refresh" (rebuilds of
+ * as well, where the collectives themselves are no-ops): "count_scalar_allreduce", "count_scalar_allreduce_cg" (those inside
+ * the linear solves), "count_vector_allreduce", "count_halo_exchange", "count_cg_host_sync", "count_cg_iterations", "count_cg_solves", "count_mg_refresh" (rebuilds of
  * the preconditioner's coarse operators).  State: "smoother_operator_active" (2 / 1: the smoother's fine-level products
  * are matrix-free / use the stored element tangents, 0: the assembled matrix), "precond", "spmv_variant",
  * "mf_single_launch", "cell_lattice", "mg_refresh_every", "cg_speculate", "halo_skip", "cut_axis" (1 / 2 / 3: the slabs
- * are cut along x / y / z, 0: not decomposed). */
+ * are cut along x / y / z, 0: not decomposed), "cg_single_reduction_active", "mg_distributed_levels" (multigrid levels cut
+ * into slabs; 0 on one slab). */
 int mi_get_tuning(mi_ctx *ctx, const char *key, int *value);
 int mi_reset_timings(mi_ctx *ctx);
 int mi_get_timings(mi_ctx *ctx, mi_timings *out);
