@@ -264,6 +264,10 @@ def main():
     ap.add_argument("--precond-storage", choices=["f64", "f32"], default="f64",
                     help="f32: the multigrid smoother multiplies with an fp32-rounded copy of the level matrices (the CG's "
                          "own product, residuals, vectors and all arithmetic stay fp64); opt-in, not the headline setting")
+    ap.add_argument("--smoother-precision", choices=["f64", "f32"], default="f64",
+                    help="f32 (opt-in, not the headline setting): the multigrid smoother's matrix-free fine-level products in fp32 "
+                         "arithmetic on fp32 point records; the CG, its product, residuals, vectors, assembly and every other kernel "
+                         "stay fp64 (a preconditioner-only change: same stopping rule, same converged solution)")
     ap.add_argument("--smoother-operator", choices=["matrix-free", "element", "assembled"], default="matrix-free",
                     help="what the multigrid smoother multiplies with on the fine level: the unassembled symmetric element "
                          "tangents (default where available: undecomposed 3D Q2 meshes; 27 %% fewer bytes per product) or the "
@@ -351,7 +355,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None):
+    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None, smoother_precision=None):
         """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
         nz = cells * parts if scaling == "weak" else cells
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
@@ -365,6 +369,8 @@ def main():
         G.set_tuning("precond", 1 if args.precond == "mg" else 0)
         if args.precond_storage == "f32":
             G.set_tuning("precond_storage", 32)
+        if (smoother_precision or args.smoother_precision) == "f32":
+            G.set_tuning("smoother_precision", 32)
 
         def one_step(k):
             ramp = min(1.0, (k + 1) / 10.0)
@@ -434,6 +440,7 @@ def main():
                                   "and Q1 levels of the fine cells distributed over the slabs, coarser levels replicated)"
                 if args.precond == "mg" else "Jacobi",
                 "preconditioner_storage": args.precond_storage,
+                "smoother_precision": args.smoother_precision,
                 "n_dofs": G.n,
                 "nnz": G.nnz,
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs cut along %s, emulated on one GPU"
@@ -644,6 +651,14 @@ def main():
             out["config"]["with_cg_start_" + other.replace("-", "_")] = {
                 "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"], "cg_iterations_per_step": S["cg_its"] / 3,
                 "cg_iterations_last_step": S["lin_its_last"], "steps": 3, "warmup": 1}
+            del S
+        if args.smoother_precision == "f64" and args.smoother_operator == "matrix-free" and n >= 24:
+            # opt-in A/B beside the headline: the smoother's matrix-free products in fp32 (preconditioner-only change)
+            S = measure(args.scaling, n, 3, 1, None, smoother_precision="f32")
+            out["config"]["with_smoother_precision_f32"] = {
+                "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"],
+                "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1,
+                "note": "opt-in, not the headline: fp32 arithmetic and records in the smoother's fine-level products only"}
             del S
         if args.cg_operator == "assembled" and n >= 24:
             # opt-in A/B beside the headline: the CG's own product on the element tangents too (no sliced-ELL copy);

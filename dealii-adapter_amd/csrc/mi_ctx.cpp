@@ -221,6 +221,7 @@ namespace mi_detail
     p.variant = c->asm_variant;
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
+    p.qrec32  = (c->d_qrec && c->smoother_precision == 32) ? c->d_qrec32 : nullptr;
     p.inverted = c->d_sc + SC_INVERTED;
     p.correct_face_F = c->correct_face_F;
     p.axmap    = 0;
@@ -403,6 +404,9 @@ namespace mi_detail
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
         mi::MfParams  f{};
         f.qrec    = c->d_qrec;
+        // opt-in "smoother_precision" 32: the SMOOTHER's products in fp32 arithmetic on fp32 records (residuals, start-vector
+        // products and mi_spmv keep the fp64 form)
+        f.qrec32  = (smoother && c->smoother_precision == 32 && c->qrec32_valid) ? c->d_qrec32 : nullptr;
         f.conn    = c->d_conn;
         f.first   = c->d_node_first;
         f.cmask   = c->d_cmask;
@@ -785,6 +789,7 @@ namespace mi_detail
         return MI_OK;
       }
     c->ke_valid = c->d_ke || c->d_qrec;
+    c->qrec32_valid = p.qrec32 != nullptr;
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -1291,7 +1296,7 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_lat_rows,
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_qrec32, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_lat_rows,
                     c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
                     c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
                     c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};
@@ -2602,6 +2607,14 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
           if (rc)
             return fail(c, rc, "mg_fuse needs the multigrid preconditioner");
         }
+      else if (k == "smoother_precision" && (value == 64 || value == 32))
+        {
+          // 32: the matrix-free smoother product in fp32 (3D Q2 meshes with point records; takes effect with the next tangent)
+          if (value == 32 && !m->d_qrec32 && m->dim == 3 && m->degree == 2)
+            HIPCHK(m, hipMalloc((void **)&m->d_qrec32, size_t(m->mesh.ncells) * mi::MF_NREC * 64 * sizeof(float)));
+          m->smoother_precision = value;
+          m->qrec32_valid       = false;
+        }
       else if (k == "precond_storage" && (value == 64 || value == 32))
         {
           const int rc = set_precond_storage(m, value);
@@ -2648,6 +2661,8 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = c->team->size > 1 ? c->team->amap.ext_axis[c->team->dim - 1] + 1 : 0;
   else if (k == "cg_speculate")
     *value = m->cg_speculate;
+  else if (k == "smoother_precision")
+    *value = m->smoother_precision;
   else if (k == "cg_single_reduction")
     *value = m->cg_single_reduction;
   else if (k == "mg_distributed_levels") // levels of the multigrid hierarchy that are cut into slabs (0: no hierarchy)

@@ -128,6 +128,9 @@ struct mi_ctx
   bool      want_dinv_blk = false;
   double   *d_ke = nullptr;   // unassembled element tangents (3D Q2, single slab): the multigrid smoother's operator
   uint32_t *d_node_first = nullptr; // per cell: bit a = first touch of local node a (see HostMesh::node_first)
+  float    *d_qrec32 = nullptr; // the same records in fp32 (opt-in "smoother_precision" 32)
+  int       smoother_precision = 64;
+  bool      qrec32_valid = false; // d_qrec32 belongs to the current tangent
   double   *d_qrec = nullptr; // quadrature-point records of the last tangent assembly (3D Q2): the matrix-free form of the smoother's operator
   double   *d_mf_yc = nullptr;        // matrix-free product in one launch: per-(cell, node) contributions ...
   int32_t  *d_mf_dst = nullptr;       // ... their slots [ncells][27] ...

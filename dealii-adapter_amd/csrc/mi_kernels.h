@@ -52,6 +52,7 @@ namespace mi
     int32_t         variant; // kernel variant for A/B timing
     int32_t         residual_only; // 1: residual without the tangent (Newton convergence check), same numbers
     double         *qrec;   // optional (3D Q2): the quadrature-point records the tangent is made of, [cell][MF_NREC][64] (see mf_spmv)
+    float          *qrec32; // optional: the same records rounded to fp32 (opt-in fp32 smoother product)
     int32_t         axmap;    // how the lattice lies over the box (mi::AxisMap): bits 2d..2d+1 the physical coordinate lattice
                               // direction d runs along, bit 6+d set if backwards; 0x24 = aligned.  Only the Neumann term needs it
                               // (the reference pairs face and cell quadrature points by their index in PHYSICAL order)
@@ -82,6 +83,7 @@ namespace mi
   struct MfParams
   {
     const double   *qrec;    // [ncells][MF_NREC][64]
+    const float    *qrec32;  // the same records rounded to fp32 (opt-in fp32 smoother product), or null
     const int32_t  *conn;    // [ncells][27] colour-sorted
     const uint32_t *first;   // as EbeParams
     const uint8_t  *cmask;   // [nnodes]
@@ -236,6 +238,7 @@ namespace mi
   // ev_start / ev_stop (optional): bracket exactly this launch (dispatch-level events, profiling)
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+  // (f32: the fp32 form -- production shape with p.qrec32 only, otherwise the fp64 kernel runs)
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);

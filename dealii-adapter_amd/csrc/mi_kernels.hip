@@ -95,16 +95,14 @@ namespace mi
   constexpr int Q_NINV = 25; // 1 / Q_SQN (0 if rho == 0)
   constexpr int Q_FACC = 26; // 3: rho JxW (acc - b)
 
-  __device__ __forceinline__ double det3x3(const double *A)
+  // (templated on the scalar type: double everywhere except the opt-in fp32 form of the matrix-free smoother product)
+  template <typename T>
+  __device__ __forceinline__ T det3x3(const T *A)
   {
     return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
   }
-  __device__ __forceinline__ void inv3x3r(const double *A, double r, double *B); // r = 1 / det A
-  __device__ __forceinline__ void inv3x3(const double *A, double det, double *B)
-  {
-    inv3x3r(A, 1.0 / det, B);
-  }
-  __device__ __forceinline__ void inv3x3r(const double *A, double r, double *B)
+  template <typename T>
+  __device__ __forceinline__ void inv3x3r(const T *A, T r, T *B) // r = 1 / det A
   {
     B[0]           = (A[4] * A[8] - A[5] * A[7]) * r;
     B[1]           = (A[2] * A[7] - A[1] * A[8]) * r;
@@ -115,6 +113,10 @@ namespace mi
     B[6]           = (A[3] * A[7] - A[4] * A[6]) * r;
     B[7]           = (A[1] * A[6] - A[0] * A[7]) * r;
     B[8]           = (A[0] * A[4] - A[1] * A[3]) * r;
+  }
+  __device__ __forceinline__ void inv3x3(const double *A, double det, double *B)
+  {
+    inv3x3r(A, 1.0 / det, B);
   }
 
   // 3x3 (row-major, embedded: for DIM==2 the [2][2] entry is 1 and off entries 0) geometry Jacobian of the
@@ -196,30 +198,29 @@ namespace mi
   //   c_II = kappa J^2 - 2/d^2 tr(tau_bar),  c_S = -kappa (J^2-1) + 2/d tr(tau_bar)
   // gu is the 3x3-embedded displacement gradient w.r.t. reference coordinates.
   // the response from F, J = det F, Jm = J^(-2/d) and rJ = 1/J (what the matrix-free product keeps per point, see mf_spmv)
-  template <int DIM>
-  __device__ __forceinline__ void neo_hooke_from_F(const double *F, double J, double Jm, double rJ, double mu, double kappa,
-                                                   double *Finv, double *tau, double *tiso, double &cII, double &cS)
+  template <int DIM, typename T>
+  __device__ __forceinline__ void neo_hooke_from_F(const T *F, T J, T Jm, T rJ, T mu, T kappa, T *Finv, T *tau, T *tiso, T &cII, T &cS)
   {
     inv3x3r(F, rJ, Finv);
-    double       b[6];                                                  // xx yy zz xy xz yz
-    b[0]            = F[0] * F[0] + F[1] * F[1] + (DIM == 3 ? F[2] * F[2] : 0.0);
-    b[1]            = F[3] * F[3] + F[4] * F[4] + (DIM == 3 ? F[5] * F[5] : 0.0);
-    b[2]            = (DIM == 3) ? F[6] * F[6] + F[7] * F[7] + F[8] * F[8] : 0.0;
-    b[3]            = F[0] * F[3] + F[1] * F[4] + (DIM == 3 ? F[2] * F[5] : 0.0);
-    b[4]            = (DIM == 3) ? F[0] * F[6] + F[1] * F[7] + F[2] * F[8] : 0.0;
-    b[5]            = (DIM == 3) ? F[3] * F[6] + F[4] * F[7] + F[5] * F[8] : 0.0;
-    const double s  = mu * Jm;
-    const double tr = s * (b[0] + b[1] + b[2]);
+    T       b[6];                                                  // xx yy zz xy xz yz
+    b[0]            = F[0] * F[0] + F[1] * F[1] + (DIM == 3 ? F[2] * F[2] : T(0.0));
+    b[1]            = F[3] * F[3] + F[4] * F[4] + (DIM == 3 ? F[5] * F[5] : T(0.0));
+    b[2]            = (DIM == 3) ? F[6] * F[6] + F[7] * F[7] + F[8] * F[8] : T(0.0);
+    b[3]            = F[0] * F[3] + F[1] * F[4] + (DIM == 3 ? F[2] * F[5] : T(0.0));
+    b[4]            = (DIM == 3) ? F[0] * F[6] + F[1] * F[7] + F[2] * F[8] : T(0.0);
+    b[5]            = (DIM == 3) ? F[3] * F[6] + F[4] * F[7] + F[5] * F[8] : T(0.0);
+    const T s  = mu * Jm;
+    const T tr = s * (b[0] + b[1] + b[2]);
 #pragma unroll
     for (int k = 0; k < 6; ++k)
       tiso[k] = s * b[k];
-    const double trd = tr * (1.0 / DIM); // (a product, not tr / DIM: an IEEE division costs the matrix-free product ten
-                                         // instructions per point for the last bit of a number the oracle agrees with to 1e-12)
+    const T trd = tr * T(1.0 / DIM); // (a product, not tr / DIM: an IEEE division costs the matrix-free product ten
+                                     // instructions per point for the last bit of a number the oracle agrees with to 1e-12)
     tiso[0] -= trd;
     tiso[1] -= trd;
     if constexpr (DIM == 3)
       tiso[2] -= trd;
-    const double pv = 0.5 * kappa * (J * J - 1.0);
+    const T pv = T(0.5) * kappa * (J * J - T(1.0));
 #pragma unroll
     for (int k = 0; k < 6; ++k)
       tau[k] = tiso[k];
@@ -227,8 +228,8 @@ namespace mi
     tau[1] += pv;
     if constexpr (DIM == 3)
       tau[2] += pv;
-    cII = kappa * J * J - (2.0 / (DIM * DIM)) * tr;
-    cS  = -kappa * (J * J - 1.0) + (2.0 / DIM) * tr;
+    cII = kappa * J * J - T(2.0 / (DIM * DIM)) * tr;
+    cS  = -kappa * (J * J - T(1.0)) + T(2.0 / DIM) * tr;
   }
   template <int DIM>
   __device__ __forceinline__ void neo_hooke_qp(const double *gu, double mu, double kappa, double *Finv, double &J,
@@ -1020,6 +1021,15 @@ namespace mi
                   g[k * 64] = Fq[k];
                 g[9 * 64]  = Jmq;
                 g[10 * 64] = rJq;
+                if (prm.qrec32) // (opt-in fp32 smoother product)
+                  {
+                    float *__restrict__ g32 = prm.qrec32 + cell * int64_t(MF_NREC * 64) + lane;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k)
+                      g32[k * 64] = float(Fq[k]);
+                    g32[9 * 64]  = float(Jmq);
+                    g32[10 * 64] = float(rJq);
+                  }
               }
         }
         MI_STAMPW(9, 0); // material
@@ -2416,10 +2426,15 @@ namespace mi
   // order as the colour-by-colour update, i.e. the same bits, in 2 launches instead of 8.
   // DBG (diagnostic instantiations, never in production): bit 0 stage stamps; timing-only ablations: bit 1 no result
   // stores, bit 2 every cell reads the records of cell 0 (cache hits), bit 3 every cell gathers the x of cell 0's nodes
-  template <bool BOX, bool SLOTS, bool LAT, int DBG = 0, int OCC = 4>
+  // T (round 5, opt-in "smoother_precision" 32): the scalar type of the arithmetic and of the records.  float: the records
+  // come from prm.qrec32, x is converted on the way in, the results on the way out; vectors, slots and every other kernel
+  // stay fp64 -- a preconditioner-only change (the production shape only).
+  template <bool BOX, bool SLOTS, bool LAT, int DBG = 0, int OCC = 4, typename T = double>
   __global__ __launch_bounds__(64, OCC) void mf_spmv(MfParams prm, int64_t cell0) // OCC = 5 (96 VGPRs) spills 8 registers: A/B MI_MF_OCC=5
   {
+    static_assert(std::is_same<T, double>::value || (BOX && SLOTS && LAT && DBG == 0), "fp32 form: production shape only");
     constexpr bool STAMP = (DBG & 1) != 0;
+    const T        mu_t = T(prm.mu), kappa_t = T(prm.kappa), mass_t = T(prm.mass);
     constexpr int NPC = 27;
     // LDS (per cell, 7.9 kB): s0 = x (81 at AO) and the (i,j)-contracted
     // planes B (3 x 9 x 20 at 0; plane stride 20 and the lane order (c*3+k)*4 + qx keep their stores conflict free), then
@@ -2427,11 +2442,11 @@ namespace mi
     // half-wave in I3, read different banks), then the qz-contracted planes C IN PLACE of the Q entries their lane
     // consumed; sE = the qy-contracted lines E (2 x 108).
     constexpr int PS = 20, PW = 9 * PS, AO = 552;
-    __shared__ double s0[768];
-    __shared__ double sE[216];
+    __shared__ T s0[768];
+    __shared__ T sE[216];
     __shared__ int    s_conn[NPC], s_cm[NPC];
     // reads go through volatile pointers: single ds_read_b64 (2 LDS cycles per wave) instead of merged ds_read2_b64 (8)
-    typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
+    typedef const volatile __attribute__((address_space(3))) T *lds_cvp;
     const lds_cvp v0 = (lds_cvp)s0, vE = (lds_cvp)sE;
     const int     lane = threadIdx.x;
     // workgroups go round robin over the 8 XCDs: give each XCD a contiguous run of cells, so that the x / y lines shared
@@ -2473,7 +2488,7 @@ namespace mi
     // wave and the records follow it (the memory counter retires loads in order: what is needed first is asked first);
     // otherwise the records go first and the gather waits for the connectivity
     int32_t node_l = 0, cm_l = 0; // lane < 27: this lane's node and its constraint bits
-    double  xg[3]  = {0.0, 0.0, 0.0};
+    T  xg[3]  = {0.0, 0.0, 0.0};
     int32_t node0  = 0;
     if constexpr (LAT)
       {
@@ -2489,15 +2504,16 @@ namespace mi
           }
       }
     // the cell's records: consumed after the gradient passes
-    double rec[MF_NREC];
+    T rec[MF_NREC];
     {
-      const double *__restrict__ rp = prm.qrec + ((DBG & 4) ? int64_t(0) : cell) * int64_t(MF_NREC * 64) + lane;
+      const T *__restrict__ rp = (std::is_same<T, float>::value ? reinterpret_cast<const T *>(prm.qrec32) : reinterpret_cast<const T *>(prm.qrec)) +
+                                 ((DBG & 4) ? int64_t(0) : cell) * int64_t(MF_NREC * 64) + lane;
 #pragma unroll
       for (int f = 0; f < MF_NREC; ++f)
         rec[f] = __builtin_nontemporal_load(&rp[f * 64]);
     }
     // 1D tables: S[q][a] = N_a(x_q), D[q][a] = N_a'(x_q) (uniform -> scalar registers)
-    double S[4][3], D[4][3];
+    T S[4][3], D[4][3];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -2507,14 +2523,14 @@ namespace mi
           D[q][a] = prm.tab1d[12 + q * 3 + a];
         }
     const int qz = lane >> 4, q16 = lane & 15;
-    double    Sz[3], Dz[3]; // this lane's rows of the tables for the last gradient pass
+    T    Sz[3], Dz[3]; // this lane's rows of the tables for the last gradient pass
 #pragma unroll
     for (int k = 0; k < 3; ++k)
       {
         Sz[k] = prm.tab1d[qz * 3 + k];
         Dz[k] = prm.tab1d[12 + qz * 3 + k];
       }
-    double Sx[3], Dx[3]; // rows qx = lane & 3 of the tables for the fused first gradient stage (lane = (c*3+k)*4 + qx)
+    T Sx[3], Dx[3]; // rows qx = lane & 3 of the tables for the fused first gradient stage (lane = (c*3+k)*4 + qx)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       {
@@ -2522,8 +2538,8 @@ namespace mi
         Dx[i] = prm.tab1d[12 + (lane & 3) * 3 + i];
       }
     // this lane's quadrature weight and (general geometry) unit-cell point: tab1d holds qw[4] at 24 and qx[4] at 28
-    const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
-    double       xiq[3];
+    const T wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
+    T       xiq[3];
     if constexpr (!BOX)
       {
         xiq[0] = prm.tab1d[28 + (lane & 3)];
@@ -2531,7 +2547,7 @@ namespace mi
         xiq[2] = prm.tab1d[28 + qz];
       }
     // the cell's geometry (BOX): 1/hx, 1/hy, 1/hz, hx hy hz -- uniform, scalar loads
-    double cbox[4] = {0.0, 0.0, 0.0, 0.0};
+    T cbox[4] = {0.0, 0.0, 0.0, 0.0};
     if constexpr (BOX)
       {
         const double *__restrict__ cb = prm.cellbox + cell * 4;
@@ -2556,12 +2572,12 @@ namespace mi
         s_cm[lane]   = cm_l;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
-          s0[AO + c * NPC + lane] = ((cm_l >> c) & 1) ? 0.0 : xg[c]; // (behind the planes B: they can land while x is read)
+          s0[AO + c * NPC + lane] = ((cm_l >> c) & 1) ? T(0.0) : xg[c]; // (behind the planes B: they can land while x is read)
       }
     // the entries of y this lane will update at the very end (lane = line (c,k,j), its three nodes i): read now, the
     // colouring keeps every other cell of this launch away from them
     const int lc = lane / 9, lkj = lane - 9 * lc;
-    double    yold[3];
+    double yold[3];
     int32_t   ydst[3];
     if (lane < 27)
       {
@@ -2585,12 +2601,12 @@ namespace mi
     const int pck = lane >> 2, pqx = lane & 3; // plane index c*3+k and qx of this lane in E12 / I2
     if (lane < 36)
       {
-        double bds[4], bsd[4], bss[4];
-        double as[3], ad[3];
+        T bds[4], bsd[4], bss[4];
+        T as[3], ad[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           {
-            const double x0 = v0[AO + pck * 9 + j * 3], x1 = v0[AO + pck * 9 + j * 3 + 1], x2 = v0[AO + pck * 9 + j * 3 + 2];
+            const T x0 = v0[AO + pck * 9 + j * 3], x1 = v0[AO + pck * 9 + j * 3 + 1], x2 = v0[AO + pck * 9 + j * 3 + 2];
             as[j] = Sx[0] * x0 + Sx[1] * x1 + Sx[2] * x2;
             ad[j] = Dx[0] * x0 + Dx[1] * x1 + Dx[2] * x2;
           }
@@ -2612,7 +2628,7 @@ namespace mi
       }
     __syncthreads();
     // ---- E3: contract k.  lane = quadrature point; H[c][l] = d x_c / d xi_l, V[c] = x_c
-    double H[3][3], V[3];
+    T H[3][3], V[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       {
@@ -2621,7 +2637,7 @@ namespace mi
         for (int k = 0; k < 3; ++k)
           {
             const int    o   = (c * 3 + k) * PS + q16;
-            const double bds = v0[o], bsd = v0[o + PW], bss = v0[o + 2 * PW];
+            const T bds = v0[o], bsd = v0[o + PW], bss = v0[o + 2 * PW];
             H[c][0]          = fma(Sz[k], bds, H[c][0]);
             H[c][1]          = fma(Sz[k], bsd, H[c][1]);
             H[c][2]          = fma(Dz[k], bss, H[c][2]);
@@ -2632,21 +2648,21 @@ namespace mi
     MF_STAMP(2); // gradients at the points
     if constexpr (BOX) // the mass term first: it needs only the cell's volume, and V dies before the tensor algebra
       {
-        const double wm = prm.mass * cbox[3] * wq;
+        const T wm = mass_t * cbox[3] * wq;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           s0[(i * 4 + 3) * 64 + (lane ^ ((i & 1) << 4))] = wm * V[i];
       }
     // ---- quadrature point: Q = JxW S M^T
     {
-      double M[9], tau[6], w, wcII, cs2;
+      T M[9], tau[6], w, wcII, cs2;
       {
-        const double *F = rec;
-        double        Finv[9], tiso[6], cII, cS, Ji[9], detJ;
-        neo_hooke_from_F<3>(F, det3x3(F), rec[9], rec[10], prm.mu, prm.kappa, Finv, tau, tiso, cII, cS);
+        const T *F = rec;
+        T        Finv[9], tiso[6], cII, cS, Ji[9], detJ;
+        neo_hooke_from_F<3>(F, det3x3(F), rec[9], rec[10], mu_t, kappa_t, Finv, tau, tiso, cII, cS);
         if constexpr (BOX)
           {
-            const double rx = cbox[0], ry = cbox[1], rz = cbox[2];
+            const T rx = cbox[0], ry = cbox[1], rz = cbox[2];
             detJ            = cbox[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k)
@@ -2659,7 +2675,7 @@ namespace mi
         else
           {
             const double *__restrict__ cv = prm.cverts + cell * 24; // uniform: scalar loads
-            double verts[24], Jm[9];
+            T verts[24], Jm[9];
 #pragma unroll
             for (int k = 0; k < 24; ++k)
               verts[k] = cv[k];
@@ -2674,33 +2690,33 @@ namespace mi
           }
         w    = detJ * wq;
         wcII = w * cII;
-        cs2  = 0.5 * cS;
+        cs2  = T(0.5) * cS;
       }
-      double        h[3][3];
+      T        h[3][3];
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           h[j][k] = H[j][0] * M[k] + H[j][1] * M[3 + k] + H[j][2] * M[6 + k];
-      const double pv  = (tau[0] + tau[1] + tau[2]) * (1.0 / 3.0); // tau_iso = dev tau
-      const double ti0 = tau[0] - pv, ti1 = tau[1] - pv, ti2 = tau[2] - pv;
-      const double trh = h[0][0] + h[1][1] + h[2][2];
-      const double th  = ti0 * h[0][0] + ti1 * h[1][1] + ti2 * h[2][2] + tau[3] * (h[0][1] + h[1][0]) +
+      const T pv  = (tau[0] + tau[1] + tau[2]) * T(1.0 / 3.0); // tau_iso = dev tau
+      const T ti0 = tau[0] - pv, ti1 = tau[1] - pv, ti2 = tau[2] - pv;
+      const T trh = h[0][0] + h[1][1] + h[2][2];
+      const T th  = ti0 * h[0][0] + ti1 * h[1][1] + ti2 * h[2][2] + tau[3] * (h[0][1] + h[1][0]) +
                         tau[4] * (h[0][2] + h[2][0]) + tau[5] * (h[1][2] + h[2][1]);
-      const double aI = wcII * trh - (2.0 / 3.0) * w * th;
-      const double m3 = -(2.0 / 3.0) * trh;
-      const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
-      const double Ti[3][3] = {{ti0, tau[3], tau[4]}, {tau[3], ti1, tau[5]}, {tau[4], tau[5], ti2}};
-      double       Sm[3][3];
+      const T aI = wcII * trh - T(2.0 / 3.0) * w * th;
+      const T m3 = T(-(2.0 / 3.0)) * trh;
+      const T Tt[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
+      const T Ti[3][3] = {{ti0, tau[3], tau[4]}, {tau[3], ti1, tau[5]}, {tau[4], tau[5], ti2}};
+      T       Sm[3][3];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           {
-            double v = m3 * Ti[i][j] + cs2 * (h[i][j] + h[j][i]) + h[i][0] * T[0][j] + h[i][1] * T[1][j] + h[i][2] * T[2][j];
-            Sm[i][j] = w * v + (i == j ? aI : 0.0);
+            T v = m3 * Ti[i][j] + cs2 * (h[i][j] + h[j][i]) + h[i][0] * Tt[0][j] + h[i][1] * Tt[1][j] + h[i][2] * Tt[2][j];
+            Sm[i][j] = w * v + (i == j ? aI : T(0.0));
           }
-      const double wm = prm.mass * w;
+      const T wm = mass_t * w;
 #pragma unroll
       for (int i = 0; i < 3; ++i)
         {
@@ -2719,7 +2735,7 @@ namespace mi
     if (lane < 48)
       {
         const int c = lane >> 4;
-        double    v[4][4];
+        T    v[4][4];
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
@@ -2728,7 +2744,7 @@ namespace mi
 #pragma unroll
         for (int k = 0; k < 3; ++k)
           {
-            double cds = 0.0, csd = 0.0, css = 0.0;
+            T cds = 0.0, csd = 0.0, css = 0.0;
 #pragma unroll
             for (int z = 0; z < 4; ++z)
               {
@@ -2747,7 +2763,7 @@ namespace mi
     // ---- I2: contract qy.  lane = (c*3+k)*4 + qx; E_D / E_S [qx][c,k,j] in sE at {0,108} + qx*27 + (c*3+k)*3 + j
     if (lane < 36)
       {
-        double cds[4], csd[4], css[4];
+        T cds[4], csd[4], css[4];
 #pragma unroll
         for (int qy = 0; qy < 4; ++qy)
           {
@@ -2760,7 +2776,7 @@ namespace mi
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           {
-            double ed = 0.0, es = 0.0;
+            T ed = 0.0, es = 0.0;
 #pragma unroll
             for (int qy = 0; qy < 4; ++qy)
               {
@@ -2778,7 +2794,7 @@ namespace mi
     // ---- I1: contract qx and update y.  lane = line (c,k,j)
     if (lane < 27)
       {
-        double ed[4], es[4];
+        T ed[4], es[4];
 #pragma unroll
         for (int qx = 0; qx < 4; ++qx)
           {
@@ -2789,7 +2805,7 @@ namespace mi
 #pragma unroll
         for (int i = 0; i < 3; ++i)
           {
-            double yv = 0.0;
+            T yv = 0.0;
 #pragma unroll
             for (int qx = 0; qx < 4; ++qx)
               {
@@ -5169,6 +5185,9 @@ namespace mi
     if (dbg && q.yc && q.cellbox && q.lat.ncol > 0)
       kern = dbg == 2 ? mf_spmv<true, true, true, 2> : dbg == 4 ? mf_spmv<true, true, true, 4> : dbg == 8 ? mf_spmv<true, true, true, 8> :
              dbg == 14 ? mf_spmv<true, true, true, 14> : dbg == 6 ? mf_spmv<true, true, true, 6> : kern;
+    // opt-in: fp32 arithmetic on fp32 records (the production shape; MfParams::qrec32 set by the caller for smoother products only)
+    if (q.qrec32 && !occ5 && !dbg && !q.stamps && q.yc && q.cellbox && q.lat.ncol > 0)
+      kern = mf_spmv<true, true, true, 0, 4, float>;
     if (ev_start || ev_stop)
       hipExtLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, s, ev_start, ev_stop, 0, q, cell_begin);
     else

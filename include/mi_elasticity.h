@@ -302,6 +302,9 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  launch after the exchange (same bits)
  *  halo_skip            1 | 0                      no exchange before a product whose operand's ghost planes are        -
  *                                                  current (first post-smoothing step) | always exchange (same bits)
+ *  smoother_precision   64 | 32                    the smoother's matrix-free fine-level products in fp64 | in fp32      -
+ *                                                  arithmetic on fp32 point records (opt-in; everything else stays fp64;
+ *                                                  takes effect with the next tangent assembly)
  *  cg_single_reduction  -1 | 0 | 1                multigrid-PCG with ONE all-reduce per iteration (r.z, z.Az, ||r||^2;      MI_CG_SINGLE_REDUCTION
  *                                                  Chronopoulos-Gear form): on teams of several slabs | never | always
  *  cg_speculate_margin  0 | 1..16                  expected iterations of a solve left to polled ones (0: two)          -
