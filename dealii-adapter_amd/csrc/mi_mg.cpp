@@ -537,6 +537,12 @@ namespace mi_detail
               nodes *= int64_t(p) * reps[d] + 1;
             const int size = c->team->size, Lf = prev_layers, Lc = reps[dim - 1];
             bool      ok   = nodes >= mg->dist_nodes;
+            // (never the coarsest level: a level cut into slabs has no matrix to invert on any one slab and would end the
+            // hierarchy with a polynomial instead of the exact solve)
+            bool more_after = false;
+            for (int d = 0; d < dim; ++d)
+              more_after = more_after || reps[d] > mg->coarsest_reps;
+            ok = ok && more_after;
             for (int r = 0; r <= size && ok; ++r)
               {
                 const int F = c->team->cuts.empty() ? int((int64_t(Lf) * r) / size) : c->team->cuts[size_t(r)];
