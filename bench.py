@@ -27,8 +27,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector (non-MFMA) peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
-MF_FLOPS_PER_LANE = 734.0  # FP64 flop per lane of a cell's wavefront in mf_spmv: (2 x 63.67 M FMA + 20.95 M MUL + 2.46 M ADD +
-# 0.21 M TRANS wave instructions) x 64 lanes / (205,379 cells x 64 lanes), profiles/r04/pmc_counters_mf_spmv_n59.json
+MF_FLOPS_PER_LANE = 712.0  # FP64 flop per lane of a cell's wavefront in mf_spmv: (2 x 61.61 M FMA + 20.54 M MUL + 2.46 M ADD
+# wave instructions) x 64 lanes / (205,379 cells x 64 lanes), profiles/r05/pmc_counters_mf_spmv_n59.json
 CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")  # unit counts of a whole CPU step (deterministic)
 
 
@@ -554,7 +554,7 @@ def main():
                 "kernel": ("mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
                            "point numbers per cell the tangent is linearised at (sum factorisation, no stored K_e; 4.8x fewer bytes "
                            "than the element tangents it replaced, which takes the product off the HBM roofline: VALU, LDS and HBM "
-                           "are each half to three quarters busy, profiles/r04/pmc_counters_mf_spmv_n59.json); "
+                           "are each half to three quarters busy, profiles/r05/pmc_counters_mf_spmv_n59.json); "
                            if form == 2 else
                            "ebe_spmv: y += sum over the cells of ONE colour of P^T K_e P x with the unassembled symmetric element "
                            "tangents (378 lower-triangle 3x3 blocks per cell); ") +
@@ -587,7 +587,7 @@ def main():
                 out["roofline"]["fp64"] = {
                     "flops_per_launch": flops, "TFLOP_per_s": flops / (ebe_ms * 1e-3) / 1e12, "peak_TFLOP_per_s": FP64_VECTOR_PEAK_TF,
                     "frac": flops / (ebe_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,
-                    "source": "profiles/r04/pmc_counters_mf_spmv_n59.json (2 x FMA + MUL + ADD wave instructions x 64 lanes per cell)"}
+                    "source": "profiles/r05/pmc_counters_mf_spmv_n59.json (2 x FMA + MUL + ADD wave instructions x 64 lanes per cell)"}
         out["roofline"]["whole_step"] = {
             "fine_level_products_per_step": n_prod, "algorithmic_GB_per_step": step_bytes / 1e9,
             "GB_per_s": step_bytes / 1e9 / (ms_step * 1e-3), "frac": step_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
@@ -601,7 +601,7 @@ def main():
             G.set_tuning("spmv_variant", 3)
             out["roofline"]["calibration_stream_read"] = {"ms": ms_cal, "GB": 8 * G.nnz / 1e9,
                                                           "GB_per_s": 8 * G.nnz / ms_cal / 1e6}
-        pmc_file = os.path.join(ROOT, "profiles", "r04", "pmc_bench_n59.json")
+        pmc_file = os.path.join(ROOT, "profiles", "r05", "pmc_bench_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
             # NOT a measurement of this run: per-launch HBM traffic of the same command under `rocprofv3 --pmc`
             # (tools/pmc_bench.sh), as committed with the round's profiles; `roofline.traffic` itself stays null because
