@@ -4300,8 +4300,16 @@ namespace mi
   // above pays three dependent round trips to the L2 per block column for the same work: 23 us per block column on the
   // shipped FSI3 case against ~4 here.  The forward substitution rides along (y is one more LDS vector, updated by the
   // panel's threads); the backward substitution reads L back from memory.  Three workgroup barriers per block column.
-  constexpr int BAND_LDS_W = 128;
-  template <int D>
+  //
+  // FAR (round 5; half bandwidths up to BAND_LDS_W - BAND_NB + BAND_FAR_MAX = 160: the reference's 3D plate at degree 2 has
+  // 152): a block column's panel reaches nfar = hbw + NB - W rows BEYOND the window.  Their entries stay in the band in
+  // memory: the far panel rows are solved by wave 3 (values requested at the top of the iteration) and kept in LDS (sF)
+  // for the iteration; the trailing update of the 16 rows that enter the window next is applied to the registers that
+  // carry them in (pre[]), the update of the rows beyond those is a read-modify-write of the band in memory (one column's
+  // 24-32 rows contiguous), both beside the window's own trailing update.  The window itself never holds an entry with
+  // r - c >= W: when a row enters, its columns further left are finished.
+  constexpr int BAND_LDS_W = 128, BAND_FAR_MAX = 48;
+  template <int D, bool FAR = false>
   __global__ __launch_bounds__(1024) void band_cholesky_lds(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
                                                             int nnodes, const double *__restrict__ b, double *x, double *work,
                                                             int32_t *flag, int do_solve, unsigned long long *dbg)
@@ -4325,6 +4333,7 @@ namespace mi
     __shared__ double sy[NB];     // y of the current block
     __shared__ double srd[NB];    // 1 / L_cc of the current block
     __shared__ double sL[NB][NB + 1];
+    __shared__ double sF[FAR ? BAND_FAR_MAX : 1][NB + 1]; // FAR: the panel rows beyond the window (row rF0 + f)
     const int tid = threadIdx.x, ld = hbw + 1;
     // ---- right-hand side into band order (memory)
     if (do_solve)
@@ -4351,7 +4360,9 @@ namespace mi
     auto diagonal_block = [&](int j0) {
       const int           nb = min(NB, n - j0), jc = j0 & (W - 1);
       double              row[NB];
-      const int           lr = tid < NB ? tid : NB - 1;
+      int                 lr = tid < NB ? tid : NB - 1;
+      if constexpr (FAR) // (registers are short there: keeps the 16 identity constants below from being hoisted and spilled)
+        asm volatile("" : "+v"(lr));
       const double *const rp = &S[((j0 + lr) & (W - 1)) * LD + jc];
 #pragma unroll
       for (int c = 0; c < NB; ++c)
@@ -4400,6 +4411,8 @@ namespace mi
     for (int j0 = 0; j0 < n; j0 += NB)
       {
         const int nb = min(NB, n - j0), jc = j0 & (W - 1); // the block's columns are the slots jc .. jc + NB - 1
+        // the panel: mall rows below the block reach into its columns, m of them in the window, nfar beyond it (FAR)
+        const int r0 = j0 + nb, mall = min(n, r0 + hbw) - r0, m = FAR ? min(mall, W - nb) : mall, nfar = mall - m, rF0 = j0 + W;
         // the rows that enter the window when this block column is done: requested now, stored at the end
         double pre[2], prey = 0.0;
 #pragma unroll
@@ -4407,22 +4420,38 @@ namespace mi
           {
             const int idx = tid + u * 1024, rr = idx >> 7, cs = idx & (W - 1), rn = j0 + W + rr;
             const int c = rn - ((rn - cs) & (W - 1)), k = rn - c;
-            pre[u] = (rn < n && k <= hbw) ? band[int64_t(c) * ld + k] : 0.0; // (c >= 0: rn >= W)
+            // (c >= 0: rn >= W.  FAR: a slot whose column belongs to this block column is dead -- the entry is finished
+            // in memory by the far panel below)
+            pre[u] = (rn < n && k <= hbw && (!FAR || c >= r0)) ? band[int64_t(c) * ld + k] : 0.0;
           }
         if (do_solve && tid < NB && j0 + W + tid < n)
           prey = work[j0 + W + tid];
+        // FAR: the far panel rows' entries in the block's columns come from memory (wave 3, one row per lane), requested here
+        double     xr[NB];
+        const int  ff   = tid - 192;
+        const bool farp = FAR && ff >= 0 && ff < nfar; // (nfar > 0: rows below the block, so nb = NB)
+        if constexpr (FAR)
+          if (farp)
+            {
+              // (entry (r, j0 + c) at band[(j0 + c) ld + r - j0 - c]: a walk of stride ld - 1 from column j0)
+              const double *pb = band + (int64_t(j0) * ld + (rF0 + ff - j0));
+#pragma unroll
+              for (int c = 0; c < NB; ++c, pb += ld - 1)
+                xr[c] = (W + ff - c <= hbw) ? *pb : 0.0;
+            }
         // ---- P: the rows below the block that reach into its columns, one triangular solve per row; a slot outside the
         // row's band holds zero and stays zero (L has the band of A)
-        const int r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
-        if (tid < m) // (m <= W - NB = 112: waves 0 and 1)
+        if (tid < m || farp) // (m <= W - NB = 112: waves 0 and 1; FAR: and the far rows' lanes of wave 3)
           {
             // right-looking in registers: a finished entry updates all later ones at once (independent multiply-adds; the
             // dependent chain is one multiply per column, not a sum over the columns before it)
             double *const rp = &S[((r0 + tid) & (W - 1)) * LD + jc];
-            double        xr[NB];
+            if (!farp)
+              {
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
-              xr[c] = rp[c];
+                for (int c = 0; c < NB; ++c)
+                  xr[c] = rp[c];
+              }
 #pragma unroll
             for (int c = 0; c < NB; ++c)
               {
@@ -4431,9 +4460,24 @@ namespace mi
                 for (int c2 = c + 1; c2 < NB; ++c2)
                   xr[c2] = fma(-xr[c], sL[c2][c], xr[c2]);
               }
+            if (!farp)
+              {
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
-              rp[c] = xr[c];
+                for (int c = 0; c < NB; ++c)
+                  rp[c] = xr[c];
+              }
+            else if constexpr (FAR)
+              {
+                // a far row: finished entries back to the band in memory, the row into sF for this iteration's updates
+                double *pb = band + (int64_t(j0) * ld + (rF0 + ff - j0));
+#pragma unroll
+                for (int c = 0; c < NB; ++c, pb += ld - 1)
+                  {
+                    sF[ff][c] = xr[c];
+                    if (W + ff - c <= hbw)
+                      *pb = xr[c];
+                  }
+              }
           }
         else if (do_solve && tid >= 128 && tid < 192)
           {
@@ -4465,8 +4509,9 @@ namespace mi
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
-            const int idx = tid + u * 1024, cc = idx / ld, k = idx - cc * ld, r = j0 + cc + k;
-            wb[u]         = (cc < nb && r < n) ? S[(r & (W - 1)) * LD + jc + cc] : 0.0;
+            // (entry k of finished column cc; rows of the window only: a FAR column's rows beyond it are the far panel's)
+            const int idx = tid + u * 1024, cc = idx >> 7, k = idx & (W - 1), r = j0 + cc + k;
+            wb[u]         = (cc < nb && k <= hbw && r < n && r < j0 + W) ? S[(r & (W - 1)) * LD + jc + cc] : 0.0;
           }
         // the next DIAGONAL block first (what the next factorisation waits for): A[s][t] -= sum_c L[s][c] L[t][c], t <= s < NB
         if (tid >= 512 && tid < 512 + NB * NB)
@@ -4539,6 +4584,76 @@ namespace mi
                   dy += rp[c] * sy[c];
                 yv[r & (W - 1)] -= dy;
               }
+            if constexpr (FAR)
+              if (nfar > NB)
+                {
+                  // the rows beyond the entering ones (far rows f >= NB): their entries against every panel column, in
+                  // the band in memory; consecutive threads = consecutive rows of one column (contiguous)
+                  // (all old values of a thread requested before any is stored: one round trip to the L2, not one per entry)
+                  const int     ncol = rF0 + nfar - r0;
+                  constexpr int NR   = ((BAND_LDS_W - BAND_NB + BAND_FAR_MAX) * 32 + 959) / 960;
+                  double        old[NR];
+                  int           tl = tid; // (opaque: the index arithmetic below is cheap to redo and expensive to keep)
+                  asm volatile("" : "+v"(tl));
+#pragma unroll
+                  for (int u = 0; u < NR; ++u)
+                    {
+                      const int p = tl - 64 + u * 960, ci = p >> 5, fi = (p & 31) + NB, c = r0 + ci, k = rF0 + fi - c;
+                      old[u] = (ci < ncol && fi < nfar && k >= 0 && k <= hbw) ? band[int64_t(c) * ld + k] : 0.0;
+                    }
+#pragma unroll
+                  for (int u = 0; u < NR; ++u)
+                    {
+                      const int p = tl - 64 + u * 960, ci = p >> 5, fi = (p & 31) + NB, c = r0 + ci, k = rF0 + fi - c;
+                      if (ci < ncol && fi < nfar && k >= 0 && k <= hbw)
+                        {
+                          const double *const pf = sF[fi], *const pc = c < rF0 ? &S[(c & (W - 1)) * LD + jc] : sF[c - rF0];
+                          double              acc = 0.0;
+#pragma unroll
+                          for (int q = 0; q < NB; ++q)
+                            acc += pf[q] * pc[q];
+                          band[int64_t(c) * ld + k] = old[u] - acc;
+                        }
+                    }
+                  if (do_solve && tid - 64 + NB < nfar) // their y
+                    {
+                      const int fi = tid - 64 + NB;
+                      double    dy = 0.0;
+#pragma unroll
+                      for (int q = 0; q < NB; ++q)
+                        dy += sF[fi][q] * sy[q];
+                      work[rF0 + fi] -= dy;
+                    }
+                }
+          }
+        if constexpr (FAR)
+          {
+            // the entering rows that are far panel rows of this block column: the same update on the way in
+            int tl = tid;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+              {
+                const int idx = tl + u * 1024, rr = idx >> 7, cs = idx & (W - 1), rn = j0 + W + rr;
+                const int c = rn - ((rn - cs) & (W - 1)), k = rn - c;
+                if (rr < nfar && c >= r0 && k <= hbw)
+                  {
+                    const double *const pf = sF[rr], *const pc = c < rF0 ? &S[(c & (W - 1)) * LD + jc] : sF[c - rF0];
+                    double              acc = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NB; ++q)
+                      acc += pf[q] * pc[q];
+                    pre[u] -= acc;
+                  }
+              }
+            if (do_solve && tid < NB && tid < nfar)
+              {
+                double dy = 0.0;
+#pragma unroll
+                for (int q = 0; q < NB; ++q)
+                  dy += sF[tid][q] * sy[q];
+                prey -= dy;
+              }
           }
         // the new rows take the slots of the block's rows (whole slot rows: band entries and zeros) ...
 #pragma unroll
@@ -4553,8 +4668,8 @@ namespace mi
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
-            const int idx = tid + u * 1024, cc = idx / ld, k = idx - cc * ld, r = j0 + cc + k;
-            if (cc < nb && r < n)
+            const int idx = tid + u * 1024, cc = idx >> 7, k = idx & (W - 1), r = j0 + cc + k;
+            if (cc < nb && k <= hbw && r < n && r < j0 + W)
               band[int64_t(j0 + cc) * ld + k] = wb[u];
           }
         __syncthreads();
@@ -5209,7 +5324,8 @@ namespace mi
       return -1;
     // factorisations of narrow bands (the reference's 2D geometries) run on the LDS-window kernel; MI_BAND_LDS=0: never (A/B)
     static const bool lds_ok = !(getenv("MI_BAND_LDS") && atoi(getenv("MI_BAND_LDS")) == 0);
-    if (factor && lds_ok && hbw + BAND_NB <= BAND_LDS_W)
+    const bool far = hbw + BAND_NB > BAND_LDS_W;
+    if (factor && lds_ok && hbw + BAND_NB <= BAND_LDS_W + BAND_FAR_MAX)
       {
         // MI_BAND_DBG (diagnostic): phase clocks of thread 0 of the first two factorisations, printed after a
         // synchronisation; the solve itself is the production one (stamps only), the buffer lives for the call
@@ -5218,9 +5334,15 @@ namespace mi
         unsigned long long *d_dbg  = nullptr;
         if (dbg_on && shown < 2 && hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
           d_dbg = nullptr;
-        if (dim == 3)
+        if (dim == 3 && far)
+          hipLaunchKernelGGL((band_cholesky_lds<3, true>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work,
+                             flag, int(solve), d_dbg);
+        else if (dim == 3)
           hipLaunchKernelGGL((band_cholesky_lds<3>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
                              int(solve), d_dbg);
+        else if (far)
+          hipLaunchKernelGGL((band_cholesky_lds<2, true>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work,
+                             flag, int(solve), d_dbg);
         else
           hipLaunchKernelGGL((band_cholesky_lds<2>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work, flag,
                              int(solve), d_dbg);

@@ -674,12 +674,16 @@ def _scenario_pair(scenario, dim, p):
 
 
 @pytest.mark.parametrize("dim,p,reps", [(2, 3, (6, 5)), (2, 4, (5, 3)), (2, 2, (40, 9)), (2, 1, (60, 25)), (2, 3, (3, 1)), (2, 1, (2, 2)),
-                                        (3, 1, (9, 3, 2)), (3, 1, (5, 4, 4)), (2, 3, (4, 7)), (2, 1, (100, 54)), (2, 1, (30, 55))])
+                                        (3, 1, (9, 3, 2)), (3, 1, (5, 4, 4)), (2, 3, (4, 7)), (2, 1, (100, 54)), (2, 1, (30, 55)),
+                                        (2, 1, (61, 70)), (2, 1, (62, 64)), (2, 1, (69, 75)), (2, 2, (18, 30)), (3, 1, (2, 15, 20)),
+                                        (2, 1, (77, 60)), (2, 1, (79, 40)), (3, 2, (2, 2, 9))])
 def test_direct_solver_over_band_widths(dim, p, reps):
     """round 4: factorisations of bands up to 112 dofs wide run with the active window of the matrix in LDS (band_cholesky_lds: a
     circular window of 128 rows, look-ahead, streamed rows), wider ones on the general kernel.  Meshes on both sides of the
     limit, windows that wrap many times (11 k dofs), last blocks and panels shorter than a block column, systems smaller than
-    the window: the direct solution against scipy's sparse LU of the exported tangent (an independent solver standing in for
+    the window; round 5: bands of 113-160 dofs (the reference's 3D plate at degree 2: 152) keep the window and take the rows
+    beyond it through memory -- half bandwidths 113, 127, 129, 143, 153, 158, 159 (1 to 47 rows beyond the window, on both
+    sides of a whole block column of them), 163 and 182 on the general kernel: the direct solution against scipy's sparse LU of the exported tangent (an independent solver standing in for
     the reference's UMFPACK) [REF nonlinear_elasticity.cc:1192-1200]; constrained dofs come back as exact zeros (:1208)."""
     import ctypes as C
     import scipy.sparse.linalg as spla
