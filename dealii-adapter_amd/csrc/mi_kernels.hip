@@ -4315,7 +4315,7 @@ namespace mi
                                                             int32_t *flag, int do_solve, unsigned long long *dbg)
   {
     constexpr int NB = BAND_NB, W = BAND_LDS_W, LD = W + 1;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0; // diagnostic (dbg != null): clocks per phase, thread 0
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tw0 = 0; // diagnostic (dbg != null): clocks per phase, thread 0
 #define BAND_STAMP(i_)                                             \
   do                                                               \
     {                                                              \
@@ -4397,12 +4397,105 @@ namespace mi
           srd[tid] = rdl;
         }
     };
+    // One 16 x 16 tile of the trailing update on the matrix cores (v_mfma_f64_16x16x4_f64, four of them for the block
+    // column's 16 columns): rows s0 + i of row block I against rows t0 + j of row block J <= I, D[i][j] = sum_k P[s0+i][k]
+    // P[t0+j][k] with the panel P in the window (S, the block's columns) or -- FAR -- in sF.  Operands: lane l holds
+    // A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the result D[(l >> 4) + 4 v][l & 15] in register v.  Panel rows
+    // past the band's edge or the matrix's end are zero rows, so whole tiles are safe.  The eight operand reads replace
+    // the 2 x 16 LDS reads PER ENTRY of a multiply-add loop: the update was LDS-bandwidth bound.
+    // Targets: the window (entering rows included: they are stored before the barrier in front of this), or -- rows
+    // beyond them -- the band in memory, with the tile transposed so that lanes walk a column's contiguous rows.
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    auto update_tile = [&](int I, int J, int j0, int jc, int r0, int rF0, int nfar) {
+      const int  lane = tid & 63, li = lane & 15, lk = lane >> 4;
+      const int  s0 = r0 + NB * I, t0 = r0 + NB * J;
+      double     a[4], b[4];
+      {
+        const int           rs = s0 + li, rt = t0 + li;
+        const double *const ps = (FAR && rs >= rF0) ? &sF[rs - rF0][0] : &S[(rs & (W - 1)) * LD + jc];
+        const double *const pt = (FAR && rt >= rF0) ? &sF[rt - rF0][0] : &S[(rt & (W - 1)) * LD + jc];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          {
+            a[kk] = ps[4 * kk + lk];
+            b[kk] = pt[4 * kk + lk];
+          }
+      }
+      v4f64 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], d, 0, 0, 0);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        {
+          const int sr = s0 + lk + 4 * v, tc = t0 + li;
+          if (I != J || tc <= sr)
+            S[(sr & (W - 1)) * LD + (tc & (W - 1))] -= d[v];
+        }
+    };
+    // FAR: tiles whose rows lie beyond the entering ones live in the band in memory.  Transposed (D'[column t0 + lk + 4 v]
+    // [row s0 + li]: lanes walk a column's contiguous rows), and TWO tiles at a time: both tiles' old values are requested
+    // before either is stored -- one round trip to the L2 and one drain of the stores per pair (a wave's memory operations
+    // retire in order, so tile after tile would pay both per tile)
+    auto update_mem_pair = [&](int p0, int p1, int jc, int r0, int rF0, int nfar) {
+      const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+      auto      block_of = [](int p) {
+        int I = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+        while ((I + 1) * (I + 2) / 2 <= p)
+          ++I;
+        while (I * (I + 1) / 2 > p)
+          --I;
+        return I;
+      };
+      const int  I0 = block_of(p0), J0 = p0 - I0 * (I0 + 1) / 2, I1 = p1 >= 0 ? block_of(p1) : I0, J1 = p1 >= 0 ? p1 - I1 * (I1 + 1) / 2 : J0;
+      const int  sA = r0 + NB * I0, tA = r0 + NB * J0, sB = r0 + NB * I1, tB = r0 + NB * J1;
+      const bool two = p1 >= 0;
+      double     oldA[4], oldB[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        {
+          const int tc = tA + lk + 4 * v, sr = sA + li;
+          oldA[v]      = (sr - rF0 < nfar && tc <= sr) ? band[int64_t(tc) * ld + (sr - tc)] : 0.0;
+        }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        {
+          const int tc = tB + lk + 4 * v, sr = sB + li;
+          oldB[v]      = (two && sr - rF0 < nfar && tc <= sr) ? band[int64_t(tc) * ld + (sr - tc)] : 0.0;
+        }
+      auto product = [&](int s0, int t0) {
+        const int           rs = s0 + li, rt = t0 + li;
+        const double *const ps = &sF[rs - rF0][0]; // (rows beyond the window)
+        const double *const pt = rt >= rF0 ? &sF[rt - rF0][0] : &S[(rt & (W - 1)) * LD + jc];
+        v4f64               d  = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          d = __builtin_amdgcn_mfma_f64_16x16x4f64(pt[4 * kk + lk], ps[4 * kk + lk], d, 0, 0, 0);
+        return d;
+      };
+      const v4f64 dA = product(sA, tA), dB = product(sB, tB);
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        {
+          const int tc = tA + lk + 4 * v, sr = sA + li;
+          if (sr - rF0 < nfar && tc <= sr)
+            band[int64_t(tc) * ld + (sr - tc)] = oldA[v] - dA[v];
+        }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        {
+          const int tc = tB + lk + 4 * v, sr = sB + li;
+          if (two && sr - rF0 < nfar && tc <= sr)
+            band[int64_t(tc) * ld + (sr - tc)] = oldB[v] - dB[v];
+        }
+    };
     // Look-ahead (a block column's dependent chain is diagonal block -> panel -> update of the NEXT block column -> next
     // diagonal block; the rest of the trailing update and the row streaming run beside the next diagonal block):
     //   P   panel rows solved against the diagonal block (waves 0-1), y of the block (wave 2)
-    //   T1  the finished columns into registers; y of the panel rows; trailing update of the next block's 16 columns
-    //   T2  wave 0: next diagonal block  |  waves 1-15: trailing update of the other columns
-    //       everybody: the new rows into the slots of the block's rows, the finished columns out to memory
+    //   T1  the finished columns into registers, the new rows into the slots of the block's rows; the trailing update's
+    //       tile of the next diagonal block
+    //   T2  wave 0: next diagonal block  |  waves 1-15: the other tiles of the trailing update, y of the panel rows
+    //       everybody: the finished columns out to memory
     if (tid < 64)
       diagonal_block(0);
     __syncthreads();
@@ -4441,6 +4534,13 @@ namespace mi
             }
         // ---- P: the rows below the block that reach into its columns, one triangular solve per row; a slot outside the
         // row's band holds zero and stays zero (L has the band of A)
+        if constexpr (FAR)
+          if (ff >= 0 && ff < BAND_FAR_MAX && !farp) // rows of sF past the panel: zero rows (whole tiles are multiplied)
+            {
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                sF[ff][c] = 0.0;
+            }
         if (tid < m || farp) // (m <= W - NB = 112: waves 0 and 1; FAR: and the far rows' lanes of wave 3)
           {
             // right-looking in registers: a finished entry updates all later ones at once (independent multiply-adds; the
@@ -4502,160 +4602,19 @@ namespace mi
           }
         __syncthreads();
         BAND_STAMP(0);
-        // ---- T1: the finished columns leave the window: into registers now (their slots are reused below), out to the band
-        // in memory as the iteration's LAST memory operation -- the memory counter retires in order, and the new rows'
-        // loads must not queue behind these stores
+        // ---- T1: the finished columns leave the window: into registers now, out to the band in memory as the iteration's LAST
+        // memory operation -- the memory counter retires in order, and the new rows' loads must not queue behind these
+        // stores.  (The block's own rows come from sL: their slots in S are dead since the diagonal block was factorised,
+        // which is what lets the new rows take them right here.)
         double wb[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
             // (entry k of finished column cc; rows of the window only: a FAR column's rows beyond it are the far panel's)
             const int idx = tid + u * 1024, cc = idx >> 7, k = idx & (W - 1), r = j0 + cc + k;
-            wb[u]         = (cc < nb && k <= hbw && r < n && r < j0 + W) ? S[(r & (W - 1)) * LD + jc + cc] : 0.0;
+            wb[u] = (cc < nb && k <= hbw && r < n && r < j0 + W) ? (r < r0 ? sL[cc + k][cc] : S[(r & (W - 1)) * LD + jc + cc]) : 0.0;
           }
-        // the next DIAGONAL block first (what the next factorisation waits for): A[s][t] -= sum_c L[s][c] L[t][c], t <= s < NB
-        if (tid >= 512 && tid < 512 + NB * NB)
-          {
-            const int t = (tid - 512) >> 4, sidx = (tid - 512) & (NB - 1);
-            if (t <= sidx && sidx < m)
-              {
-                const double *const ps = &S[((r0 + sidx) & (W - 1)) * LD + jc], *const pt = &S[((r0 + t) & (W - 1)) * LD + jc];
-                double              acc = 0.0;
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                  acc += ps[c] * pt[c];
-                S[((r0 + sidx) & (W - 1)) * LD + ((r0 + t) & (W - 1))] -= acc;
-              }
-          }
-        __syncthreads();
-        BAND_STAMP(1);
-        // ---- T2: the next diagonal block (wave 0) beside the rest of the trailing update (2 x 2 register tiles: one LDS read
-        // per multiply-add instead of two -- the update is LDS-bandwidth bound)
-        if (tid < 64)
-          {
-            if (r0 < n)
-              diagonal_block(r0);
-          }
-        else
-          {
-            // tiles (si, ti) of panel rows 2 si, 2 si + 1 against panel columns 2 ti, 2 ti + 1, ti <= si, all but the
-            // NB / 2 (NB / 2 + 1) / 2 tiles of the next diagonal block (si < NB / 2), which are done
-            constexpr int skip = (NB / 2) * (NB / 2 + 1) / 2;
-            const int     mt = (m + 1) >> 1, ntile = mt * (mt + 1) / 2 - skip;
-            for (int p = tid - 64 + skip; p < ntile + skip; p += 960)
-              {
-                int si = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
-                while ((si + 1) * (si + 2) / 2 <= p)
-                  ++si;
-                while (si * (si + 1) / 2 > p)
-                  --si;
-                const int  ti = p - si * (si + 1) / 2;
-                const int  s0i = 2 * si, t0i = 2 * ti;
-                const bool s1 = s0i + 1 < m, t1 = t0i + 1 < m;
-                const double *const ps0 = &S[((r0 + s0i) & (W - 1)) * LD + jc], *const ps1 = &S[((r0 + s0i + 1) & (W - 1)) * LD + jc];
-                const double *const pt0 = &S[((r0 + t0i) & (W - 1)) * LD + jc], *const pt1 = &S[((r0 + t0i + 1) & (W - 1)) * LD + jc];
-                double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
-#pragma unroll 4
-                for (int c = 0; c < NB; ++c)
-                  {
-                    const double x0 = ps0[c], x1 = s1 ? ps1[c] : 0.0, y0 = pt0[c], y1 = t1 ? pt1[c] : 0.0;
-                    a00 += x0 * y0;
-                    a01 += x0 * y1;
-                    a10 += x1 * y0;
-                    a11 += x1 * y1;
-                  }
-                double *const o0 = &S[((r0 + s0i) & (W - 1)) * LD], *const o1 = &S[((r0 + s0i + 1) & (W - 1)) * LD];
-                const int     c0 = (r0 + t0i) & (W - 1), c1 = (r0 + t0i + 1) & (W - 1);
-                o0[c0] -= a00; // t0 <= s0
-                if (t1 && t0i + 1 <= s0i)
-                  o0[c1] -= a01;
-                if (s1)
-                  o1[c0] -= a10;
-                if (s1 && t1)
-                  o1[c1] -= a11;
-              }
-            if (do_solve && tid >= 896 && tid - 896 < m) // y of the panel's rows: y_r -= L[r][block] . y_block
-              {
-                const int           r  = r0 + tid - 896;
-                const double *const rp = &S[(r & (W - 1)) * LD + jc];
-                double              dy = 0.0;
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                  dy += rp[c] * sy[c];
-                yv[r & (W - 1)] -= dy;
-              }
-            if constexpr (FAR)
-              if (nfar > NB)
-                {
-                  // the rows beyond the entering ones (far rows f >= NB): their entries against every panel column, in
-                  // the band in memory; consecutive threads = consecutive rows of one column (contiguous)
-                  // (all old values of a thread requested before any is stored: one round trip to the L2, not one per entry)
-                  const int     ncol = rF0 + nfar - r0;
-                  constexpr int NR   = ((BAND_LDS_W - BAND_NB + BAND_FAR_MAX) * 32 + 959) / 960;
-                  double        old[NR];
-                  int           tl = tid; // (opaque: the index arithmetic below is cheap to redo and expensive to keep)
-                  asm volatile("" : "+v"(tl));
-#pragma unroll
-                  for (int u = 0; u < NR; ++u)
-                    {
-                      const int p = tl - 64 + u * 960, ci = p >> 5, fi = (p & 31) + NB, c = r0 + ci, k = rF0 + fi - c;
-                      old[u] = (ci < ncol && fi < nfar && k >= 0 && k <= hbw) ? band[int64_t(c) * ld + k] : 0.0;
-                    }
-#pragma unroll
-                  for (int u = 0; u < NR; ++u)
-                    {
-                      const int p = tl - 64 + u * 960, ci = p >> 5, fi = (p & 31) + NB, c = r0 + ci, k = rF0 + fi - c;
-                      if (ci < ncol && fi < nfar && k >= 0 && k <= hbw)
-                        {
-                          const double *const pf = sF[fi], *const pc = c < rF0 ? &S[(c & (W - 1)) * LD + jc] : sF[c - rF0];
-                          double              acc = 0.0;
-#pragma unroll
-                          for (int q = 0; q < NB; ++q)
-                            acc += pf[q] * pc[q];
-                          band[int64_t(c) * ld + k] = old[u] - acc;
-                        }
-                    }
-                  if (do_solve && tid - 64 + NB < nfar) // their y
-                    {
-                      const int fi = tid - 64 + NB;
-                      double    dy = 0.0;
-#pragma unroll
-                      for (int q = 0; q < NB; ++q)
-                        dy += sF[fi][q] * sy[q];
-                      work[rF0 + fi] -= dy;
-                    }
-                }
-          }
-        if constexpr (FAR)
-          {
-            // the entering rows that are far panel rows of this block column: the same update on the way in
-            int tl = tid;
-            asm volatile("" : "+v"(tl));
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-              {
-                const int idx = tl + u * 1024, rr = idx >> 7, cs = idx & (W - 1), rn = j0 + W + rr;
-                const int c = rn - ((rn - cs) & (W - 1)), k = rn - c;
-                if (rr < nfar && c >= r0 && k <= hbw)
-                  {
-                    const double *const pf = sF[rr], *const pc = c < rF0 ? &S[(c & (W - 1)) * LD + jc] : sF[c - rF0];
-                    double              acc = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NB; ++q)
-                      acc += pf[q] * pc[q];
-                    pre[u] -= acc;
-                  }
-              }
-            if (do_solve && tid < NB && tid < nfar)
-              {
-                double dy = 0.0;
-#pragma unroll
-                for (int q = 0; q < NB; ++q)
-                  dy += sF[tid][q] * sy[q];
-                prey -= dy;
-              }
-          }
-        // the new rows take the slots of the block's rows (whole slot rows: band entries and zeros) ...
+        // the new rows take the slots of the block's rows (whole slot rows: band entries and zeros)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
@@ -4664,7 +4623,78 @@ namespace mi
           }
         if (do_solve && tid < NB)
           yv[(j0 + W + tid) & (W - 1)] = prey;
-        // ... and the finished columns go out
+        // the next DIAGONAL block first (what the next factorisation waits for): tile (0, 0) of the trailing update
+        if (tid >= 512 && tid < 576 && m > 0)
+          update_tile(0, 0, j0, jc, r0, rF0, nfar);
+        __syncthreads();
+        BAND_STAMP(1);
+        // ---- T2: the next diagonal block (wave 0) beside the rest of the trailing update (waves 1-15, one 16 x 16 tile of
+        // it at a time on the matrix cores)
+        if (tid < 64)
+          {
+            if (r0 < n)
+              diagonal_block(r0);
+            if (dbg && tid == 0)
+              tacc[3] += __builtin_amdgcn_s_memtime() - tlast; // (of the third phase: until wave 0 is through)
+          }
+        else
+          {
+            // row blocks of 16 below the block column: nbw in the window, then (FAR) the entering rows and the rows beyond
+            const int nbw = (m + NB - 1) / NB, nbf = FAR ? (nfar + NB - 1) / NB : 0, nbr = nbw + nbf;
+            const int ntile = nbr * (nbr + 1) / 2;
+            // (FAR: the tiles of the last nbr - 8 row blocks live in memory: at most 19, in pairs, on the first waves)
+            const int wv = (tid - 64) >> 6, pmem = FAR && nbr > 8 ? 8 * 9 / 2 : ntile;
+            if (dbg && tid == 64)
+              tw0 = __builtin_amdgcn_s_memtime();
+            for (int p = 1 + wv; p < min(pmem, ntile); p += 15) // (tile 0 is done)
+              {
+                int I = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
+                while ((I + 1) * (I + 2) / 2 <= p)
+                  ++I;
+                while (I * (I + 1) / 2 > p)
+                  --I;
+                update_tile(I, p - I * (I + 1) / 2, j0, jc, r0, rF0, nfar);
+              }
+            if (dbg && tid == 64)
+              tacc[4] += __builtin_amdgcn_s_memtime() - tw0; // wave 1: its window tiles done
+            if constexpr (FAR)
+              if (pmem + 2 * wv < ntile)
+                update_mem_pair(pmem + 2 * wv, pmem + 2 * wv + 1 < ntile ? pmem + 2 * wv + 1 : -1, jc, r0, rF0, nfar);
+            if (dbg && tid == 64)
+              tacc[5] += __builtin_amdgcn_s_memtime() - tw0; // ... its memory tiles issued
+            if (do_solve && tid >= 896) // y of the panel's rows: y_r -= L[r][block] . y_block
+              {
+                const int t = tid - 896;
+                if (t < m)
+                  {
+                    const int           r  = r0 + t;
+                    const double *const rp = &S[(r & (W - 1)) * LD + jc];
+                    double              dy = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                      dy += rp[c] * sy[c];
+                    yv[r & (W - 1)] -= dy;
+                  }
+                else if (FAR && t - m < min(nfar, NB)) // (m = W - NB here) the entering rows
+                  {
+                    double dy = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c)
+                      dy += sF[t - m][c] * sy[c];
+                    yv[(rF0 + t - m) & (W - 1)] -= dy;
+                  }
+              }
+            if (FAR && do_solve && tid >= 832 && tid < 864 && tid - 832 + NB < nfar) // the rows beyond them: y in memory
+              {
+                const int f  = tid - 832 + NB;
+                double    dy = 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                  dy += sF[f][c] * sy[c];
+                work[rF0 + f] -= dy;
+              }
+          }
+        // the finished columns go out
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
@@ -4672,11 +4702,21 @@ namespace mi
             if (cc < nb && k <= hbw && r < n && r < j0 + W)
               band[int64_t(j0 + cc) * ld + k] = wb[u];
           }
+        if (dbg && tid == 64)
+          {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tacc[6] += __builtin_amdgcn_s_memtime() - tw0; // ... its stores drained
+          }
         __syncthreads();
+        if (dbg && tid == 64)
+          tacc[7] += __builtin_amdgcn_s_memtime() - tw0; // ... the barrier behind it
         BAND_STAMP(2);
       }
     if (dbg && tid == 0)
-      for (int i = 0; i < 3; ++i)
+      for (int i = 0; i < 4; ++i)
+        dbg[i] = tacc[i];
+    if (dbg && tid == 64)
+      for (int i = 4; i < 8; ++i)
         dbg[i] = tacc[i];
 #undef BAND_STAMP
     if (!do_solve)
@@ -5334,6 +5374,8 @@ namespace mi
         unsigned long long *d_dbg  = nullptr;
         if (dbg_on && shown < 2 && hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
           d_dbg = nullptr;
+        if (d_dbg)
+          hipMemsetAsync(d_dbg, 0, 8 * sizeof(unsigned long long), s);
         if (dim == 3 && far)
           hipLaunchKernelGGL((band_cholesky_lds<3, true>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x, work,
                              flag, int(solve), d_dbg);
@@ -5348,13 +5390,13 @@ namespace mi
                              int(solve), d_dbg);
         if (d_dbg)
           {
-            unsigned long long h[4];
+            unsigned long long h[8];
             hipStreamSynchronize(s);
             hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
             hipFree(d_dbg);
             ++shown;
             fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: panel + y %llu, next block's columns %llu, next "
-                            "diagonal block beside the trailing update %llu\n", n, hbw, h[0], h[1], h[2]);
+                            "diagonal block beside the trailing update %llu (wave 0 through after %llu; wave 1: window tiles %llu, memory tiles %llu, stores drained %llu, barrier %llu)\n", n, hbw, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
           }
         return 0;
       }
