@@ -4289,25 +4289,34 @@ namespace mi
       }
   }
 
-  // ------------------------------------------------------------------ banded Cholesky, LDS-window form (round 4)
-  // The same factorisation K = L L^T + substitutions for half bandwidths hbw <= BAND_LDS_W - BAND_NB (the reference's 2D
-  // geometries: 67 dofs at the shipped degree 3): the ACTIVE part of the matrix -- the BAND_LDS_W rows below the current
-  // block column, i.e. everything a block column's panel and trailing update touch -- lives in LDS as a circular window
-  // (entry (r, c) at [(r mod W) * (W + 1) + (c mod W)]; the padded row stride keeps column walks conflict free), so a block
-  // column is: the diagonal block factorised by wave 0 in registers, the panel rows solved against it, the trailing update
-  // -- all LDS to LDS -- and two streams that nobody waits for: the finished columns go out to the band in memory, the NB
-  // rows that enter the window next come in (requested at the top of the iteration, stored at its end).  band_cholesky_solve
-  // above pays three dependent round trips to the L2 per block column for the same work: 23 us per block column on the
-  // shipped FSI3 case against ~4 here.  The forward substitution rides along (y is one more LDS vector, updated by the
-  // panel's threads); the backward substitution reads L back from memory.  Three workgroup barriers per block column.
+  // ------------------------------------------------------------------ banded Cholesky, LDS-window form (rounds 4-5)
+  // The same factorisation K = L L^T + substitutions for half bandwidths hbw <= BAND_LDS_W - BAND_NB + BAND_FAR_MAX.  The
+  // ACTIVE part of the matrix -- the BAND_LDS_W rows below the current block column -- lives in LDS as a circular window
+  // (entry (r, c) at [(r mod W) * (W + 1) + (c mod W)]); a block column never waits for the L2: the finished columns go
+  // out to the band in memory and the NB rows that enter the window next come in (requested at the top of an iteration)
+  // beside the arithmetic.  band_cholesky_solve above pays three dependent round trips to the L2 per block column.
   //
-  // FAR (round 5; half bandwidths up to BAND_LDS_W - BAND_NB + BAND_FAR_MAX = 160: the reference's 3D plate at degree 2 has
-  // 152): a block column's panel reaches nfar = hbw + NB - W rows BEYOND the window.  Their entries stay in the band in
-  // memory: the far panel rows are solved by wave 3 (values requested at the top of the iteration) and kept in LDS (sF)
-  // for the iteration; the trailing update of the 16 rows that enter the window next is applied to the registers that
-  // carry them in (pre[]), the update of the rows beyond those is a read-modify-write of the band in memory (one column's
-  // 24-32 rows contiguous), both beside the window's own trailing update.  The window itself never holds an entry with
-  // r - c >= W: when a row enters, its columns further left are finished.
+  // One block column (two workgroup barriers):
+  //   T1  the first tile column of the trailing update -- every panel row block against the block column's first 16 rows,
+  //       i.e. everything the NEXT block column's diagonal block and panel are made of; meanwhile the finished columns
+  //       are read into registers and the entering rows take the slots of the block's own rows
+  //   T2  waves 0-3: the next block column, diagonal block AND panel in one instruction stream (factor_block below);
+  //       waves 4-15: the other tiles of the trailing update; everybody: the finished columns out to memory
+  // factor_block: lane r < 16 of a wave holds row r of the diagonal block, lanes 16-63 hold 48 panel rows, all as 16
+  // registers; the right-looking elimination of the diagonal block (pivot, scale, 15 multiply-adds with the pivot
+  // column's entries read from the lanes of the diagonal rows) IS the panel rows' triangular solve when the same
+  // instructions run on their lanes, and with the right-hand side as a 17th column the forward substitution as well.
+  // Each of the four waves repeats the diagonal rows (no exchange between them), so a block column's panel costs no phase
+  // of its own: the dependent chain per block column is one tile + one 16-pivot elimination.
+  // The trailing update runs on the matrix cores (v_mfma_f64_16x16x4_f64, update_tile): a multiply-add loop reads
+  // 2 x 16 LDS operands per entry and was LDS-bandwidth bound.
+  //
+  // FAR (half bandwidths 113-160; the reference's 3D plate at degree 2 has 152): a block column's panel reaches nfar =
+  // hbw + NB - W rows BEYOND the window.  Their entries stay in the band in memory: far panel rows are lanes of
+  // factor_block like the others (loaded from / stored to memory, and kept in sF for the iteration's tiles); tiles of
+  // the 16 entering rows are tiles of the window; tiles of the rows beyond those are read-modify-writes of the band in
+  // memory, two tiles per wave at a time (update_mem_pair).  The window itself never holds an entry with r - c >= W: when
+  // a row enters, its columns further left are finished.
   constexpr int BAND_LDS_W = 128, BAND_FAR_MAX = 48;
   template <int D, bool FAR = false>
   __global__ __launch_bounds__(1024) void band_cholesky_lds(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
@@ -4315,7 +4324,7 @@ namespace mi
                                                             int32_t *flag, int do_solve, unsigned long long *dbg)
   {
     constexpr int NB = BAND_NB, W = BAND_LDS_W, LD = W + 1;
-    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0, tw0 = 0; // diagnostic (dbg != null): clocks per phase, thread 0
+    unsigned long long tacc[3] = {0, 0, 0}, tlast = 0; // diagnostic (dbg != null): clocks per phase, thread 0
 #define BAND_STAMP(i_)                                             \
   do                                                               \
     {                                                              \
@@ -4328,12 +4337,12 @@ namespace mi
     }                                                              \
   while (0)
     static_assert(W % NB == 0, "a block column must not wrap inside the window");
-    __shared__ double S[W * LD];  // slot row (r mod W), slot column (c mod W); slots outside a row's band hold ZERO
-    __shared__ double yv[W];      // right-hand side / y of the rows in the window (circular)
-    __shared__ double sy[NB];     // y of the current block
-    __shared__ double srd[NB];    // 1 / L_cc of the current block
-    __shared__ double sL[NB][NB + 1];
-    __shared__ double sF[FAR ? BAND_FAR_MAX : 1][NB + 1]; // FAR: the panel rows beyond the window (row rF0 + f)
+    __shared__ double S[W * LD];      // slot row (r mod W), slot column (c mod W); slots outside a row's band hold ZERO
+    __shared__ double yv[W];          // right-hand side / y of the rows in the window (circular)
+    __shared__ double sL[NB][NB + 1]; // the current diagonal block of L (for the stream of finished columns)
+    __shared__ double sy[NB];         // (backward substitution)
+    __shared__ double sF[FAR ? 2 : 1][FAR ? BAND_FAR_MAX : 1][NB + 1]; // FAR: panel rows beyond the window (row rF0 + f);
+                                                                       // two copies: one read by tiles, one being made
     const int tid = threadIdx.x, ld = hbw + 1;
     // ---- right-hand side into band order (memory)
     if (do_solve)
@@ -4353,103 +4362,156 @@ namespace mi
     if (do_solve && tid < W)
       yv[tid] = tid < n ? work[tid] : 0.0;
     __syncthreads();
-    // diagonal block at j0: wave 0, lane = row, the block in registers, other rows' entries by lane reads.  Straight-line
-    // code on purpose (no lane or block-size conditions): entries above the diagonal are computed and never used, a short
-    // last block is padded with the identity -- so the scheduler can fill the latency of one pivot's chain (lane read,
-    // 1 / sqrt, two Newton steps) with the updates the previous pivot left behind
-    auto diagonal_block = [&](int j0) {
-      const int           nb = min(NB, n - j0), jc = j0 & (W - 1);
-      double              row[NB];
-      int                 lr = tid < NB ? tid : NB - 1;
-      if constexpr (FAR) // (registers are short there: keeps the 16 identity constants below from being hoisted and spilled)
-        asm volatile("" : "+v"(lr));
-      const double *const rp = &S[((j0 + lr) & (W - 1)) * LD + jc];
+    // Block column jb, diagonal block and panel (waves 0-3; see the head comment).  Straight-line code on purpose (no lane
+    // or block-size conditions in the elimination): entries above the diagonal are computed and never used, a short last
+    // block is padded with the identity -- so the scheduler can fill the latency of one pivot's chain (lane read,
+    // 1 / sqrt, two Newton steps) with the updates the previous pivot left behind.  fb: which copy of sF to fill.
+    auto factor_block = [&](int jb, int fb) {
+      const int nbb = min(NB, n - jb), jcb = jb & (W - 1), rb = jb + nbb;
+      const int mallb = min(n, rb + hbw) - rb, mb = FAR ? min(mallb, W - nbb) : mallb;
+      int       ln = tid & 63;
+      if constexpr (FAR) // (registers are short there: keeps lane constants from being hoisted out of the loop and spilled)
+        asm volatile("" : "+v"(ln));
+      const bool isdiag = ln < NB;
+      const int  q = (tid >> 6) * (64 - NB) + ln - NB; // panel row rb + q
+      const int  r = isdiag ? jb + ln : rb + q;
+      const bool inwin = !isdiag && q < mb, isfar = FAR && !isdiag && q >= mb && q < mallb;
+      double     row[NB], y = 0.0;
+      double    *rp = &S[(r & (W - 1)) * LD + jcb];
+      double    *pb = band + (int64_t(jb) * ld + (r - jb)); // far rows: entry (r, jb + c) at pb[c (ld - 1)]
+      if (isdiag)
+        {
 #pragma unroll
-      for (int c = 0; c < NB; ++c)
-        row[c] = (lr < nb && c <= lr && c < nb) ? rp[c] : (lr == c ? 1.0 : 0.0);
-      double rdl = 1.0; // 1 / L_cc of this lane's own column
-      bool   bad = false;
+          for (int c = 0; c < NB; ++c)
+            row[c] = (ln < nbb && c <= ln && c < nbb) ? rp[c] : (ln == c ? 1.0 : 0.0);
+          if (do_solve && ln < nbb)
+            y = yv[r & (W - 1)];
+        }
+      else if (inwin)
+        {
+#pragma unroll
+          for (int c = 0; c < NB; ++c)
+            row[c] = rp[c];
+          if (do_solve)
+            y = yv[r & (W - 1)];
+        }
+      else if (isfar)
+        {
+#pragma unroll
+          for (int c = 0; c < NB; ++c)
+            row[c] = (r - jb - c <= hbw) ? pb[int64_t(c) * (ld - 1)] : 0.0;
+          if (do_solve)
+            y = work[r];
+        }
+      else
+        {
+#pragma unroll
+          for (int c = 0; c < NB; ++c)
+            row[c] = 0.0;
+        }
+      bool bad = false;
 #pragma unroll
       for (int c = 0; c < NB; ++c)
         {
           const double d  = lane_value(row[c], c);
           bad             = bad || !(d > 0.0);
           const double rd = rsqrt_nr(d);
-          rdl             = (tid == c) ? rd : rdl;
           row[c] *= rd; // column c of L (the diagonal becomes sqrt(d))
 #pragma unroll
           for (int c2 = c + 1; c2 < NB; ++c2)
             row[c2] = fma(-row[c], lane_value(row[c], c2), row[c2]); // - L[r][c] L[c2][c]
+          const double yc = lane_value(y, c) * rd;                   // y_c is final: the rows below it take it
+          y               = ln == c ? yc : (ln > c ? fma(-row[c], yc, y) : y);
         }
       if (bad && tid == 0)
         flag[0] = 1;
-      if (tid < NB)
+      if (isdiag)
         {
-          double *const wp = &S[((j0 + tid) & (W - 1)) * LD + jc];
+          if (tid < NB) // (wave 0 keeps the diagonal block; the other waves only needed it)
+            {
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                sL[tid][c] = (tid < nbb && c <= tid) ? row[c] : (tid == c ? 1.0 : 0.0);
+              if (do_solve && tid < nbb)
+                work[jb + tid] = y;
+            }
+        }
+      else if (inwin)
+        {
 #pragma unroll
           for (int c = 0; c < NB; ++c)
+            rp[c] = row[c];
+          if (do_solve)
+            yv[r & (W - 1)] = y;
+        }
+      else if constexpr (FAR)
+        {
+          const int f = q - mb; // (mb = W - NB wherever a far row exists)
+          if (isfar)
             {
-              const double v = (tid < nb && c <= tid) ? row[c] : (tid == c ? 1.0 : 0.0);
-              sL[tid][c]     = v;
-              if (tid < nb && c <= tid)
-                wp[c] = v;
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                {
+                  sF[fb][f][c] = row[c];
+                  if (r - jb - c <= hbw)
+                    pb[int64_t(c) * (ld - 1)] = row[c];
+                }
+              if (do_solve)
+                work[r] = y;
             }
-          srd[tid] = rdl;
+          else if (mallb > mb && f < BAND_FAR_MAX) // rows of sF past the panel: zero rows (whole tiles are multiplied)
+            {
+#pragma unroll
+              for (int c = 0; c < NB; ++c)
+                sF[fb][f][c] = 0.0;
+            }
         }
     };
-    // One 16 x 16 tile of the trailing update on the matrix cores (v_mfma_f64_16x16x4_f64, four of them for the block
-    // column's 16 columns): rows s0 + i of row block I against rows t0 + j of row block J <= I, D[i][j] = sum_k P[s0+i][k]
-    // P[t0+j][k] with the panel P in the window (S, the block's columns) or -- FAR -- in sF.  Operands: lane l holds
-    // A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the result D[(l >> 4) + 4 v][l & 15] in register v.  Panel rows
-    // past the band's edge or the matrix's end are zero rows, so whole tiles are safe.  The eight operand reads replace
-    // the 2 x 16 LDS reads PER ENTRY of a multiply-add loop: the update was LDS-bandwidth bound.
-    // Targets: the window (entering rows included: they are stored before the barrier in front of this), or -- rows
-    // beyond them -- the band in memory, with the tile transposed so that lanes walk a column's contiguous rows.
+    // One 16 x 16 tile of the trailing update: rows s0 + i of row block I against rows t0 + j of row block J <= I (blocks
+    // of 16 rows counted from r0), D[i][j] = sum_k P[s0+i][k] P[t0+j][k] with the panel P in the window (S, the block's
+    // columns) or -- FAR -- in sF.  Operands: lane l holds A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15], the
+    // result D[(l >> 4) + 4 v][l & 15] in register v.  Panel rows past the band's edge or the matrix's end are zero rows, so
+    // whole tiles are safe.  For tiles whose rows are in the window (the entering rows included).
+    // init: the tile's entries come from there (D layout) instead of from S -- a tile of rows that are not stored yet.
     typedef double v4f64 __attribute__((ext_vector_type(4)));
-    auto update_tile = [&](int I, int J, int j0, int jc, int r0, int rF0, int nfar) {
-      const int  lane = tid & 63, li = lane & 15, lk = lane >> 4;
-      const int  s0 = r0 + NB * I, t0 = r0 + NB * J;
-      double     a[4], b[4];
-      {
-        const int           rs = s0 + li, rt = t0 + li;
-        const double *const ps = (FAR && rs >= rF0) ? &sF[rs - rF0][0] : &S[(rs & (W - 1)) * LD + jc];
-        const double *const pt = (FAR && rt >= rF0) ? &sF[rt - rF0][0] : &S[(rt & (W - 1)) * LD + jc];
+    auto update_tile = [&](int I, int J, int jc, int r0, int rF0, int fb, const double *init) {
+      const int           lane = tid & 63, li = lane & 15, lk = lane >> 4;
+      const int           s0 = r0 + NB * I, t0 = r0 + NB * J, rs = s0 + li, rt = t0 + li;
+      const double *const ps = (FAR && rs >= rF0) ? &sF[fb][rs - rF0][0] : &S[(rs & (W - 1)) * LD + jc];
+      const double *const pt = (FAR && rt >= rF0) ? &sF[fb][rt - rF0][0] : &S[(rt & (W - 1)) * LD + jc];
+      double              a[4], b[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          {
-            a[kk] = ps[4 * kk + lk];
-            b[kk] = pt[4 * kk + lk];
-          }
-      }
+      for (int kk = 0; kk < 4; ++kk)
+        {
+          a[kk] = ps[4 * kk + lk];
+          b[kk] = pt[4 * kk + lk];
+        }
       v4f64 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
         d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], d, 0, 0, 0);
+      // (all four reads, then the four writes; an entry above the diagonal of a diagonal tile is the dead slot of a
+      // finished column: it is written back unchanged)
+      double *o[4], cur[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v)
         {
           const int sr = s0 + lk + 4 * v, tc = t0 + li;
-          if (I != J || tc <= sr)
-            S[(sr & (W - 1)) * LD + (tc & (W - 1))] -= d[v];
+          o[v]         = &S[(sr & (W - 1)) * LD + (tc & (W - 1))];
+          cur[v]       = init ? init[v] : *o[v];
         }
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        *o[v] = cur[v] - ((I != J || t0 + li <= s0 + lk + 4 * v) ? d[v] : 0.0);
     };
     // FAR: tiles whose rows lie beyond the entering ones live in the band in memory.  Transposed (D'[column t0 + lk + 4 v]
-    // [row s0 + li]: lanes walk a column's contiguous rows), and TWO tiles at a time: both tiles' old values are requested
-    // before either is stored -- one round trip to the L2 and one drain of the stores per pair (a wave's memory operations
-    // retire in order, so tile after tile would pay both per tile)
-    auto update_mem_pair = [&](int p0, int p1, int jc, int r0, int rF0, int nfar) {
-      const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
-      auto      block_of = [](int p) {
-        int I = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
-        while ((I + 1) * (I + 2) / 2 <= p)
-          ++I;
-        while (I * (I + 1) / 2 > p)
-          --I;
-        return I;
-      };
-      const int  I0 = block_of(p0), J0 = p0 - I0 * (I0 + 1) / 2, I1 = p1 >= 0 ? block_of(p1) : I0, J1 = p1 >= 0 ? p1 - I1 * (I1 + 1) / 2 : J0;
-      const int  sA = r0 + NB * I0, tA = r0 + NB * J0, sB = r0 + NB * I1, tB = r0 + NB * J1;
-      const bool two = p1 >= 0;
+    // [row s0 + li]: lanes walk a column's contiguous rows), and TWO tiles at a time (J1 < 0: one): both tiles' old values are
+    // requested before either is stored -- one round trip to the L2 and one drain of the stores per pair (a wave's memory
+    // operations retire in order, so tile after tile would pay both per tile)
+    auto update_mem_pair = [&](int I0, int J0, int I1, int J1, int jc, int r0, int rF0, int nfar, int fb) {
+      const int  lane = tid & 63, li = lane & 15, lk = lane >> 4;
+      const bool two = J1 >= 0;
+      const int  sA = r0 + NB * I0, tA = r0 + NB * J0, sB = two ? r0 + NB * I1 : sA, tB = two ? r0 + NB * J1 : tA;
       double     oldA[4], oldB[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v)
@@ -4465,8 +4527,8 @@ namespace mi
         }
       auto product = [&](int s0, int t0) {
         const int           rs = s0 + li, rt = t0 + li;
-        const double *const ps = &sF[rs - rF0][0]; // (rows beyond the window)
-        const double *const pt = rt >= rF0 ? &sF[rt - rF0][0] : &S[(rt & (W - 1)) * LD + jc];
+        const double *const ps = &sF[fb][rs - rF0][0]; // (rows beyond the window)
+        const double *const pt = rt >= rF0 ? &sF[fb][rt - rF0][0] : &S[(rt & (W - 1)) * LD + jc];
         v4f64               d  = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -4489,24 +4551,22 @@ namespace mi
             band[int64_t(tc) * ld + (sr - tc)] = oldB[v] - dB[v];
         }
     };
-    // Look-ahead (a block column's dependent chain is diagonal block -> panel -> update of the NEXT block column -> next
-    // diagonal block; the rest of the trailing update and the row streaming run beside the next diagonal block):
-    //   P   panel rows solved against the diagonal block (waves 0-1), y of the block (wave 2)
-    //   T1  the finished columns into registers, the new rows into the slots of the block's rows; the trailing update's
-    //       tile of the next diagonal block
-    //   T2  wave 0: next diagonal block  |  waves 1-15: the other tiles of the trailing update, y of the panel rows
-    //       everybody: the finished columns out to memory
-    if (tid < 64)
-      diagonal_block(0);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // this wave (a scalar: the tile loops branch on it)
+    if (tid < 256)
+      factor_block(0, 0);
     __syncthreads();
     if (dbg && tid == 0)
       tlast = __builtin_amdgcn_s_memtime();
     for (int j0 = 0; j0 < n; j0 += NB)
       {
-        const int nb = min(NB, n - j0), jc = j0 & (W - 1); // the block's columns are the slots jc .. jc + NB - 1
+        const int nb = min(NB, n - j0), jc = j0 & (W - 1), fb = (j0 / NB) & 1; // the block's columns: slots jc .. jc + NB - 1
         // the panel: mall rows below the block reach into its columns, m of them in the window, nfar beyond it (FAR)
         const int r0 = j0 + nb, mall = min(n, r0 + hbw) - r0, m = FAR ? min(mall, W - nb) : mall, nfar = mall - m, rF0 = j0 + W;
-        // the rows that enter the window when this block column is done: requested now, stored at the end
+        // row blocks of 16 below the block column: nbw in the window, then (FAR) the entering rows and the rows beyond
+        const int nbw = (m + NB - 1) / NB, nbf = FAR ? (nfar + NB - 1) / NB : 0, nbr = nbw + nbf;
+        const int nwin = FAR ? min(nbr, W / NB) : nbr; // row blocks whose tiles are tiles of the window
+        // the rows that enter the window when this block column is done: requested now (an iteration ahead is no faster: T1
+        // is as long as its tile; and FAR could not -- the tiles of the iteration before still update those rows in memory)
         double pre[2], prey = 0.0;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
@@ -4514,103 +4574,58 @@ namespace mi
             const int idx = tid + u * 1024, rr = idx >> 7, cs = idx & (W - 1), rn = j0 + W + rr;
             const int c = rn - ((rn - cs) & (W - 1)), k = rn - c;
             // (c >= 0: rn >= W.  FAR: a slot whose column belongs to this block column is dead -- the entry is finished
-            // in memory by the far panel below)
+            // in memory by the far panel row's lane)
             pre[u] = (rn < n && k <= hbw && (!FAR || c >= r0)) ? band[int64_t(c) * ld + k] : 0.0;
           }
         if (do_solve && tid < NB && j0 + W + tid < n)
           prey = work[j0 + W + tid];
-        // FAR: the far panel rows' entries in the block's columns come from memory (wave 3, one row per lane), requested here
-        double     xr[NB];
-        const int  ff   = tid - 192;
-        const bool farp = FAR && ff >= 0 && ff < nfar; // (nfar > 0: rows below the block, so nb = NB)
+        // FAR: the entering rows' entries in the next block column (their tile of the first tile column) come in through
+        // the wave that updates them, in the tile's layout -- the other waves' stores of entering rows are not visible to it
+        // before the barrier
+        constexpr int WENTER = 4 + W / NB - 1; // that wave
+        double        pre7[FAR ? 4 : 1];
         if constexpr (FAR)
-          if (farp)
-            {
-              // (entry (r, j0 + c) at band[(j0 + c) ld + r - j0 - c]: a walk of stride ld - 1 from column j0)
-              const double *pb = band + (int64_t(j0) * ld + (rF0 + ff - j0));
-#pragma unroll
-              for (int c = 0; c < NB; ++c, pb += ld - 1)
-                xr[c] = (W + ff - c <= hbw) ? *pb : 0.0;
-            }
-        // ---- P: the rows below the block that reach into its columns, one triangular solve per row; a slot outside the
-        // row's band holds zero and stays zero (L has the band of A)
-        if constexpr (FAR)
-          if (ff >= 0 && ff < BAND_FAR_MAX && !farp) // rows of sF past the panel: zero rows (whole tiles are multiplied)
+          if (wv == WENTER)
             {
 #pragma unroll
-              for (int c = 0; c < NB; ++c)
-                sF[ff][c] = 0.0;
+              for (int v = 0; v < 4; ++v)
+                {
+                  const int rn = rF0 + ((tid & 63) >> 4) + 4 * v, tc = r0 + (tid & 15);
+                  pre7[v]      = (rn < n && rn - tc <= hbw) ? band[int64_t(tc) * ld + (rn - tc)] : 0.0;
+                }
             }
-        if (tid < m || farp) // (m <= W - NB = 112: waves 0 and 1; FAR: and the far rows' lanes of wave 3)
+        // ---- T1: the first tile column (one tile per wave, waves 4 ...), before anything that waits for the rows requested above
+        if (wv >= 4)
           {
-            // right-looking in registers: a finished entry updates all later ones at once (independent multiply-adds; the
-            // dependent chain is one multiply per column, not a sum over the columns before it)
-            double *const rp = &S[((r0 + tid) & (W - 1)) * LD + jc];
-            if (!farp)
+            const int I = wv - 4;
+            if (I < nwin && I < W / NB - 1)
+              update_tile(I, 0, jc, r0, rF0, fb, nullptr);
+            if constexpr (FAR)
               {
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                  xr[c] = rp[c];
-              }
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-              {
-                xr[c] *= srd[c];
-#pragma unroll
-                for (int c2 = c + 1; c2 < NB; ++c2)
-                  xr[c2] = fma(-xr[c], sL[c2][c], xr[c2]);
-              }
-            if (!farp)
-              {
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                  rp[c] = xr[c];
-              }
-            else if constexpr (FAR)
-              {
-                // a far row: finished entries back to the band in memory, the row into sF for this iteration's updates
-                double *pb = band + (int64_t(j0) * ld + (rF0 + ff - j0));
-#pragma unroll
-                for (int c = 0; c < NB; ++c, pb += ld - 1)
+                if (wv == WENTER)
                   {
-                    sF[ff][c] = xr[c];
-                    if (W + ff - c <= hbw)
-                      *pb = xr[c];
-                  }
-              }
-          }
-        else if (do_solve && tid >= 128 && tid < 192)
-          {
-            // meanwhile wave 2: y of the block, column sweeps (lane = row of the block)
-            const int l = tid - 128;
-            double    w = l < nb ? yv[(j0 + l) & (W - 1)] : 0.0;
+                    if (nfar > 0)
+                      update_tile(W / NB - 1, 0, jc, r0, rF0, fb, pre7);
+                    else // (no far rows: the entries are stored as they came)
+                      {
 #pragma unroll
-            for (int c = 0; c < NB; ++c)
-              {
-                const double yc = lane_value(w, c) * srd[c];
-                if (l == c)
-                  w = yc;
-                else if (l > c && l < NB)
-                  w -= sL[l][c] * yc;
-              }
-            if (l < NB)
-              {
-                sy[l] = l < nb ? w : 0.0;
-                if (l < nb)
-                  work[j0 + l] = w;
+                        for (int v = 0; v < 4; ++v)
+                          S[((rF0 + ((tid & 63) >> 4) + 4 * v) & (W - 1)) * LD + ((r0 + (tid & 15)) & (W - 1))] = pre7[v];
+                      }
+                  }
+                if (I == W / NB && nbr > W / NB) // (one wave: the tiles (8, 0) and (9, 0))
+                  update_mem_pair(W / NB, 0, W / NB + 1, nbr > W / NB + 1 ? 0 : -1, jc, r0, rF0, nfar, fb);
               }
           }
-        __syncthreads();
-        BAND_STAMP(0);
-        // ---- T1: the finished columns leave the window: into registers now, out to the band in memory as the iteration's LAST
+        // the finished columns leave the window: into registers now, out to the band in memory as the iteration's LAST
         // memory operation -- the memory counter retires in order, and the new rows' loads must not queue behind these
-        // stores.  (The block's own rows come from sL: their slots in S are dead since the diagonal block was factorised,
-        // which is what lets the new rows take them right here.)
+        // stores.  (The block's own rows come from sL: their slots in S are dead since the block was factorised, which is
+        // what lets the new rows take them right here.)
         double wb[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u)
           {
-            // (entry k of finished column cc; rows of the window only: a FAR column's rows beyond it are the far panel's)
+            // (entry k of finished column cc; rows of the window only: a FAR column's rows beyond it went out from their lanes)
             const int idx = tid + u * 1024, cc = idx >> 7, k = idx & (W - 1), r = j0 + cc + k;
             wb[u] = (cc < nb && k <= hbw && r < n && r < j0 + W) ? (r < r0 ? sL[cc + k][cc] : S[(r & (W - 1)) * LD + jc + cc]) : 0.0;
           }
@@ -4619,79 +4634,54 @@ namespace mi
         for (int u = 0; u < 2; ++u)
           {
             const int idx = tid + u * 1024, rr = idx >> 7, cs = idx & (W - 1);
-            S[((j0 + W + rr) & (W - 1)) * LD + cs] = pre[u];
+            if (!FAR || ((cs - r0) & (W - 1)) >= NB) // (FAR: the slots of the next block column: see pre7)
+              S[((j0 + W + rr) & (W - 1)) * LD + cs] = pre[u];
           }
         if (do_solve && tid < NB)
           yv[(j0 + W + tid) & (W - 1)] = prey;
-        // the next DIAGONAL block first (what the next factorisation waits for): tile (0, 0) of the trailing update
-        if (tid >= 512 && tid < 576 && m > 0)
-          update_tile(0, 0, j0, jc, r0, rF0, nfar);
         __syncthreads();
-        BAND_STAMP(1);
-        // ---- T2: the next diagonal block (wave 0) beside the rest of the trailing update (waves 1-15, one 16 x 16 tile of
-        // it at a time on the matrix cores)
-        if (tid < 64)
+        BAND_STAMP(0);
+        // ---- T2
+        if (wv < 4)
           {
             if (r0 < n)
-              diagonal_block(r0);
+              factor_block(r0, fb ^ 1);
             if (dbg && tid == 0)
-              tacc[3] += __builtin_amdgcn_s_memtime() - tlast; // (of the third phase: until wave 0 is through)
+              tacc[2] += __builtin_amdgcn_s_memtime() - tlast; // (of T2: until wave 0 is through)
           }
         else
           {
-            // row blocks of 16 below the block column: nbw in the window, then (FAR) the entering rows and the rows beyond
-            const int nbw = (m + NB - 1) / NB, nbf = FAR ? (nfar + NB - 1) / NB : 0, nbr = nbw + nbf;
-            const int ntile = nbr * (nbr + 1) / 2;
-            // (FAR: the tiles of the last nbr - 8 row blocks live in memory: at most 19, in pairs, on the first waves)
-            const int wv = (tid - 64) >> 6, pmem = FAR && nbr > 8 ? 8 * 9 / 2 : ntile;
-            if (dbg && tid == 64)
-              tw0 = __builtin_amdgcn_s_memtime();
-            for (int p = 1 + wv; p < min(pmem, ntile); p += 15) // (tile 0 is done)
-              {
-                int I = int((sqrtf(8.0f * float(p) + 1.0f) - 1.0f) * 0.5f);
-                while ((I + 1) * (I + 2) / 2 <= p)
-                  ++I;
-                while (I * (I + 1) / 2 > p)
-                  --I;
-                update_tile(I, p - I * (I + 1) / 2, j0, jc, r0, rF0, nfar);
-              }
-            if (dbg && tid == 64)
-              tacc[4] += __builtin_amdgcn_s_memtime() - tw0; // wave 1: its window tiles done
+            // the tiles (I, J) with J >= 1, twelve waves.  FAR: those of the last nbr - 8 row blocks live in memory, at most
+            // 17, in pairs on the first nine of these waves -- first thing, the window's tiles run behind their stores
+            const int w12 = wv - 4;
             if constexpr (FAR)
-              if (pmem + 2 * wv < ntile)
-                update_mem_pair(pmem + 2 * wv, pmem + 2 * wv + 1 < ntile ? pmem + 2 * wv + 1 : -1, jc, r0, rF0, nfar);
-            if (dbg && tid == 64)
-              tacc[5] += __builtin_amdgcn_s_memtime() - tw0; // ... its memory tiles issued
-            if (do_solve && tid >= 896) // y of the panel's rows: y_r -= L[r][block] . y_block
+              if (nbr > W / NB)
+                {
+                  const int nm0 = W / NB, nm = nm0 + (nbr > W / NB + 1 ? W / NB + 1 : 0); // tiles of row block 8 (J = 1 .. 8), of 9 (1 .. 9)
+                  const int q0 = 2 * w12, q1 = q0 + 1;
+                  if (q0 < nm)
+                    {
+                      const int I0 = q0 < nm0 ? W / NB : W / NB + 1, J0 = q0 < nm0 ? q0 + 1 : q0 - nm0 + 1;
+                      const int I1 = q1 < nm0 ? W / NB : W / NB + 1, J1 = q1 < nm ? (q1 < nm0 ? q1 + 1 : q1 - nm0 + 1) : -1;
+                      update_mem_pair(I0, J0, I1, J1, jc, r0, rF0, nfar, fb);
+                    }
+                }
+            // window tiles: (I, J), 1 <= J <= I < nwin, in rows of I tiles
+            int I = 1, J = 1 + w12;
+            while (J > I)
               {
-                const int t = tid - 896;
-                if (t < m)
-                  {
-                    const int           r  = r0 + t;
-                    const double *const rp = &S[(r & (W - 1)) * LD + jc];
-                    double              dy = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NB; ++c)
-                      dy += rp[c] * sy[c];
-                    yv[r & (W - 1)] -= dy;
-                  }
-                else if (FAR && t - m < min(nfar, NB)) // (m = W - NB here) the entering rows
-                  {
-                    double dy = 0.0;
-#pragma unroll
-                    for (int c = 0; c < NB; ++c)
-                      dy += sF[t - m][c] * sy[c];
-                    yv[(rF0 + t - m) & (W - 1)] -= dy;
-                  }
+                J -= I;
+                ++I;
               }
-            if (FAR && do_solve && tid >= 832 && tid < 864 && tid - 832 + NB < nfar) // the rows beyond them: y in memory
+            while (I < nwin)
               {
-                const int f  = tid - 832 + NB;
-                double    dy = 0.0;
-#pragma unroll
-                for (int c = 0; c < NB; ++c)
-                  dy += sF[f][c] * sy[c];
-                work[rF0 + f] -= dy;
+                update_tile(I, J, jc, r0, rF0, fb, nullptr);
+                J += 12;
+                while (J > I)
+                  {
+                    J -= I;
+                    ++I;
+                  }
               }
           }
         // the finished columns go out
@@ -4702,21 +4692,11 @@ namespace mi
             if (cc < nb && k <= hbw && r < n && r < j0 + W)
               band[int64_t(j0 + cc) * ld + k] = wb[u];
           }
-        if (dbg && tid == 64)
-          {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tacc[6] += __builtin_amdgcn_s_memtime() - tw0; // ... its stores drained
-          }
         __syncthreads();
-        if (dbg && tid == 64)
-          tacc[7] += __builtin_amdgcn_s_memtime() - tw0; // ... the barrier behind it
-        BAND_STAMP(2);
+        BAND_STAMP(1);
       }
     if (dbg && tid == 0)
-      for (int i = 0; i < 4; ++i)
-        dbg[i] = tacc[i];
-    if (dbg && tid == 64)
-      for (int i = 4; i < 8; ++i)
+      for (int i = 0; i < 3; ++i)
         dbg[i] = tacc[i];
 #undef BAND_STAMP
     if (!do_solve)
@@ -5395,8 +5375,8 @@ namespace mi
             hipMemcpy(h, d_dbg, sizeof(h), hipMemcpyDeviceToHost);
             hipFree(d_dbg);
             ++shown;
-            fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: panel + y %llu, next block's columns %llu, next "
-                            "diagonal block beside the trailing update %llu (wave 0 through after %llu; wave 1: window tiles %llu, memory tiles %llu, stores drained %llu, barrier %llu)\n", n, hbw, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+            fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: first tile column %llu, next block column "
+                            "beside the other tiles %llu (waves 0-3 through after %llu)\n", n, hbw, h[0], h[1], h[2]);
           }
         return 0;
       }
