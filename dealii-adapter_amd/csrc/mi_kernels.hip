@@ -4063,6 +4063,16 @@ namespace mi
   // factor_only / solve_only split the two halves (the linear model factorises its constant matrix once).
   // value of lane `lane` (uniform) in every lane: two v_readlane_b32 into scalar registers -- a few cycles, where __shfl goes
   // through the LDS crossbar (ds_bpermute) and costs a hundred
+  // f(integral_constant<int, I>) for I = I0 .. N - 1 (loop bodies that need the index as a constant expression)
+  template <int I, int N, typename F>
+  __device__ __forceinline__ void static_for(F &&f)
+  {
+    if constexpr (I < N)
+      {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+      }
+  }
   __device__ __forceinline__ double lane_value(double v, int lane)
   {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -4409,10 +4419,10 @@ namespace mi
           for (int c = 0; c < NB; ++c)
             row[c] = 0.0;
         }
-      bool bad = false;
-#pragma unroll
-      for (int c = 0; c < NB; ++c)
-        {
+      bool bad  = false;
+      int  yflo = 0, yfhi = 0; // the finished y of the diagonal rows, lane c = row c
+      static_for<0, NB>([&](auto cc) {
+          constexpr int c = decltype(cc)::value; // (a constant: v_writelane takes its lane as an immediate)
           const double d  = lane_value(row[c], c);
           bad             = bad || !(d > 0.0);
           const double rd = rsqrt_nr(d);
@@ -4420,9 +4430,17 @@ namespace mi
 #pragma unroll
           for (int c2 = c + 1; c2 < NB; ++c2)
             row[c2] = fma(-row[c], lane_value(row[c], c2), row[c2]); // - L[r][c] L[c2][c]
-          const double yc = lane_value(y, c) * rd;                   // y_c is final: the rows below it take it
-          y               = ln == c ? yc : (ln > c ? fma(-row[c], yc, y) : y);
-        }
+          // y_c = y_c / L_cc is final: written into lane c of a register of its own (v_writelane: no lane masks), and the
+          // rows below take it -- the multiply-add runs on every lane, like the ones above; what it leaves on the lanes of
+          // finished diagonal rows is not used
+          const double ys  = y * rd;
+          const int    ylo = __builtin_amdgcn_readlane(__double2loint(ys), c), yhi = __builtin_amdgcn_readlane(__double2hiint(ys), c);
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(yflo) : "s"(ylo), "n"(c));
+          asm("v_writelane_b32 %0, %1, %2" : "+v"(yfhi) : "s"(yhi), "n"(c));
+          y                = fma(-row[c], __hiloint2double(yhi, ylo), y);
+      });
+      if (isdiag)
+        y = __hiloint2double(yfhi, yflo);
       if (bad && tid == 0)
         flag[0] = 1;
       if (isdiag)
@@ -4692,7 +4710,13 @@ namespace mi
             if (cc < nb && k <= hbw && r < n && r < j0 + W)
               band[int64_t(j0 + cc) * ld + k] = wb[u];
           }
-        __syncthreads();
+        // (nothing the next iterations load from memory was stored by this one -- the finished columns and y are read again
+        // after the loop -- so the barrier orders the LDS only and the stores drain beside the next tile; FAR: the far rows
+        // ARE re-read, the full barrier stays)
+        if constexpr (FAR)
+          __syncthreads();
+        else
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         BAND_STAMP(1);
       }
     if (dbg && tid == 0)
