@@ -4427,9 +4427,24 @@ namespace mi
           bad             = bad || !(d > 0.0);
           const double rd = rsqrt_nr(d);
           row[c] *= rd; // column c of L (the diagonal becomes sqrt(d))
+          // - L[r][c] L[c2][c]; the lane reads four ahead of their multiply-adds: a scalar register written by a lane read
+          // is not ready for the next instruction, and one pair after the other costs 21 clocks per entry against 15 this
+          // way (tools/probe/fp64_issue.hip)
 #pragma unroll
-          for (int c2 = c + 1; c2 < NB; ++c2)
-            row[c2] = fma(-row[c], lane_value(row[c], c2), row[c2]); // - L[r][c] L[c2][c]
+          for (int c2 = c + 1; c2 < NB; c2 += 4)
+            {
+              double l4[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (c2 + i < NB)
+                  l4[i] = lane_value(row[c], c2 + i);
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                if (c2 + i < NB)
+                  row[c2 + i] = fma(-row[c], l4[i], row[c2 + i]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
           // y_c = y_c / L_cc is final: written into lane c of a register of its own (v_writelane: no lane masks), and the
           // rows below take it -- the multiply-add runs on every lane, like the ones above; what it leaves on the lanes of
           // finished diagonal rows is not used

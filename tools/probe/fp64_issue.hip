@@ -40,6 +40,41 @@ __global__ void probe(double *out, unsigned long long *t, int active_waves)
               r[i] = fma(-x, lane_value(x, i), r[i]);
             x += 1e-12;
           }
+        else if (MODE == 4) // 16 groups, lane reads in batches of four ahead of their multiply-adds
+          {
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 4)
+              {
+                double l[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  l[i] = lane_value(x, i0 + i);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  r[i0 + i] = fma(-x, l[i], r[i0 + i]);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            x += 1e-12;
+          }
+        else if (MODE == 5) // 16 groups through the LDS crossbar (ds_bpermute) instead of scalar lane reads
+          {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              {
+                const int    lo = __builtin_amdgcn_ds_bpermute(4 * i, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(4 * i, __double2hiint(x));
+                r[i] = fma(-x, __hiloint2double(hi, lo), r[i]);
+              }
+            x += 1e-12;
+          }
+        else if (MODE == 6) // only the lane reads (32 v_readlane_b32), results summed on the scalar side
+          {
+            int acc = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+              acc += __builtin_amdgcn_readlane(__double2loint(x), i) ^ __builtin_amdgcn_readlane(__double2hiint(x), i);
+            x += 1e-12 * (acc & 1);
+          }
         else if (MODE == 3) // 16 independent f32 multiply-adds (for scale)
           {
             float f[16];
@@ -73,9 +108,10 @@ int main()
   unsigned long long *t, h[2];
   hipMalloc(&out, 1024 * 8);
   hipMalloc(&t, 16);
-  const char *names[4] = {"16 independent f64 fma", "16 dependent f64 fma", "16 x (lane read + f64 fma)", "16 f64->f32 cvt + f32 fma + cvt back"};
-  for (int mode = 0; mode < 4; ++mode)
-    for (int cfg = 0; cfg < 3; ++cfg)
+  const char *names[7] = {"16 independent f64 fma", "16 dependent f64 fma", "16 x (lane read + f64 fma)", "16 f64->f32 cvt + f32 fma + cvt back",
+                          "16 x (lane read + f64 fma), reads 4 ahead", "16 x (ds_bpermute x 2 + f64 fma)", "16 x 2 v_readlane_b32 alone"};
+  for (int mode = 0; mode < 7; ++mode)
+    for (int cfg = 0; cfg < 1; ++cfg)
       {
         const int threads = cfg == 0 ? 64 : 1024, act = cfg == 0 ? 1 : (cfg == 1 ? 4 : 16);
         for (int rep = 0; rep < 2; ++rep)
@@ -86,8 +122,14 @@ int main()
               hipLaunchKernelGGL(probe<1>, dim3(1), dim3(threads), 0, 0, out, t, act);
             else if (mode == 2)
               hipLaunchKernelGGL(probe<2>, dim3(1), dim3(threads), 0, 0, out, t, act);
-            else
+            else if (mode == 3)
               hipLaunchKernelGGL(probe<3>, dim3(1), dim3(threads), 0, 0, out, t, act);
+            else if (mode == 4)
+              hipLaunchKernelGGL(probe<4>, dim3(1), dim3(threads), 0, 0, out, t, act);
+            else if (mode == 5)
+              hipLaunchKernelGGL(probe<5>, dim3(1), dim3(threads), 0, 0, out, t, act);
+            else
+              hipLaunchKernelGGL(probe<6>, dim3(1), dim3(threads), 0, 0, out, t, act);
             hipDeviceSynchronize();
           }
         hipMemcpy(h, t, 16, hipMemcpyDeviceToHost);
