@@ -4354,6 +4354,7 @@ namespace mi
     __shared__ double sF[FAR ? 2 : 1][FAR ? BAND_FAR_MAX : 1][NB + 1]; // FAR: panel rows beyond the window (row rF0 + f);
                                                                        // two copies: one read by tiles, one being made
     const int tid = threadIdx.x, ld = hbw + 1;
+    const unsigned long long tk0 = (dbg && tid == 0) ? __builtin_amdgcn_s_memtime() : 0;
     // ---- right-hand side into band order (memory)
     if (do_solve)
       for (int i = tid; i < n; i += 1024)
@@ -4589,7 +4590,10 @@ namespace mi
       factor_block(0, 0);
     __syncthreads();
     if (dbg && tid == 0)
-      tlast = __builtin_amdgcn_s_memtime();
+      {
+        tlast  = __builtin_amdgcn_s_memtime();
+        dbg[3] = tlast - tk0; // before the loop: right-hand side, first window, first block column
+      }
     for (int j0 = 0; j0 < n; j0 += NB)
       {
         const int nb = min(NB, n - j0), jc = j0 & (W - 1), fb = (j0 / NB) & 1; // the block's columns: slots jc .. jc + NB - 1
@@ -4741,50 +4745,104 @@ namespace mi
     if (!do_solve)
       return;
     __syncthreads();
-    // ---- backward substitution L^T x = y (L from memory), as in band_cholesky_solve
-    auto A = [&](int r, int c) -> double & { return band[int64_t(c) * ld + (r - c)]; };
-    for (int j0 = ((n - 1) / NB) * NB; j0 >= 0; j0 -= NB)
+    // ---- backward substitution L^T x = y, L from memory.  A block column is: s_c = sum_r L[r][c] x[r] over the rows below
+    // the block (wave c = column c, a wave sum), then the block's own 16 unknowns swept by wave 0.  Nothing in it waits for
+    // the L2 (band_cholesky_solve pays two round trips per block column): x lives in LDS (the window is free now; systems
+    // beyond its 16.5 k entries keep x in memory), and the entries of L that a block column needs -- up to three per
+    // thread for the sums, one per thread of the diagonal block -- are requested one block column ahead.
+    auto          A  = [&](int r, int c) -> double & { return band[int64_t(c) * ld + (r - c)]; };
+    const bool    xl = n <= W * LD; // x in LDS
+    double *const xs = S;
+    if (xl)
+      for (int i = tid; i < n; i += 1024)
+        xs[i] = work[i];
+    constexpr int NA = (BAND_LDS_W - BAND_NB + BAND_FAR_MAX + 63) / 64; // rows below a block, per lane of a column's wave
+    double        acur[NA], dcur = 0.0;
+    auto          request = [&](int j0, double *a, double &dd) {
+      const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0, c = tid >> 6, l = tid & 63;
+#pragma unroll
+      for (int u = 0; u < NA; ++u)
+        {
+          const int t = l + 64 * u;
+          a[u]        = (j0 >= 0 && c < nb && t < m && r0 + t - (j0 + c) <= hbw) ? A(r0 + t, j0 + c) : 0.0;
+        }
+      const int r = tid / NB, cc = tid % NB;
+      dd          = (j0 >= 0 && tid < NB * NB && r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
+    };
+    const int jlast = ((n - 1) / NB) * NB;
+    request(jlast, acur, dcur);
+    __syncthreads();
+    for (int j0 = jlast; j0 >= 0; j0 -= NB)
       {
         const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        double    anext[NA], dnext;
+        request(j0 - NB, anext, dnext); // (below the first block column: zeros, nothing is loaded)
         {
           const int c = tid >> 6, l = tid & 63;
           double    sacc = 0.0;
-          if (c < nb)
-            for (int t = l; t < m; t += 64)
-              if (r0 + t - (j0 + c) <= hbw)
-                sacc += A(r0 + t, j0 + c) * work[r0 + t];
+#pragma unroll
+          for (int u = 0; u < NA; ++u)
+            {
+              const int t = l + 64 * u;
+              if (t < m)
+                sacc += acur[u] * (xl ? xs[r0 + t] : work[r0 + t]);
+            }
           sacc = wave_sum(sacc);
-          if (l == 0 && c < NB)
+          if (l == 0)
             sy[c] = sacc;
           if (tid < NB * NB)
-            {
-              const int r = tid / NB, cc = tid % NB;
-              sL[r][cc]   = (r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
-            }
+            sL[tid / NB][tid % NB] = dcur; // (outside the band or the block: zero)
         }
-        __syncthreads();
+        if (xl)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (the requests for the next block stay in flight)
+        else
+          __syncthreads();
         if (tid < 64)
           {
-            double       w  = tid < nb ? work[j0 + tid] - sy[tid] : 0.0;
-            const double ri = tid < nb ? 1.0 / sL[tid][tid] : 1.0; // all reciprocals at once, off the sweep's chain
-            for (int q = nb - 1; q >= 0; --q)
-              {
-                const double xq = lane_value(w, q) * lane_value(ri, q);
-                if (tid == q)
-                  w = xq;
-                else if (tid < q)
-                  w -= sL[q][tid] * xq;
-              }
+            // lane t = column t of the block, swept from the last row upwards: x_q = w_q / L_qq goes into lane q of a register
+            // of its own (v_writelane), every lane takes w -= L[q][t] x_q (zero above the diagonal: the lanes of finished
+            // unknowns keep what nobody reads)
+            const int tt = tid < NB ? tid : 0;
+            double    col[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              col[q] = sL[q][tt];
+            const double dg = sL[tt][tt];
+            double       w  = tid < nb ? (xl ? xs[j0 + tid] : work[j0 + tid]) - sy[tid] : 0.0;
+            const double ri = tid < nb ? 1.0 / dg : 1.0;
+            int          xflo = 0, xfhi = 0;
+            static_for<0, NB>([&](auto qq) {
+              constexpr int q   = NB - 1 - decltype(qq)::value;
+              const double  ws  = w * ri;
+              const int     xlo = __builtin_amdgcn_readlane(__double2loint(ws), q), xhi = __builtin_amdgcn_readlane(__double2hiint(ws), q);
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(xflo) : "s"(xlo), "n"(q));
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(xfhi) : "s"(xhi), "n"(q));
+              w = fma(-col[q], __hiloint2double(xhi, xlo), w);
+            });
             if (tid < nb)
-              work[j0 + tid] = w;
+              {
+                if (xl)
+                  xs[j0 + tid] = __hiloint2double(xfhi, xflo);
+                else
+                  work[j0 + tid] = __hiloint2double(xfhi, xflo);
+              }
           }
-        __syncthreads();
+        if (xl)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+          __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+          acur[u] = anext[u];
+        dcur = dnext;
       }
     for (int i = tid; i < n; i += 1024)
       {
-        const int node = i / D, c = i - node * D;
-        x[i]           = work[bperm[node] * D + c];
+        const int node = i / D, c = i - node * D, bi = bperm[node] * D + c;
+        x[i]           = xl ? xs[bi] : work[bi];
       }
+    if (dbg && tid == 0)
+      dbg[4] = __builtin_amdgcn_s_memtime() - tlast; // the backward substitution
   }
 
   // ------------------------------------------------------------------ small vector kernels
@@ -5415,7 +5473,7 @@ namespace mi
             hipFree(d_dbg);
             ++shown;
             fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: first tile column %llu, next block column "
-                            "beside the other tiles %llu (waves 0-3 through after %llu)\n", n, hbw, h[0], h[1], h[2]);
+                            "beside the other tiles %llu (waves 0-3 through after %llu); before the loop %llu, backward substitution %llu\n", n, hbw, h[0], h[1], h[2], h[3], h[4]);
           }
         return 0;
       }
