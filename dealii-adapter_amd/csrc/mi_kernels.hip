@@ -33,6 +33,26 @@ namespace mi
     return v;
   }
 
+  // The same sum through the DPP network (row shifts inside rows of 16 lanes, then the two row broadcasts): about 90 clocks
+  // against ~900 for the six dependent trips through the LDS crossbar above.  The total arrives in lane 63 ONLY.
+  template <int CTRL, int ROW_MASK, int BANK_MASK>
+  __device__ __forceinline__ double dpp_add(double v)
+  {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, false);
+    return v + __hiloint2double(hi, lo); // (lanes without a source or masked out add 0)
+  }
+  __device__ __forceinline__ double wave_sum_lane63(double v)
+  {
+    v = dpp_add<0x111, 0xf, 0xf>(v); // row_shr:1
+    v = dpp_add<0x112, 0xf, 0xf>(v); // row_shr:2
+    v = dpp_add<0x114, 0xf, 0xe>(v); // row_shr:4
+    v = dpp_add<0x118, 0xf, 0xc>(v); // row_shr:8   -> lane 15 of a row: the row's sum
+    v = dpp_add<0x142, 0xa, 0xf>(v); // row_bcast:15 -> rows 1 and 3 take the row before
+    v = dpp_add<0x143, 0xc, 0xf>(v); // row_bcast:31 -> rows 2 and 3 take lane 31
+    return v;
+  }
+
   // sum over the workgroup, result valid in every thread; s_red needs blockDim/64 doubles
   template <int NT>
   __device__ __forceinline__ double block_sum(double v, double *s_red)
@@ -4787,8 +4807,8 @@ namespace mi
               if (t < m)
                 sacc += acur[u] * (xl ? xs[r0 + t] : work[r0 + t]);
             }
-          sacc = wave_sum(sacc);
-          if (l == 0)
+          sacc = wave_sum_lane63(sacc);
+          if (l == 63)
             sy[c] = sacc;
           if (tid < NB * NB)
             sL[tid / NB][tid % NB] = dcur; // (outside the band or the block: zero)
