@@ -4319,6 +4319,113 @@ namespace mi
       }
   }
 
+  // ------------------------------------------------------------------ backward substitution of the LDS-window kernels
+  // L^T x = y for the factor L in `band` (memory); y in `work` (from_work) or already in xs; x to the library's dof order.
+  // xl: x lives in LDS (xs, at least n doubles), otherwise in `work`.  All 1024 threads of the one workgroup.
+  constexpr int BAND_BACK_NA = 4; // rows below a block column per lane of a column's wave: half bandwidths up to 256
+  template <int D>
+  __device__ __forceinline__ void band_backward_lds(const double *__restrict__ band, int n, int hbw, bool xl, double *xs, double *work,
+                                                    double (*sL)[BAND_NB + 1], double *sy, const int32_t *__restrict__ bperm,
+                                                    double *x, bool from_work = true)
+  {
+    // ---- backward substitution L^T x = y, L from memory.  A block column is: s_c = sum_r L[r][c] x[r] over the rows below
+    // the block (wave c = column c, a wave sum), then the block's own 16 unknowns swept by wave 0.  Nothing in it waits for
+    // the L2 (band_cholesky_solve pays two round trips per block column): x lives in LDS (the window is free now; systems
+    // beyond its 16.5 k entries keep x in memory), and the entries of L that a block column needs -- up to three per
+    // thread for the sums, one per thread of the diagonal block -- are requested one block column ahead.
+    constexpr int NB = BAND_NB;
+    const int     tid = threadIdx.x, ld = hbw + 1;
+    auto          A  = [&](int r, int c) -> const double & { return band[int64_t(c) * ld + (r - c)]; };
+    if (xl && from_work)
+      for (int i = tid; i < n; i += 1024)
+        xs[i] = work[i];
+    constexpr int NA = BAND_BACK_NA; // rows below a block, per lane of a column's wave
+    double        acur[NA], dcur = 0.0;
+    auto          request = [&](int j0, double *a, double &dd) {
+      const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0, c = tid >> 6, l = tid & 63;
+#pragma unroll
+      for (int u = 0; u < NA; ++u)
+        {
+          const int t = l + 64 * u;
+          a[u]        = (j0 >= 0 && c < nb && t < m && r0 + t - (j0 + c) <= hbw) ? A(r0 + t, j0 + c) : 0.0;
+        }
+      const int r = tid / NB, cc = tid % NB;
+      dd          = (j0 >= 0 && tid < NB * NB && r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
+    };
+    const int jlast = ((n - 1) / NB) * NB;
+    request(jlast, acur, dcur);
+    __syncthreads();
+    for (int j0 = jlast; j0 >= 0; j0 -= NB)
+      {
+        const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        double    anext[NA], dnext;
+        request(j0 - NB, anext, dnext); // (below the first block column: zeros, nothing is loaded)
+        {
+          const int c = tid >> 6, l = tid & 63;
+          double    sacc = 0.0;
+#pragma unroll
+          for (int u = 0; u < NA; ++u)
+            {
+              const int t = l + 64 * u;
+              if (t < m)
+                sacc += acur[u] * (xl ? xs[r0 + t] : work[r0 + t]);
+            }
+          sacc = wave_sum_lane63(sacc);
+          if (l == 63)
+            sy[c] = sacc;
+          if (tid < NB * NB)
+            sL[tid / NB][tid % NB] = dcur; // (outside the band or the block: zero)
+        }
+        if (xl)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (the requests for the next block stay in flight)
+        else
+          __syncthreads();
+        if (tid < 64)
+          {
+            // lane t = column t of the block, swept from the last row upwards: x_q = w_q / L_qq goes into lane q of a register
+            // of its own (v_writelane), every lane takes w -= L[q][t] x_q (zero above the diagonal: the lanes of finished
+            // unknowns keep what nobody reads)
+            const int tt = tid < NB ? tid : 0;
+            double    col[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              col[q] = sL[q][tt];
+            const double dg = sL[tt][tt];
+            double       w  = tid < nb ? (xl ? xs[j0 + tid] : work[j0 + tid]) - sy[tid] : 0.0;
+            const double ri = tid < nb ? 1.0 / dg : 1.0;
+            int          xflo = 0, xfhi = 0;
+            static_for<0, NB>([&](auto qq) {
+              constexpr int q   = NB - 1 - decltype(qq)::value;
+              const double  ws  = w * ri;
+              const int     xlo = __builtin_amdgcn_readlane(__double2loint(ws), q), xhi = __builtin_amdgcn_readlane(__double2hiint(ws), q);
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(xflo) : "s"(xlo), "n"(q));
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(xfhi) : "s"(xhi), "n"(q));
+              w = fma(-col[q], __hiloint2double(xhi, xlo), w);
+            });
+            if (tid < nb)
+              {
+                if (xl)
+                  xs[j0 + tid] = __hiloint2double(xfhi, xflo);
+                else
+                  work[j0 + tid] = __hiloint2double(xfhi, xflo);
+              }
+          }
+        if (xl)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else
+          __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+          acur[u] = anext[u];
+        dcur = dnext;
+      }
+    for (int i = tid; i < n; i += 1024)
+      {
+        const int node = i / D, c = i - node * D, bi = bperm[node] * D + c;
+        x[i]           = xl ? xs[bi] : work[bi];
+      }
+  }
+
   // ------------------------------------------------------------------ banded Cholesky, LDS-window form (rounds 4-5)
   // The same factorisation K = L L^T + substitutions for half bandwidths hbw <= BAND_LDS_W - BAND_NB + BAND_FAR_MAX.  The
   // ACTIVE part of the matrix -- the BAND_LDS_W rows below the current block column -- lives in LDS as a circular window
@@ -4765,104 +4872,117 @@ namespace mi
     if (!do_solve)
       return;
     __syncthreads();
-    // ---- backward substitution L^T x = y, L from memory.  A block column is: s_c = sum_r L[r][c] x[r] over the rows below
-    // the block (wave c = column c, a wave sum), then the block's own 16 unknowns swept by wave 0.  Nothing in it waits for
-    // the L2 (band_cholesky_solve pays two round trips per block column): x lives in LDS (the window is free now; systems
-    // beyond its 16.5 k entries keep x in memory), and the entries of L that a block column needs -- up to three per
-    // thread for the sums, one per thread of the diagonal block -- are requested one block column ahead.
-    auto          A  = [&](int r, int c) -> double & { return band[int64_t(c) * ld + (r - c)]; };
-    const bool    xl = n <= W * LD; // x in LDS
-    double *const xs = S;
-    if (xl)
-      for (int i = tid; i < n; i += 1024)
-        xs[i] = work[i];
-    constexpr int NA = (BAND_LDS_W - BAND_NB + BAND_FAR_MAX + 63) / 64; // rows below a block, per lane of a column's wave
-    double        acur[NA], dcur = 0.0;
-    auto          request = [&](int j0, double *a, double &dd) {
-      const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0, c = tid >> 6, l = tid & 63;
-#pragma unroll
-      for (int u = 0; u < NA; ++u)
-        {
-          const int t = l + 64 * u;
-          a[u]        = (j0 >= 0 && c < nb && t < m && r0 + t - (j0 + c) <= hbw) ? A(r0 + t, j0 + c) : 0.0;
-        }
-      const int r = tid / NB, cc = tid % NB;
-      dd          = (j0 >= 0 && tid < NB * NB && r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
-    };
-    const int jlast = ((n - 1) / NB) * NB;
-    request(jlast, acur, dcur);
-    __syncthreads();
-    for (int j0 = jlast; j0 >= 0; j0 -= NB)
-      {
-        const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
-        double    anext[NA], dnext;
-        request(j0 - NB, anext, dnext); // (below the first block column: zeros, nothing is loaded)
-        {
-          const int c = tid >> 6, l = tid & 63;
-          double    sacc = 0.0;
-#pragma unroll
-          for (int u = 0; u < NA; ++u)
-            {
-              const int t = l + 64 * u;
-              if (t < m)
-                sacc += acur[u] * (xl ? xs[r0 + t] : work[r0 + t]);
-            }
-          sacc = wave_sum_lane63(sacc);
-          if (l == 63)
-            sy[c] = sacc;
-          if (tid < NB * NB)
-            sL[tid / NB][tid % NB] = dcur; // (outside the band or the block: zero)
-        }
-        if (xl)
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (the requests for the next block stay in flight)
-        else
-          __syncthreads();
-        if (tid < 64)
-          {
-            // lane t = column t of the block, swept from the last row upwards: x_q = w_q / L_qq goes into lane q of a register
-            // of its own (v_writelane), every lane takes w -= L[q][t] x_q (zero above the diagonal: the lanes of finished
-            // unknowns keep what nobody reads)
-            const int tt = tid < NB ? tid : 0;
-            double    col[NB];
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-              col[q] = sL[q][tt];
-            const double dg = sL[tt][tt];
-            double       w  = tid < nb ? (xl ? xs[j0 + tid] : work[j0 + tid]) - sy[tid] : 0.0;
-            const double ri = tid < nb ? 1.0 / dg : 1.0;
-            int          xflo = 0, xfhi = 0;
-            static_for<0, NB>([&](auto qq) {
-              constexpr int q   = NB - 1 - decltype(qq)::value;
-              const double  ws  = w * ri;
-              const int     xlo = __builtin_amdgcn_readlane(__double2loint(ws), q), xhi = __builtin_amdgcn_readlane(__double2hiint(ws), q);
-              asm("v_writelane_b32 %0, %1, %2" : "+v"(xflo) : "s"(xlo), "n"(q));
-              asm("v_writelane_b32 %0, %1, %2" : "+v"(xfhi) : "s"(xhi), "n"(q));
-              w = fma(-col[q], __hiloint2double(xhi, xlo), w);
-            });
-            if (tid < nb)
-              {
-                if (xl)
-                  xs[j0 + tid] = __hiloint2double(xfhi, xflo);
-                else
-                  work[j0 + tid] = __hiloint2double(xfhi, xflo);
-              }
-          }
-        if (xl)
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else
-          __syncthreads();
-#pragma unroll
-        for (int u = 0; u < NA; ++u)
-          acur[u] = anext[u];
-        dcur = dnext;
-      }
-    for (int i = tid; i < n; i += 1024)
-      {
-        const int node = i / D, c = i - node * D, bi = bperm[node] * D + c;
-        x[i]           = xl ? xs[bi] : work[bi];
-      }
+    band_backward_lds<D>(band, n, hbw, n <= W * LD, S, work, sL, sy, bperm, x);
     if (dbg && tid == 0)
       dbg[4] = __builtin_amdgcn_s_memtime() - tlast; // the backward substitution
+  }
+
+  // ------------------------------------------------------------------ substitutions alone, x in LDS (round 5)
+  // x = K^-1 b for a band that holds the factor already (the linear model factorises its constant matrix once and
+  // substitutes every time step).  One workgroup, x in LDS from the first read of b to the last write of x, the entries of
+  // L requested one block column ahead in both sweeps -- band_cholesky_solve's substitutions go through memory and pay five
+  // dependent round trips to the L2 per block column.  Forward, per block column (two barriers): wave 0 sweeps the block's
+  // 16 unknowns (lane t = row t of the diagonal block in registers, y_q into lane q by v_writelane); then waves 1-15 take
+  // one 16-row tile of the panel each, y_panel -= P y_block on the matrix cores (operand A = the tile as requested,
+  // B = y_block on every column).  Backward: band_backward_lds.  Systems of up to BAND_SOLVE_XMAX dofs, half bandwidths up to
+  // 15 tiles.
+  constexpr int BAND_SOLVE_XMAX = 18432, BAND_SOLVE_MAXH = 15 * BAND_NB;
+  template <int D>
+  __global__ __launch_bounds__(1024) void band_solve_lds(const double *__restrict__ band, int n, int hbw, const int32_t *__restrict__ bperm,
+                                                         int nnodes, const double *__restrict__ b, double *x)
+  {
+    constexpr int NB = BAND_NB;
+    __shared__ double xs[BAND_SOLVE_XMAX];
+    __shared__ double sL[NB][NB + 1];
+    __shared__ double sy[NB];
+    const int tid = threadIdx.x, ld = hbw + 1, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto      A  = [&](int r, int c) -> const double & { return band[int64_t(c) * ld + (r - c)]; };
+    for (int i = tid; i < n; i += 1024)
+      {
+        const int node = i / D, c = i - node * D;
+        xs[bperm[node] * D + c] = b[i];
+      }
+    // what block column j0 needs from memory: its diagonal block (one entry per thread of waves 0-3) and, waves 1-15, the
+    // wave's tile of the panel in the layout of the matrix cores' A operand (lane: row s0 + li, columns j0 + 4 kk + lk)
+    auto request = [&](int j0, double &dd, double *pa) {
+      const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+      const int r = tid / NB, cc = tid % NB;
+      dd          = (j0 < n && tid < NB * NB && r < nb && cc <= r && r - cc <= hbw) ? A(j0 + r, j0 + cc) : 0.0;
+      const int row = r0 + NB * (wv - 1) + li;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        {
+          const int col = j0 + 4 * kk + lk;
+          pa[kk]        = (j0 < n && wv >= 1 && row - r0 < m && row - col <= hbw) ? A(row, col) : 0.0; // (m > 0: nb = NB)
+        }
+    };
+    typedef double v4f64 __attribute__((ext_vector_type(4)));
+    double dcur, pcur[4];
+    request(0, dcur, pcur);
+    if (tid < NB * NB)
+      sL[tid / NB][tid % NB] = dcur;
+    __syncthreads();
+    for (int j0 = 0; j0 < n; j0 += NB)
+      {
+        const int nb = min(NB, n - j0), r0 = j0 + nb, m = min(n, r0 + hbw) - r0;
+        double    dnext, pnext[4];
+        request(j0 + NB, dnext, pnext);
+        if (wv == 0)
+          {
+            // lane t = row t of the block: y_q = w_q / L_qq into lane q of a register of its own, the rows below take
+            // w -= L[t][q] y_q (zero above the diagonal: the lanes of finished rows keep what nobody reads)
+            const int tt = tid < NB ? tid : 0;
+            double    rowl[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q)
+              rowl[q] = sL[tt][q];
+            const double dg = sL[tt][tt];
+            double       w  = tid < nb ? xs[j0 + tid] : 0.0;
+            const double ri = tid < nb ? 1.0 / dg : 1.0;
+            int          yflo = 0, yfhi = 0;
+            static_for<0, NB>([&](auto qq) {
+              constexpr int q   = decltype(qq)::value;
+              const double  ws  = w * ri;
+              const int     ylo = __builtin_amdgcn_readlane(__double2loint(ws), q), yhi = __builtin_amdgcn_readlane(__double2hiint(ws), q);
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(yflo) : "s"(ylo), "n"(q));
+              asm("v_writelane_b32 %0, %1, %2" : "+v"(yfhi) : "s"(yhi), "n"(q));
+              w = fma(-rowl[q], __hiloint2double(yhi, ylo), w);
+            });
+            if (tid < NB)
+              {
+                const double yt = tid < nb ? __hiloint2double(yfhi, yflo) : 0.0;
+                sy[tid]         = yt;
+                if (tid < nb)
+                  xs[j0 + tid] = yt;
+              }
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (the requests for the next block stay in flight)
+        if (wv >= 1 && NB * (wv - 1) < m)
+          {
+            v4f64 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+              d = __builtin_amdgcn_mfma_f64_16x16x4f64(pcur[kk], sy[4 * kk + lk], d, 0, 0, 0);
+            if (li == 0) // (every column of the product is the same vector)
+              {
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                  {
+                    const int t = NB * (wv - 1) + lk + 4 * v;
+                    if (t < m)
+                      xs[r0 + t] -= d[v];
+                  }
+              }
+          }
+        if (tid < NB * NB)
+          sL[tid / NB][tid % NB] = dnext; // the next diagonal block (outside the band or the block: zero)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          pcur[kk] = pnext[kk];
+      }
+    band_backward_lds<D>(band, n, hbw, true, xs, nullptr, sL, sy, bperm, x, false);
   }
 
   // ------------------------------------------------------------------ small vector kernels
@@ -5495,6 +5615,15 @@ namespace mi
             fprintf(stderr, "band_cholesky_lds (n = %d, hbw = %d) clocks of thread 0: first tile column %llu, next block column "
                             "beside the other tiles %llu (waves 0-3 through after %llu); before the loop %llu, backward substitution %llu\n", n, hbw, h[0], h[1], h[2], h[3], h[4]);
           }
+        return 0;
+      }
+    // substitutions alone (the linear model's time steps): x in LDS where the system fits
+    if (!factor && solve && lds_ok && n <= BAND_SOLVE_XMAX && hbw <= BAND_SOLVE_MAXH)
+      {
+        if (dim == 3)
+          hipLaunchKernelGGL((band_solve_lds<3>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x);
+        else
+          hipLaunchKernelGGL((band_solve_lds<2>), dim3(1), dim3(1024), 0, s, band, n, hbw, bperm, nnodes, b, x);
         return 0;
       }
     if (dim == 3)
