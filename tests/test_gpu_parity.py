@@ -707,6 +707,43 @@ def test_direct_solver_over_band_widths(dim, p, reps):
     G.close()
 
 
+@pytest.mark.parametrize("dim,p,reps", [(2, 3, (6, 5)), (2, 1, (100, 54)), (2, 1, (62, 64)), (2, 2, (18, 30)), (3, 1, (2, 15, 20)),
+                                        (2, 1, (79, 40)), (2, 1, (300, 30)), (3, 2, (3, 2, 6)), (2, 1, (2, 2))])
+def test_linear_model_substitutions_over_band_widths(dim, p, reps):
+    """round 5: the linear model factorises its constant matrix in the first step and only substitutes afterwards
+    (linear_elasticity.cc:479-497 solves with the matrix assembled once, :236); the substitutions run with x in LDS, the
+    panel updates on the matrix cores (band_solve_lds) for systems up to 18,432 dofs and half bandwidths up to 240.  Meshes
+    on both sides of both limits and of the window kernel's (half bandwidths 67, 113, 129, 153, 158, 163, 65 with 18,662 dofs,
+    248, and a system smaller than a block column): three steps -- factorisation + substitution, then substitutions alone,
+    with both right-hand-side paths -- against the oracle's banded LU."""
+    import ctypes as C
+    hi = tuple(0.1 * r for r in reps)
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_ZCLAMP]
+    P = O.LinearProblem(O.make_desc(dim=dim, degree=p, reps=reps, hi=hi, face_role=roles, theta=0.6))
+    G = M.Context(dim=dim, degree=p, reps=reps, hi=hi, face_role=roles)
+    G.set_tuning("solver_type", 1)
+    L = M.lib()
+    L.mi_linear_setup.argtypes = [C.c_void_p, C.c_double]
+    L.mi_linear_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int64, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    assert L.mi_linear_setup(G.h, 0.6) == 0, L.mi_last_error(G.h)
+    rng = np.random.default_rng(11)
+    ids = P.interface_nodes
+    for step in range(3):
+        consistent = step != 1
+        t = 50.0 * rng.standard_normal((len(ids), dim))
+        P.vec(O.L_STRESS)[:] = 0
+        for c in range(dim):
+            P.vec(O.L_STRESS)[ids * dim + c] = t[:, c]
+        G.set_interface_traction(t)
+        assert P.step(O.SOLVER_DIRECT, consistent)[0] == 0
+        its, res = C.c_int(0), C.c_double(0)
+        assert L.mi_linear_step(G.h, int(consistent), 1e-12, G.n * 10, C.byref(its), C.byref(res)) == 0, L.mi_last_error(G.h)
+        assert its.value == 1  # one "iteration" per direct solve
+        for vo, vg in ((O.L_D, 0), (O.L_V, 2)):
+            assert _relmax(G.get(vg), P.vec(vo)) < 1e-9, (step, vo)
+    G.close()
+
+
 @pytest.mark.parametrize("scenario,dim,p", DIRECT_CASES)
 def test_direct_solver_matches_the_oracle_direct_solve(scenario, dim, p):
     """the reference's shipped default (parameters.prm:43, nonlinear_elasticity.cc:1192-1200) on its own geometries: one
