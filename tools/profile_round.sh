@@ -33,6 +33,12 @@ done
 timeout 400 python bench.py --cells 120 --steps 3 --warmup 1 --cpu-cells 0 2>/dev/null | tail -1 > "$OUT/bench_n120_42M_dofs.json"
 timeout 900 python tools/r5_asm_ab.py 59 4 3,9 > "$OUT/assembly_kernels_n59.txt" 2>&1
 timeout 900 python tools/small_case_latency.py > "$OUT/small_case_latency.txt" 2>&1
+timeout 300 python tools/linear_model_latency.py > "$OUT/linear_model_latency.txt" 2>&1
+# the direct solver's kernels: LDS-window kernels, the general kernel everywhere, phase clocks
+(timeout 100 python tools/r5_direct_far.py; MI_BAND_LDS=0 timeout 100 python tools/r5_direct_far.py
+ MI_BAND_DBG=1 timeout 100 python tools/r5_direct_far.py FSI3 2>&1 | grep clocks | head -1
+ MI_BAND_DBG=1 timeout 100 python tools/r5_direct_far.py "PF 3D p=2" 2>&1 | grep clocks | head -1) > "$OUT/direct_solver_kernels.txt" 2>&1
+if [ -x tools/probe/fp64_issue ]; then timeout 60 tools/probe/fp64_issue > "$OUT/fp64_issue_probe.txt" 2>&1; fi
 timeout 1500 bash tools/pmc_mf.sh > /dev/null 2>&1; cp gpurun_out/pmc_mf.json "$OUT/pmc_counters_mf_spmv_n59.json"
 timeout 1500 bash tools/pmc_asm.sh > /dev/null 2>&1; cp gpurun_out/pmc_asm.json "$OUT/pmc_counters_assemble_q2sf_n59.json"
 timeout 900 python tools/time_element_products.py 59 2,1 > "$OUT/fine_level_product_forms_n59.txt" 2>&1
