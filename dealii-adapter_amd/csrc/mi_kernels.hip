@@ -4062,27 +4062,43 @@ namespace mi
     const int     len = prm.len[sl], wx = prm.wx[sl], ld = hbw + 1;
     const int64_t off = prm.off[sl];
     const int     pr  = bperm[node];
-    for (int k = 0; k < len; ++k)
+    // (eight entries of the row at a time: their column ids, then the columns' band positions, then the values are requested
+    // together -- one entry after the other was 50 x three dependent round trips to the L2 for a 2D Q3 row: 34 us)
+    constexpr int NU = 8;
+    for (int k0 = 0; k0 < len; k0 += NU)
       {
-        const int     pc = bperm[prm.col[(off + k) * 64 + lane]];
-        const double *v  = prm.vals + (off * 64 + int64_t(k / wx) * (64 * wx) + lane * wx + k % wx) * DD;
+        int cn[NU], pc[NU];
 #pragma unroll
-        for (int i = 0; i < D; ++i)
+        for (int u = 0; u < NU; ++u)
+          cn[u] = k0 + u < len ? prm.col[(off + k0 + u) * 64 + lane] : node;
 #pragma unroll
-          for (int j = 0; j < D; ++j)
-            {
-              const int r = pr * D + i, c = pc * D + j;
-              if (r >= c)
-                band[int64_t(c) * ld + (r - c)] = v[i * D + j];
-            }
+        for (int u = 0; u < NU; ++u)
+          pc[u] = bperm[cn[u]];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+          {
+            const int k = k0 + u;
+            if (k < len)
+              {
+                const double *v = prm.vals + (off * 64 + int64_t(k / wx) * (64 * wx) + lane * wx + k % wx) * DD;
+                double        e[DD];
+#pragma unroll
+                for (int q = 0; q < DD; ++q)
+                  e[q] = v[q];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                  for (int j = 0; j < D; ++j)
+                    {
+                      const int r = pr * D + i, c = pc[u] * D + j;
+                      if (r >= c)
+                        band[int64_t(c) * ld + (r - c)] = e[i * D + j];
+                    }
+              }
+          }
       }
   }
 
-  // x = K^-1 b with K in `band` (overwritten by its factor).  b, x: vectors in the library's dof order (dof = D node + c);
-  // bperm: node -> band position; work: n doubles.  flag[0] = 1 when a pivot is not positive (K not positive definite).
-  // factor_only / solve_only split the two halves (the linear model factorises its constant matrix once).
-  // value of lane `lane` (uniform) in every lane: two v_readlane_b32 into scalar registers -- a few cycles, where __shfl goes
-  // through the LDS crossbar (ds_bpermute) and costs a hundred
   // f(integral_constant<int, I>) for I = I0 .. N - 1 (loop bodies that need the index as a constant expression)
   template <int I, int N, typename F>
   __device__ __forceinline__ void static_for(F &&f)
@@ -4093,6 +4109,8 @@ namespace mi
         static_for<I + 1, N>(f);
       }
   }
+  // value of lane `lane` (uniform) in every lane: two v_readlane_b32 into scalar registers -- a few cycles, where __shfl goes
+  // through the LDS crossbar (ds_bpermute) and costs a hundred
   __device__ __forceinline__ double lane_value(double v, int lane)
   {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -4111,6 +4129,9 @@ namespace mi
       }
     return rd;
   }
+  // x = K^-1 b with K in `band` (overwritten by its factor).  b, x: vectors in the library's dof order (dof = D node + c);
+  // bperm: node -> band position; work: n doubles.  flag[0] = 1 when a pivot is not positive (K not positive definite).
+  // factor_only / solve_only split the two halves (the linear model factorises its constant matrix once).
   template <int D>
   __global__ __launch_bounds__(1024) void band_cholesky_solve(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
                                                              int nnodes, const double *__restrict__ b, double *x, double *work,
