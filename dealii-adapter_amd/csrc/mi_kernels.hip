@@ -4501,6 +4501,11 @@ namespace mi
     __shared__ double sy[NB];         // (backward substitution)
     __shared__ double sF[FAR ? 2 : 1][FAR ? BAND_FAR_MAX : 1][NB + 1]; // FAR: panel rows beyond the window (row rF0 + f);
                                                                        // two copies: one read by tiles, one being made
+    // FAR: what the NEXT block column's far panel rows start from -- their entries in its 16 columns, as the first tile column
+    // of the trailing update leaves them (sX: rows beyond the window never wait for the L2 inside factor_block) -- and the
+    // right-hand side of the rows beyond the window (yF, circular over 64 rows; a row's y goes to memory when it is final)
+    __shared__ double sX[FAR ? BAND_FAR_MAX : 1][NB + 1];
+    __shared__ double yF[FAR ? 64 : 1];
     const int tid = threadIdx.x, ld = hbw + 1;
     const unsigned long long tk0 = (dbg && tid == 0) ? __builtin_amdgcn_s_memtime() : 0;
     // ---- right-hand side into band order (memory)
@@ -4520,6 +4525,16 @@ namespace mi
     __syncthreads();
     if (do_solve && tid < W)
       yv[tid] = tid < n ? work[tid] : 0.0;
+    if constexpr (FAR)
+      {
+        if (tid < BAND_FAR_MAX * NB) // block column 0's far rows W + f, columns 0 .. 15
+          {
+            const int f = tid >> 4, c = tid & (NB - 1), r = W + f;
+            sX[f][c]    = (r < n && r - c <= hbw) ? band[int64_t(c) * ld + (r - c)] : 0.0;
+          }
+        if (tid >= 960)
+          yF[tid - 960] = (do_solve && tid - 960 < BAND_FAR_MAX && W + tid - 960 < n) ? work[W + tid - 960] : 0.0; // rows W .. W + 47
+      }
     __syncthreads();
     // Block column jb, diagonal block and panel (waves 0-3; see the head comment).  Straight-line code on purpose (no lane
     // or block-size conditions in the elimination): entries above the diagonal are computed and never used, a short last
@@ -4556,11 +4571,14 @@ namespace mi
         }
       else if (isfar)
         {
+          if constexpr (FAR)
+            {
 #pragma unroll
-          for (int c = 0; c < NB; ++c)
-            row[c] = (r - jb - c <= hbw) ? pb[int64_t(c) * (ld - 1)] : 0.0;
-          if (do_solve)
-            y = work[r];
+              for (int c = 0; c < NB; ++c)
+                row[c] = sX[q - mb][c]; // (zero outside the band)
+              if (do_solve)
+                y = yF[r & 63];
+            }
         }
       else
         {
@@ -4639,7 +4657,7 @@ namespace mi
                     pb[int64_t(c) * (ld - 1)] = row[c];
                 }
               if (do_solve)
-                work[r] = y;
+                yF[r & 63] = y;
             }
           else if (mallb > mb && f < BAND_FAR_MAX) // rows of sF past the panel: zero rows (whole tiles are multiplied)
             {
@@ -4762,7 +4780,7 @@ namespace mi
             // in memory by the far panel row's lane)
             pre[u] = (rn < n && k <= hbw && (!FAR || c >= r0)) ? band[int64_t(c) * ld + k] : 0.0;
           }
-        if (do_solve && tid < NB && j0 + W + tid < n)
+        if (!FAR && do_solve && tid < NB && j0 + W + tid < n)
           prey = work[j0 + W + tid];
         // FAR: the entering rows' entries in the next block column (their tile of the first tile column) come in through
         // the wave that updates them, in the tile's layout -- the other waves' stores of entering rows are not visible to it
@@ -4798,8 +4816,43 @@ namespace mi
                           S[((rF0 + ((tid & 63) >> 4) + 4 * v) & (W - 1)) * LD + ((r0 + (tid & 15)) & (W - 1))] = pre7[v];
                       }
                   }
-                if (I == W / NB && nbr > W / NB) // (one wave: the tiles (8, 0) and (9, 0))
-                  update_mem_pair(W / NB, 0, W / NB + 1, nbr > W / NB + 1 ? 0 : -1, jc, r0, rF0, nfar, fb);
+                // the next block column's far rows rF0 + 16 + f in its columns r0 .. r0 + 15, into sX: f < 32 are this block
+                // column's rows beyond the entering ones -- the tiles (8, 0) and (9, 0) of its trailing update, taken from
+                // memory, updated, and NOT stored back (factor_block finishes and stores them) --, f >= 32 come as they are
+                if (I == W / NB || I == W / NB + 1)
+                  {
+                    const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+                    double    old[2][4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                      for (int v = 0; v < 4; ++v)
+                        {
+                          const int f = 32 * (I - W / NB) + 16 * h + li, rr = rF0 + NB + f, tc = r0 + lk + 4 * v;
+                          old[h][v]   = (f < BAND_FAR_MAX && rr < n && rr - tc <= hbw) ? band[int64_t(tc) * ld + (rr - tc)] : 0.0;
+                        }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                      {
+                        const int f0 = 32 * (I - W / NB) + 16 * h; // rows rF0 + 16 + f0 ..: row block 8 + f0 / 16 of this block column
+                        v4f64     d  = {0.0, 0.0, 0.0, 0.0};
+                        if (f0 < 32 && nfar > NB + f0)
+                          {
+                            const double *const ps = &sF[fb][NB + f0 + li][0], *const pt = &S[((r0 + li) & (W - 1)) * LD + jc];
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk)
+                              d = __builtin_amdgcn_mfma_f64_16x16x4f64(pt[4 * kk + lk], ps[4 * kk + lk], d, 0, 0, 0);
+                          }
+                        if (f0 < BAND_FAR_MAX)
+                          {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                              sX[f0 + li][lk + 4 * v] = old[h][v] - d[v];
+                          }
+                      }
+                    if (I == W / NB + 1 && do_solve && lane < NB) // the right-hand side of the rows that become far rows now
+                      yF[(rF0 + NB + 32 + lane) & 63] = rF0 + NB + 32 + lane < n ? work[rF0 + NB + 32 + lane] : 0.0;
+                  }
               }
           }
         // the finished columns leave the window: into registers now, out to the band in memory as the iteration's LAST
@@ -4823,8 +4876,10 @@ namespace mi
               S[((j0 + W + rr) & (W - 1)) * LD + cs] = pre[u];
           }
         if (do_solve && tid < NB)
-          yv[(j0 + W + tid) & (W - 1)] = prey;
-        __syncthreads();
+          yv[(j0 + W + tid) & (W - 1)] = FAR ? yF[(j0 + W + tid) & 63] : prey;
+        // (LDS only: nothing stored to memory in T1 is read in T2, and the finished columns' stores of the iteration before
+        // need not be waited for)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         BAND_STAMP(0);
         // ---- T2
         if (wv < 4)
@@ -4877,13 +4932,13 @@ namespace mi
             if (cc < nb && k <= hbw && r < n && r < j0 + W)
               band[int64_t(j0 + cc) * ld + k] = wb[u];
           }
-        // (nothing the next iterations load from memory was stored by this one -- the finished columns and y are read again
-        // after the loop -- so the barrier orders the LDS only and the stores drain beside the next tile; FAR: the far rows
-        // ARE re-read, the full barrier stays)
+        // (the finished columns, the far rows' finished entries and y are read again after the loop only: the barrier orders
+        // the LDS and those stores drain beside the next tile.  FAR: the memory tiles of this iteration ARE read by the next
+        // one's requests, so the waves that stored them wait for their stores first)
         if constexpr (FAR)
-          __syncthreads();
-        else
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (wv >= 4 && nbr > W / NB)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         BAND_STAMP(1);
       }
     if (dbg && tid == 0)
