@@ -4471,10 +4471,12 @@ namespace mi
   //
   // FAR (half bandwidths 113-160; the reference's 3D plate at degree 2 has 152): a block column's panel reaches nfar =
   // hbw + NB - W rows BEYOND the window.  Their entries stay in the band in memory: far panel rows are lanes of
-  // factor_block like the others (loaded from / stored to memory, and kept in sF for the iteration's tiles); tiles of
-  // the 16 entering rows are tiles of the window; tiles of the rows beyond those are read-modify-writes of the band in
-  // memory, two tiles per wave at a time (update_mem_pair).  The window itself never holds an entry with r - c >= W: when
-  // a row enters, its columns further left are finished.
+  // factor_block like the others (finished entries stored to memory, the rows kept in sF for the iteration's tiles); tiles
+  // of the 16 entering rows are tiles of the window; tiles of the rows beyond those are read-modify-writes of the band in
+  // memory, two tiles per wave at a time (update_mem_pair) -- except their first tile column, whose results are what the
+  // next block column's far lanes start from: it goes to LDS (sX) and is never stored unfinished, and the far rows'
+  // right-hand side lives in LDS too (yF), so factor_block's chain neither loads from nor waits for memory.  The window
+  // itself never holds an entry with r - c >= W: when a row enters, its columns further left are finished.
   constexpr int BAND_LDS_W = 128, BAND_FAR_MAX = 48;
   template <int D, bool FAR = false>
   __global__ __launch_bounds__(1024) void band_cholesky_lds(double *band, int n, int hbw, const int32_t *__restrict__ bperm,
