@@ -245,11 +245,32 @@ def free_port():
 
 
 def launch_ranks(n):
-    """start the N ranks as child processes of this (GPU-free) process and pass their exit code on"""
+    """start the N ranks as child processes of this (GPU-free) process and pass their exit code on.  A wall-clock limit
+    (MI_BENCH_RANKS_TIMEOUT_S, default 1800 s) stands over them: ranks that hang -- an RCCL rendezvous that never completes
+    on the first real multi-GPU run, say -- are ended as a process group (they were started in a session of their own) and
+    the bench exits with 124 instead of hanging.  Never a re-exec: this process has not touched the GPU and only waits."""
+    import signal
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    return subprocess.run(cmd, env=env).returncode
+    limit = float(os.environ.get("MI_BENCH_RANKS_TIMEOUT_S", "1800"))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print("bench.py: the %d ranks did not finish within %.0f s (MI_BENCH_RANKS_TIMEOUT_S): ending their process group"
+              % (n, limit), file=sys.stderr, flush=True)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(child.pid, sig)  # exactly the group started above
+            except ProcessLookupError:
+                break
+            try:
+                child.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        return 124
 
 
 def main():
@@ -275,6 +296,11 @@ def main():
     ap.add_argument("--cg-operator", choices=["assembled", "element"], default="assembled",
                     help="A/B: the CG's own product on the assembled sliced-ELL matrix (default; the kernel the north star names) or "
                          "on the unassembled element tangents like the smoother's (then no sliced-ELL copy is made)")
+    ap.add_argument("--fine-level", choices=["assembled", "matrix-free"], default="assembled",
+                    help="assembled (default; the north-star path: global tangent scattered by colours + sell_spmv) or matrix-free: "
+                         "no assembled fine tangent at all -- a tangent assembly writes point records, residual and the nodes' "
+                         "diagonal blocks, every fine-level product runs on mf_spmv (tuning \"fine_level\" 1); the default run "
+                         "reports it as config.with_matrix_free_fine_level over the same step window")
     ap.add_argument("--cg-start", choices=["zero", "previous-update", "previous-step", "extrapolated"], default="previous-step",
                     help="start vector of the linear solves: previous-step (default, what the executable sets: the j-th solve of "
                          "a step starts from the solution of the j-th solve of the previous step), extrapolated (the same over "
@@ -355,7 +381,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None, smoother_precision=None):
+    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None, smoother_precision=None, fine_level=None):
         """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
         nz = cells * parts if scaling == "weak" else cells
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
@@ -371,6 +397,8 @@ def main():
             G.set_tuning("precond_storage", 32)
         if (smoother_precision or args.smoother_precision) == "f32":
             G.set_tuning("smoother_precision", 32)
+        if (fine_level or args.fine_level) == "matrix-free":
+            G.set_tuning("fine_level", 1)
 
         def one_step(k):
             ramp = min(1.0, (k + 1) / 10.0)

@@ -18,9 +18,9 @@ HEADER = os.path.join(ROOT, "include", "mi_elasticity.h")
 MI_OK, MI_EINVAL, MI_EHIP, MI_ENOCONV_LIN, MI_ENOCONV_NR, MI_ECOMM = 0, -1, -2, -3, -4, -5
 FACE_FREE, FACE_CLAMPED, FACE_INTERFACE, FACE_ZCLAMP = 0, 1, 7, 8
 (V_U, V_U_OLD, V_V, V_V_OLD, V_A, V_A_OLD, V_STRESS, V_DELTA, V_NEWTON, V_RHS) = range(10)
-(T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_SELL_COPY, T_ASSEMBLE_RESIDUAL,
+(T_ASSEMBLE_CELLS, T_ASSEMBLE_TOTAL, T_SPMV, T_CG_VECTOR, T_CG_TOTAL, T_NEWMARK, T_STEP, T_ASSEMBLE_DIAG, T_ASSEMBLE_RESIDUAL,
  T_SPMV_PRECOND, T_EBE_LAUNCH, T_COUNT) = range(12)
-TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step", "sell_copy",
+TIMING_NAMES = ["assemble_cells", "assemble_total", "spmv", "cg_vector", "cg_total", "newmark", "step", "assemble_diag",
                 "assemble_residual", "spmv_precond", "ebe_launch"]
 
 
@@ -124,6 +124,8 @@ def lib():
         L.mi_vec_set.argtypes = [vp, C.c_int, dp, C.c_int64]
         L.mi_matrix_get_csr.argtypes = [vp, C.POINTER(C.c_int64), i32p, dp]
         L.mi_spmv.argtypes = [vp, dp, dp]
+        L.mi_get_diagonal_blocks.argtypes = [vp, dp]
+        L.mi_get_diagonal_blocks.restype = C.c_int
         L.mi_set_profiling.argtypes = [vp, C.c_int]
         L.mi_get_timings.argtypes = [vp, C.POINTER(Timings)]
         L.mi_partition_describe.restype = C.c_int
@@ -378,6 +380,12 @@ class Context:
         y = np.zeros_like(x)
         self._chk(lib().mi_spmv(self.h, _dp(x), _dp(y)))
         return y
+
+    def diagonal_blocks(self):
+        """[n_nodes, dim, dim]: the diagonal block of every node of the current tangent"""
+        b = np.zeros((self.nnodes, self.dim, self.dim))
+        self._chk(lib().mi_get_diagonal_blocks(self.h, _dp(b)))
+        return b
 
     def set_profiling(self, on=True):
         self._chk(lib().mi_set_profiling(self.h, int(on)))

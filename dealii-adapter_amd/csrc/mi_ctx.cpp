@@ -386,10 +386,11 @@ namespace mi_detail
     // (opt-in A/B "cg_operator" 1: the CG's own product as well, with p.q by a separate reduction -- then the
     // sliced-ELL copy of the tangent is never made)
     const int  kind       = element_form(c);
-    const bool ebe_for_cg = dotv && c->cg_operator == 1 && kind && !c->active_sell_vals && !cheb;
+    const bool mf_all     = c->mf_fine && !c->active_sell_vals; // matrix-free fine level: every product of the tangent
+    const bool ebe_for_cg = dotv && (c->cg_operator == 1 || mf_all) && kind && !c->active_sell_vals && !cheb;
     const bool cheb_ok    = !cheb || (cheb->inplace && smoother && mf_gather_fusable(c));
     if (ebe_for_cg || (kind && cheb_ok && !dotv && !c->active_sell_vals &&
-                       (smoother ? (c->ebe != 0 && c->precond_storage == 64) : (c->spmv_variant == 4 || c->unassembled_now))))
+                       (mf_all || (smoother ? (c->ebe != 0 && c->precond_storage == 64) : (c->spmv_variant == 4 || c->unassembled_now)))))
       {
         // on a slab every local cell (own layers + ghost layer) contributes to owned rows, and the cells are not sorted
         // by layer: the whole product waits for the ghost planes of x (part 2 = after the halo exchange); the rows of
@@ -398,7 +399,7 @@ namespace mi_detail
         // touch no ghost plane of x -- all but the lowest layer (rank > 0) and the ghost layer (rank < size - 1) -- run as part 1
         // while the halo is in flight, the others as part 2; every cell still writes its own slots, so the sum is the same
         const bool mf_split = part != 0 && kind == 2 && c->mf_slots && c->d_mf_yc && c->lat.ncol > 0 && c->team->mf_overlap &&
-                              !ebe_for_cg;
+                              !(ebe_for_cg && !mf_all);
         if (part == 1 && !mf_split)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
@@ -410,8 +411,8 @@ namespace mi_detail
         f.conn    = c->d_conn;
         f.first   = c->d_node_first;
         f.cmask   = c->d_cmask;
-        f.vals    = c->d_vals;
-        f.diagpos = c->d_diagpos;
+        f.vals    = c->mf_fine ? c->d_diag_blk : c->d_vals;      // (diagonal entries of constrained dofs)
+        f.diagpos = c->mf_fine ? c->d_diagpos_mf : c->d_diagpos;
         f.tab1d   = c->d_tab;
         f.cverts  = c->d_cverts;
         f.mu      = c->mat.mu;
@@ -487,6 +488,8 @@ namespace mi_detail
             else if (cheb) // ... with the update vector d, in place / the residual
               mi::launch_mf_gather_cheb(f, cheb->b, cheb->dinv, cheb->d, const_cast<double *>(x), y, cheb->c1, cheb->c2,
                                         c->own0 / 3, c->own_n / 3, c->stream);
+            else if (ebe_for_cg) // the CG's q = K p: the slot sum and the partials of p.q in one launch
+              mi::launch_mf_gather_dot(f, int64_t(c->mesh.nnodes) * 3, dotv, partials, c->grid_vec, c->own0, c->own_n, c->stream);
             else
               mi::launch_mf_gather(f, int64_t(c->mesh.nnodes) * 3, c->stream);
           }
@@ -502,7 +505,7 @@ namespace mi_detail
               mi::launch_ebe_spmv(e, c->mesh.colour_begin[col], cnt, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
                                   t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
           }
-        if (ebe_for_cg) // partials of dotv . y over the owned dofs (the early-exit flag is honoured by their consumer)
+        if (ebe_for_cg && !one_launch) // partials of dotv . y over the owned dofs (the early-exit flag is honoured by their consumer)
           mi::launch_dot_partials(dotv + c->own0, y + c->own0, c->own_n, partials, c->grid_vec, c->stream);
         return;
       }
@@ -769,6 +772,17 @@ namespace mi_detail
     HIPCHK(c, hipMemsetAsync(c->d_sc + SC_INVERTED, 0, sizeof(double), c->stream));
     mi::AsmParams p  = asm_params(c);
     p.residual_only  = residual_only ? 1 : 0;
+    // matrix-free fine level: the tangent pass IS the residual kernel, handed the record pointers (it then writes the
+    // state its residual was formed at); the diagonal blocks follow from the records below
+    const bool mf_tangent = c->mf_fine && !residual_only;
+    if (c->mf_fine)
+      {
+        p.residual_only = 1;
+        p.variant       = 0;
+        p.ke            = nullptr;
+      }
+    if (residual_only) // the convergence check's pass leaves the records of the last tangent alone
+      p.qrec = nullptr, p.qrec32 = nullptr;
     mi_ctx       *c0 = c->team->members[0];
     const int     t0 = tic(c0, residual_only ? MI_T_ASSEMBLE_RESIDUAL : MI_T_ASSEMBLE_CELLS);
     for (int col = 0; col < c->mesh.ncolours; ++col)
@@ -788,8 +802,24 @@ namespace mi_detail
         HIPCHK(c, hipGetLastError());
         return MI_OK;
       }
-    c->ke_valid = c->d_ke || c->d_qrec;
-    c->qrec32_valid = p.qrec32 != nullptr;
+    // which kernel ran: assemble_q2sf (sum factorised; it alone writes the fp32 records) or the node-pair form
+    const bool q2sf = c->dim == 3 && c->degree == 2 && (p.variant == 0 || (p.variant >= 3 && p.variant <= 8));
+    c->ke_valid     = (c->d_ke && q2sf && !c->mf_fine) || c->d_qrec;
+    c->qrec32_valid = p.qrec32 != nullptr && q2sf;
+    if (mf_tangent)
+      {
+        mi::MfParams f{};
+        f.qrec = c->d_qrec, f.tab1d = c->d_tab, f.cverts = c->d_cverts, f.cellbox = c->d_cellbox, f.dst = c->d_mf_dst;
+        f.mu = c->mat.mu, f.kappa = c->kappa, f.mass = c->alpha[1] * c->mat.rho;
+        const int td = tic(c0, MI_T_ASSEMBLE_DIAG);
+        mi::launch_mf_diag(f, c->d_diag_slots, int32_t(c->mesh.ncells), c->stream);
+        mi::launch_mf_diag_gather(c->d_diag_slots, c->d_mf_slot_base, c->d_cmask, c->d_diagpos_mf, c->d_diag_blk, c->work(W_DINV),
+                                  c->d_dinv_blk, c->d_dinv_sym6, c->mesh.nnodes, c->stream);
+        toc(c0, td);
+        HIPCHK(c, hipGetLastError());
+        c->mg_stale = true;
+        return MI_OK;
+      }
     mi::launch_extract_dinv(c->dim, c->d_vals, c->d_diagpos, c->work(W_DINV), c->mesh.nnodes, c->stream);
     if (c->want_dinv_blk) // block-Jacobi diagonal for the multigrid smoother
       {
@@ -859,6 +889,66 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // tuning "fine_level": 1 = the fine level matrix-free end to end (see mi_ctx::mf_fine), 0 = assembled (default).  Takes
+  // effect with the next tangent assembly; the assembled tangent's 8 bytes per non-zero are released / allocated again.
+  int set_fine_level(mi_ctx *c, int on)
+  {
+    if ((on != 0) == (c->mf_fine != 0))
+      return MI_OK;
+    if (on)
+      {
+        if (c->dim != 3 || c->degree != 2)
+          return fail(c, MI_EINVAL, "the matrix-free fine level exists for 3D Q2 meshes only");
+        if (c->precond_storage != 64 || c->solver_direct)
+          return fail(c, MI_EINVAL, "the matrix-free fine level excludes \"precond_storage\" 32 and \"solver_type\" 1");
+        int rc = alloc_point_records(c);
+        if (rc == MI_OK && !c->d_node_first)
+          rc = upload(c, &c->d_node_first, c->mesh.node_first);
+        if (rc)
+          return rc;
+        const size_t nn = size_t(c->mesh.nnodes);
+        if (!c->d_diagpos_mf)
+          {
+            std::vector<int32_t> dp(nn);
+            for (size_t n = 0; n < nn; ++n)
+              dp[n] = c->mesh.diagpos[n] >= 0 ? int32_t(n) : -1;
+            if ((rc = upload(c, &c->d_diagpos_mf, dp)))
+              return rc;
+            HIPCHK(c, hipMalloc((void **)&c->d_diag_blk, nn * 9 * sizeof(double)));
+            HIPCHK(c, hipMalloc((void **)&c->d_diag_slots, size_t(c->mesh.ncells) * 27 * 6 * sizeof(double)));
+          }
+        if (!c->d_dinv_blk)
+          HIPCHK(c, hipMalloc((void **)&c->d_dinv_blk, nn * 9 * sizeof(double)));
+        if (!c->d_dinv_sym6)
+          HIPCHK(c, hipMalloc((void **)&c->d_dinv_sym6, nn * 6 * sizeof(double)));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipFree(c->d_vals));
+        c->d_vals   = nullptr;
+        c->ebe      = 2;
+        c->mf_slots = 1;
+      }
+    else
+      {
+        HIPCHK(c, hipMalloc((void **)&c->d_vals, c->vals_doubles * sizeof(double)));
+        HIPCHK(c, hipMemsetAsync(c->d_vals, 0, c->vals_doubles * sizeof(double), c->stream));
+      }
+    c->mf_fine      = on ? 1 : 0;
+    c->ke_valid     = false;
+    c->qrec32_valid = false;
+    c->vals32_stale = true;
+    c->mg_stale = c->mg_force = true;
+    return MI_OK;
+  }
+
+  // the tangent's products on a matrix-free fine level need the point records of an assembly
+  int check_mf_tangent(mi_ctx *c)
+  {
+    for (mi_ctx *m : c->team->members)
+      if (m->mf_fine && !m->active_sell_vals && element_form(m) != 2)
+        return fail(c, MI_EINVAL, "matrix-free fine level: no tangent has been assembled yet (mi_assemble first)");
+    return MI_OK;
+  }
+
   // storage for the unassembled element tangents, where the smoother can use them (filled by the next full assembly)
   int ensure_element_tangents(mi_ctx *c)
   {
@@ -920,6 +1010,8 @@ namespace mi_detail
       int64_t at;
       ~CountCg() { T.n_scalar_allreduce_cg += T.n_scalar_allreduce - at; }
     } count_cg{T, T.n_scalar_allreduce};
+    if (int e = check_mf_tangent(c0))
+      return e;
     for (mi_ctx *m : T.members) // outside the timed SpMV launches
       refresh_vals32(m);
     const int  tt   = tic(c0, MI_T_CG_TOTAL);
@@ -939,7 +1031,7 @@ namespace mi_detail
         cg.flags    = m->d_flags;
         cg.n        = m->own_n;
         cg.npart    = m->grid_vec;
-        cg.npart_pq = (m->cg_fused_dot && !(m->cg_operator == 1 && element_form(m) && !m->active_sell_vals)) ? m->grid_spmv : m->grid_vec;
+        cg.npart_pq = (m->cg_fused_dot && !((m->cg_operator == 1 || m->mf_fine) && element_form(m) && !m->active_sell_vals)) ? m->grid_spmv : m->grid_vec;
         cg.totals   = dist ? m->d_sc + SC_TOT : nullptr;
         cgs.push_back(cg);
       }
@@ -1188,7 +1280,7 @@ namespace mi_detail
             // come from the dispatch itself (kernel start / end, as rocprofv3 reports them)
             const bool one_launch = !dist && c0->profiling && c0->spmv_variant == 3 && c0->sell_icol && c0->sell_unroll == 5 &&
                                     !c0->active_sell_vals && c0->mesh.sell_nslices_interior == c0->mesh.sell_nslices &&
-                                    !(c0->cg_operator == 1 && element_form(c0));
+                                    !((c0->cg_operator == 1 || c0->mf_fine) && element_form(c0));
             t = tic(c0, MI_T_SPMV, one_launch);
             if (one_launch && t >= 0)
               mi::set_next_sell_launch_events(c0->stamps[size_t(t)].a, c0->stamps[size_t(t)].b);
@@ -1203,7 +1295,7 @@ namespace mi_detail
             if (dist)
               {
                 for (size_t k = 0; k < R; ++k)
-                  mi::launch_reduce_to_totals(cgs[k].part_pq, T.members[k]->grid_spmv, T.members[k]->d_sc + SC_TOT + 2,
+                  mi::launch_reduce_to_totals(cgs[k].part_pq, cgs[k].npart_pq, T.members[k]->d_sc + SC_TOT + 2,
                                               nullptr, 0, nullptr, cgs[k].flags, T.members[k]->stream);
                 if ((rc = team_allreduce(T, SC_TOT + 2, 1)))
                   return rc;
@@ -1297,6 +1389,7 @@ namespace mi_detail
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
                     c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_qrec32, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_lat_rows,
+                    c->d_diag_blk, c->d_diag_slots, c->d_diagpos_mf,
                     c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
                     c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
                     c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};
@@ -1424,7 +1517,8 @@ namespace mi_detail
     // length class included: they are zeroed once and never written)
     const size_t nvals = std::max<size_t>(1, size_t(m.nvalblocks()) * dd);
     // (+ the ZERO and TRASH blocks of the element kernel's branch-free scatter: blocks nvalblocks + 1 and + 2)
-    HIPCHK(c, hipMalloc((void **)&c->d_vals, (nvals + 2 + 4 * dd) * sizeof(double)));
+    c->vals_doubles = nvals + 2 + 4 * dd;
+    HIPCHK(c, hipMalloc((void **)&c->d_vals, c->vals_doubles * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_vecs, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_work, size_t(W_COUNT) * size_t(c->n) * sizeof(double)));
     HIPCHK(c, hipMalloc((void **)&c->d_saved, size_t(6) * size_t(c->n) * sizeof(double)));
@@ -1435,7 +1529,7 @@ namespace mi_detail
     HIPCHK(c, hipMalloc((void **)&c->d_iface_buf, nif * sizeof(double)));
     c->h_pinned_doubles = std::max(nif, T.iface_global.size() * size_t(c->dim)) + 64;
     HIPCHK(c, hipHostMalloc((void **)&c->h_pinned, c->h_pinned_doubles * sizeof(double), hipHostMallocDefault));
-    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, (nvals + 2 + 4 * dd) * sizeof(double), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_vals, 0, c->vals_doubles * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_vecs, 0, size_t(MI_V_COUNT) * size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_work, 0, size_t(W_COUNT) * size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sc, 0, 16 * sizeof(double), c->stream));
@@ -2125,6 +2219,8 @@ int mi_direct_solve(mi_ctx *c, double *res)
       m->active_dinv      = nullptr;
     }
   c->newton_update_is_zero = false;
+  if (c->mf_fine)
+    return fail(c, MI_EINVAL, "the direct solver factorises the assembled tangent (\"fine_level\" 0)");
   int rc = direct_factor_solve(c, c->d_vals, c->vec(MI_V_SYSTEM_RHS), c->vec(MI_V_NEWTON_UPDATE), true, true);
   if (rc)
     return rc;
@@ -2440,6 +2536,8 @@ int mi_matrix_get_csr(mi_ctx *c, int64_t *rowptr, int32_t *col, double *val)
 {
   if (c->team->size != 1)
     return fail(c, MI_EINVAL, "matrix export is only available on an undecomposed mesh");
+  if (c->mf_fine)
+    return fail(c, MI_EINVAL, "matrix export: the matrix-free fine level keeps no assembled tangent (\"fine_level\" 0)");
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const int           D = c->dim, DD = D * D;
@@ -2463,11 +2561,52 @@ int mi_matrix_get_csr(mi_ctx *c, int64_t *rowptr, int32_t *col, double *val)
   return MI_OK;
 }
 
+// the dim x dim diagonal block of every node of the current tangent, [n_nodes][dim * dim] row-major in the reference's node
+// order: out of the assembled tangent, or -- matrix-free fine level -- what mf_diag formed from the point records
+int mi_get_diagonal_blocks(mi_ctx *c, double *blocks)
+{
+  Team &T = *c->team;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (int e = check_mf_tangent(c))
+    return e;
+  const int DD = c->dim * c->dim;
+  if (T.nccl)
+    return fail(c, MI_EINVAL, "mi_get_diagonal_blocks: one process only (single or emulated slabs)");
+  std::fill(blocks, blocks + T.nnodes_global * DD, 0.0);
+  for (mi_ctx *m : T.members)
+    {
+      const size_t        cnt = size_t(m->mesh.nnodes) * DD;
+      std::vector<double> h(cnt);
+      if (m->mf_fine)
+        {
+          HIPCHK(m, hipStreamSynchronize(m->stream));
+          HIPCHK(m, hipMemcpy(h.data(), m->d_diag_blk, cnt * sizeof(double), hipMemcpyDeviceToHost));
+        }
+      else
+        {
+          double *tmp = nullptr;
+          HIPCHK(m, hipMalloc((void **)&tmp, cnt * sizeof(double)));
+          mi::launch_gather_diag_blocks(m->dim, m->d_vals, m->d_diagpos, tmp, m->mesh.nnodes, m->stream);
+          const hipError_t e1 = hipStreamSynchronize(m->stream);
+          const hipError_t e2 = hipMemcpy(h.data(), tmp, cnt * sizeof(double), hipMemcpyDeviceToHost);
+          hipFree(tmp);
+          HIPCHK(m, e1);
+          HIPCHK(m, e2);
+        }
+      for (int64_t ln = m->slab.own_begin; ln < m->slab.own_end; ++ln)
+        for (int k = 0; k < DD; ++k)
+          blocks[T.ext_node(ln + m->slab.node_offset) * DD + k] = h[size_t(ln) * DD + k];
+    }
+  return MI_OK;
+}
+
 // y = K x through the device kernels (global arrays)
 int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
 {
   Team &T = *c->team;
   HIPCHK(c, hipSetDevice(c->device));
+  if (int e = check_mf_tangent(c))
+    return e;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<double> rot;
   x_host = to_internal_order(T, x_host, rot);
@@ -2501,6 +2640,17 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
   const std::string k(key ? key : "");
   for (mi_ctx *m : c->team->members)
     {
+      if (m->mf_fine && ((k == "smoother_operator" && value != 2) || (k == "mf_single_launch" && value != 1) ||
+                         (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
+                         (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
+        return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
+      if (k == "fine_level" && (value == 0 || value == 1))
+        {
+          const int rc = set_fine_level(m, value);
+          if (rc)
+            return fail(c, rc, "%s", m->err.c_str());
+          continue;
+        }
       if (k == "solver_type" && (value == 0 || value == 1))
         {
           m->solver_direct = value;
@@ -2655,6 +2805,8 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
                0;
   else if (k == "mf_single_launch")
     *value = (m->mf_slots && m->d_mf_yc) ? 1 : 0;
+  else if (k == "fine_level")
+    *value = m->mf_fine;
   else if (k == "cell_lattice")
     *value = m->lat.ncol > 0 ? 1 : 0;
   else if (k == "cut_axis") // the box direction the slabs are cut along: 1 / 2 / 3 = x / y / z, 0: not decomposed
@@ -2728,10 +2880,12 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
   hipEvent_t a, b;
   HIPCHK(c, hipEventCreate(&a));
   HIPCHK(c, hipEventCreate(&b));
+  if (int e = check_mf_tangent(c))
+    return e;
   auto once = [&]() {
     for (mi_ctx *m : c->team->members)
       {
-        const bool plain = m->spmv_variant == 4; // the unassembled forms carry no fused dot product
+        const bool plain = m->spmv_variant == 4 && !m->mf_fine; // the unassembled forms carry no fused dot product
         enqueue_spmv(m, m->work(W_P), m->work(W_Q), plain ? nullptr : m->work(W_P), plain ? nullptr : m->part(2), nullptr);
       }
   };
@@ -2811,7 +2965,7 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_assembly = double(ms) / std::max(1, reps);
-  if (getenv("MI_ASM_STAMPS") && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 8)))
+  if (getenv("MI_ASM_STAMPS") && !c->mf_fine && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 8)))
     {
       // diagnostic: where a workgroup of the sum-factorised element kernel spends its life (shader-clock stamps of one
       // tangent wave at the phase boundaries), averaged over the cells of the first colour

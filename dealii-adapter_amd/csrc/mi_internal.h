@@ -164,6 +164,15 @@ struct mi_ctx
   int       cg_speculate = 1; // multigrid-PCG: enqueue the iterations the previous step's same solve needed (minus two)
                               // without polling the convergence flag in between (tuning "cg_speculate" 0: poll every one)
   int       pred_its[NPRED] = {}; // iterations of the j-th solve of the previous time step (0: unknown)
+  // Matrix-free fine level (round 6; tuning "fine_level" 1; 3D Q2): the level keeps NO assembled tangent.  A tangent
+  // assembly is the residual pass that also writes the point records (assemble_q2sf<true>) + the nodes' diagonal blocks
+  // from those records (mf_diag); the CG's product, start-vector and residual products and the smoother all run on
+  // mf_spmv; d_vals is released.  Same results as the assembled level [REF nonlinear_elasticity.cc:1044-1087, 1153-1191].
+  int       mf_fine = 0;
+  double   *d_diag_blk   = nullptr; // [nnodes][9] diagonal blocks under the assembled matrix's constraint rule
+  double   *d_diag_slots = nullptr; // [ncells * 27][6] the cells' contributions (slot order = processing order)
+  int32_t  *d_diagpos_mf = nullptr; // [nnodes] the node's own id where it has a row here, else -1: d_diag_blk read as `vals`
+  size_t    vals_doubles = 0;       // size of d_vals (released while mf_fine, allocated again with "fine_level" 0)
   int       ebe = 2;          // tuning "smoother_operator": 2 matrix-free from the quadrature-point records, 1 element
                               // tangents (both where available), 0 assembled matrix
   float    *d_sell_vals32 = nullptr; // fp32-rounded copy for the multigrid smoother (tuning "precond_storage" 32)

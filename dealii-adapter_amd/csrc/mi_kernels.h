@@ -242,6 +242,14 @@ namespace mi
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);
+  // ... with the partials of dotv . y over the owned dofs (fixed grid): the CG's product on the matrix-free fine level
+  void launch_mf_gather_dot(const MfParams &p, int64_t ndofs, const double *dotv, double *partials, int grid, int64_t own0,
+                            int64_t own_n, hipStream_t s);
+  // matrix-free fine level (round 6): the nodes' diagonal blocks from the point records -- every cell into its own slots
+  // [nslots][6] (MfParams::dst), then summed per node under the assembled matrix's constraint rule (see mf_diag)
+  void launch_mf_diag(const MfParams &p, double *slots6, int32_t cell_count, hipStream_t s);
+  void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const uint8_t *cmask, const int32_t *diagpos,
+                             double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s);
   // gather fused with the smoother's Chebyshev step (d != null: x += d in place) or residual (d == null: yres = b - K x)
   void launch_mf_gather_cheb3(const MfParams &p, const double *b, const double *dinv6, const double *xprev, const double *xcur,
                               double *xnext, double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);
@@ -268,6 +276,7 @@ namespace mi
                          double cb, int64_t n, hipStream_t s);
   void launch_extract_dinv_blk(int dim, const double *vals, const int32_t *diagpos, double *dinv, double *sym6, int64_t nnodes,
                                hipStream_t s);
+  void launch_gather_diag_blocks(int dim, const double *vals, const int32_t *diagpos, double *out, int64_t nnodes, hipStream_t s);
   void launch_blk_apply(int dim, double *out, const double *a, const double *dinv, int64_t nnodes, hipStream_t s);
   void launch_cheb_step_blk(int dim, double *x, double *d, const double *b, const double *q, const double *dinv,
                             double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);

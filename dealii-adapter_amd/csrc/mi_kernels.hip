@@ -1032,7 +1032,8 @@ namespace mi
             for (int j = 0; j < 3; ++j)
               M[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
           w = detJ * wq; // JxW of the reference configuration
-          if constexpr (!RES_ONLY)
+          // (RES_ONLY with records: the tangent pass of the matrix-free fine level, round 6 -- the residual-only pass of
+          // the Newton convergence check hands in no record pointer)
             if (prm.qrec) // the state the tangent is linearised at, for the matrix-free product (mf_spmv)
               {
                 double *__restrict__ g = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
@@ -2834,7 +2835,7 @@ namespace mi
               }
             if constexpr (SLOTS)
               {
-                if (!(DBG & 2) || yv == 1.2345678e300)
+                if (!(DBG & 2) || yv == T(-1.2345678e30)) // (DBG 2, timing only: the store stays in the code, never taken)
                   prm.yc[int64_t(ydst[i]) * 3 + lc] = yv;
                 continue;
               }
@@ -2984,6 +2985,253 @@ namespace mi
     s += a2 * s_res[r0 + 2];
     const double dn = (c1 != 0.0 ? c1 * (xc - xp) : 0.0) + c2 * s;
     xnext[g]        = xc + dn;
+  }
+
+  // y = sum of the slots as mf_gather, with the partials of dotv . y over the owned dofs [own0, own0 + own_n) in the same
+  // launch: the CG's q = K p and p.q on the matrix-free fine level (round 6).  Fixed grid (grid-stride over the dofs, as
+  // dot_partials): the partials -- one per workgroup -- and their sum do not depend on the launch.
+  __global__ __launch_bounds__(256) void mf_gather_dot(MfParams prm, int64_t ndofs, const double *__restrict__ dotv,
+                                                       double *partials, int64_t own0, int64_t own_n)
+  {
+    __shared__ double s_red[4];
+    double            acc = 0.0;
+    const int64_t     per = ((ndofs + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t     g0 = int64_t(blockIdx.x) * per, g1 = imin64(ndofs, g0 + per);
+    for (int64_t g = g0 + threadIdx.x; g < g1; g += 256)
+      {
+        const int64_t n = g / 3;
+        const int     c = int(g - n * 3);
+        double        s;
+        if ((prm.cmask[n] >> c) & 1)
+          {
+            const int32_t dp = prm.diagpos[n];
+            s                = dp >= 0 ? prm.vals[int64_t(dp) * 9 + c * 4] * prm.x[g] : 0.0;
+          }
+        else
+          {
+            const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
+            s                = prm.yc[int64_t(b0) * 3 + c];
+            for (int32_t k = b0 + 1; k < b1; ++k)
+              s = s + prm.yc[int64_t(k) * 3 + c];
+          }
+        prm.y[g] = s;
+        if (g >= own0 && g < own0 + own_n)
+          acc = fma(dotv[g], s, acc);
+      }
+    acc = block_sum<256>(acc, s_red);
+    if (threadIdx.x == 0)
+      partials[blockIdx.x] = acc;
+  }
+
+  // ------------------------------------------------------------------ matrix-free fine level: the diagonal blocks (round 6)
+  // With the fine level matrix-free end to end (tuning "fine_level" 1) nothing multiplies the assembled fine tangent any
+  // more; what the level still needs of it are the 3x3 DIAGONAL blocks K_aa of every node: the block-Jacobi smoother's
+  // D, the Jacobi diagonal, and the diagonal entries of constrained dofs (what their rows of the operator hold).  They
+  // come from the point records the residual pass has just written, by the node-pair formula of SURVEY section 10 with
+  // a = b  [REF nonlinear_elasticity.cc:1011-1023]:
+  //   g = M^T grad_xi N_a,  t = tau g,  v = (c_II + c_S/2 + 4/3 p)/2 g - 2/3 t   (p = kappa/2 (J^2-1): tau_iso g = t - p g)
+  //   K_aa += w [ g (x) v + v (x) g + (c_S/2 g.g + g.t + alpha_1 rho N_a^2) I ]
+  // One wave per cell.  Stage 1, lane = quadrature point: material response from the record (the assembly's own
+  // function), 20 numbers per point to LDS.  Stage 2, lane = (node a, half h of the points): 32 points each, the point's
+  // numbers as LDS broadcasts, the lane's 1D table rows in registers; the two halves meet in LDS and the node's six
+  // numbers (xx yy zz xy xz yz) go to the cell's slot of the node (MfParams::dst, as the product's results): no two
+  // cells share a slot, so ONE launch covers all colours, and mf_diag_gather sums the slots of a node in processing order.
+  constexpr int DG_NF = 20; // M[9], tau[6], (c_II + c_S/2 + 4/3 p) w / 2, 2/3 w, c_S/2 w, w, alpha_1 rho w
+  template <bool BOX>
+  __global__ __launch_bounds__(64, 3) void mf_diag(MfParams prm, double *__restrict__ slots6)
+  {
+    constexpr int NPC = 27;
+    __shared__ __attribute__((aligned(16))) double sF[64 * DG_NF];
+    __shared__ double sR[NPC * 6];
+    const int     lane = threadIdx.x;
+    int64_t       cell = blockIdx.x;
+    if (prm.xcd_chunk > 0)
+      {
+        const int64_t local = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
+        if (local >= prm.count)
+          return;
+        cell = local;
+      }
+    // ---- stage 1: lane = quadrature point
+    {
+      double rec[MF_NREC];
+      const double *__restrict__ rp = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
+#pragma unroll
+      for (int f = 0; f < MF_NREC; ++f)
+        rec[f] = rp[f * 64];
+      const int    qz = lane >> 4;
+      const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
+      double       Finv[9], tau[6], tiso[6], cII, cS, M[9], detJ;
+      neo_hooke_from_F<3>(rec, det3x3(rec), rec[9], rec[10], prm.mu, prm.kappa, Finv, tau, tiso, cII, cS);
+      if constexpr (BOX)
+        {
+          const double *__restrict__ cb = prm.cellbox + cell * 4;
+          const double rx = cb[0], ry = cb[1], rz = cb[2];
+          detJ            = cb[3];
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            {
+              M[k]     = rx * Finv[k];
+              M[3 + k] = ry * Finv[3 + k];
+              M[6 + k] = rz * Finv[6 + k];
+            }
+        }
+      else
+        {
+          const double *__restrict__ cv = prm.cverts + cell * 24;
+          double verts[24], Jm[9], Ji[9];
+          const double xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
+#pragma unroll
+          for (int k = 0; k < 24; ++k)
+            verts[k] = cv[k];
+          q1_jacobian<3>(verts, xiq, Jm);
+          detJ = det3x3(Jm);
+          inv3x3(Jm, detJ, Ji);
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              M[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+        }
+      const double w  = detJ * wq;
+      const double pv = tau[0] - tiso[0]; // kappa/2 (J^2 - 1)
+      double      *o  = sF + lane * DG_NF;
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        o[k] = M[k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        o[9 + k] = tau[k];
+      o[15] = 0.5 * w * (cII + 0.5 * cS + (4.0 / 3.0) * pv);
+      o[16] = (2.0 / 3.0) * w;
+      o[17] = 0.5 * cS * w;
+      o[18] = w;
+      o[19] = prm.mass * w;
+    }
+    __syncthreads();
+    // ---- stage 2: lane = (a, h)
+    const int  h = lane >= NPC ? 1 : 0, a = lane - NPC * h;
+    const bool act = lane < 2 * NPC;
+    const int  a3 = a / 9, a2 = (a - 9 * a3) / 3, a1 = a - 9 * a3 - 3 * a2;
+    double     Sx[4], Dx[4], Sy[4], Dy[4], Sz[2], Dz[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      {
+        Sx[q] = prm.tab1d[q * 3 + (act ? a1 : 0)];
+        Dx[q] = prm.tab1d[12 + q * 3 + (act ? a1 : 0)];
+        Sy[q] = prm.tab1d[q * 3 + (act ? a2 : 0)];
+        Dy[q] = prm.tab1d[12 + q * 3 + (act ? a2 : 0)];
+      }
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+      {
+        Sz[z] = prm.tab1d[(2 * h + z) * 3 + (act ? a3 : 0)];
+        Dz[z] = prm.tab1d[12 + (2 * h + z) * 3 + (act ? a3 : 0)];
+      }
+    double K[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // xx yy zz xy xz yz
+    const double *__restrict__ fb = sF + h * (32 * DG_NF);
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+#pragma unroll
+      for (int qy = 0; qy < 4; ++qy)
+        {
+          const double syz = Sy[qy] * Sz[z], dyz = Dy[qy] * Sz[z], sdz = Sy[qy] * Dz[z];
+#pragma unroll
+          for (int qx = 0; qx < 4; ++qx)
+            {
+              const double *__restrict__ f = fb + (z * 16 + qy * 4 + qx) * DG_NF;
+              const double d0 = Dx[qx] * syz, d1 = Sx[qx] * dyz, d2 = Sx[qx] * sdz, N = Sx[qx] * syz;
+              double       g[3], t[3], v[3];
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+                g[j] = fma(d2, f[6 + j], fma(d1, f[3 + j], d0 * f[j]));
+              sym_mul(f + 9, g, t);
+              const double gg = fma(g[2], g[2], fma(g[1], g[1], g[0] * g[0]));
+              const double gt = fma(g[2], t[2], fma(g[1], t[1], g[0] * t[0]));
+              const double dd = fma(f[19] * N, N, fma(f[18], gt, f[17] * gg));
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+                v[j] = fma(-f[16], t[j], f[15] * g[j]);
+              K[0] = fma(2.0 * g[0], v[0], K[0]) + dd;
+              K[1] = fma(2.0 * g[1], v[1], K[1]) + dd;
+              K[2] = fma(2.0 * g[2], v[2], K[2]) + dd;
+              K[3] = fma(g[0], v[1], fma(v[0], g[1], K[3]));
+              K[4] = fma(g[0], v[2], fma(v[0], g[2], K[4]));
+              K[5] = fma(g[1], v[2], fma(v[1], g[2], K[5]));
+            }
+        }
+    if (h == 1 && act)
+#pragma unroll
+      for (int e = 0; e < 6; ++e)
+        sR[a * 6 + e] = K[e];
+    __syncthreads();
+    if (lane < NPC)
+      {
+        double *__restrict__ o = slots6 + int64_t(prm.dst[cell * NPC + lane]) * 6;
+#pragma unroll
+        for (int e = 0; e < 6; ++e)
+          o[e] = K[e] + sR[lane * 6 + e];
+      }
+  }
+
+  // the slots of every node summed in processing order under the rule of the assembled matrix ([DEAL.II]
+  // distribute_local_to_global as assemble_q2sf's scatter applies it): entries in the row or column of a constrained
+  // component are dropped, its diagonal receives |K_e(i,i)| of every cell.  Out: the block (what mf_spmv / the gathers
+  // read at constrained dofs and mi_get_diagonal_blocks returns), its inverse in full and as symmetric half (block-Jacobi
+  // smoother), 1 / diagonal (Jacobi).  Nodes without a row here (ghost planes of a slab): zeros, never read.
+  __global__ __launch_bounds__(256) void mf_diag_gather(const double *__restrict__ slots6, const int32_t *__restrict__ slot_base,
+                                                        const uint8_t *__restrict__ cmask, const int32_t *__restrict__ diagpos,
+                                                        double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes)
+  {
+    const int64_t n = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (n >= nnodes)
+      return;
+    double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, B[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (diagpos[n] >= 0)
+      {
+        const int     cm = cmask[n] & 7;
+        const int32_t b0 = slot_base[n], b1 = slot_base[n + 1];
+        double        s[6] = {0, 0, 0, 0, 0, 0};
+        for (int32_t k = b0; k < b1; ++k)
+          {
+            const double2 *__restrict__ p = reinterpret_cast<const double2 *>(slots6 + int64_t(k) * 6);
+            const double2 p0 = p[0], p1 = p[1], p2 = p[2];
+            double        v[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+              if ((cm >> c) & 1)
+                v[c] = fabs(v[c]);
+            if (cm & 3) // xy: row / column x or y constrained
+              v[3] = 0.0;
+            if (cm & 5)
+              v[4] = 0.0;
+            if (cm & 6)
+              v[5] = 0.0;
+#pragma unroll
+            for (int e = 0; e < 6; ++e)
+              s[e] = (k == b0) ? v[e] : s[e] + v[e];
+          }
+        A[0] = s[0], A[4] = s[1], A[8] = s[2];
+        A[1] = A[3] = s[3];
+        A[2] = A[6] = s[4];
+        A[5] = A[7] = s[5];
+        inv3x3(A, det3x3(A), B);
+      }
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      blk[n * 9 + k] = A[k];
+    if (dinv_blk)
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        dinv_blk[n * 9 + k] = B[k];
+    if (sym6)
+      {
+        double *q = sym6 + n * 6;
+        q[0] = B[0], q[1] = B[4], q[2] = B[8], q[3] = B[3], q[4] = B[6], q[5] = B[7];
+      }
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dinv[n * 3 + c] = diagpos[n] >= 0 ? 1.0 / A[c * 4] : 0.0;
   }
 
   // fp32-rounded copy of the value array for the multigrid smoother (opt-in "precond_storage" 32; same layout)
@@ -5078,6 +5326,19 @@ namespace mi
     dinv[i]          = dp >= 0 ? 1.0 / vals[int64_t(dp) * (D * D) + c * D + c] : 0.0;
   }
 
+  // the DxD diagonal block of every node out of the assembled tangent (mi_get_diagonal_blocks; nodes without a row: zeros)
+  template <int D>
+  __global__ __launch_bounds__(256) void gather_diag_blocks(const double *__restrict__ vals, const int32_t *__restrict__ diagpos,
+                                                            double *out, int64_t nnodes)
+  {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= nnodes * (D * D))
+      return;
+    const int64_t n  = i / (D * D);
+    const int32_t dp = diagpos[n];
+    out[i]           = dp >= 0 ? vals[int64_t(dp) * (D * D) + (i - n * (D * D))] : 0.0;
+  }
+
   // inverse of the DxD diagonal block of every node (block-Jacobi smoother of the multigrid).  Dirichlet rows and
   // columns of a block are unit rows/columns up to the kept diagonal, so the block stays invertible.
   template <int D>
@@ -5757,6 +6018,29 @@ namespace mi
   {
     hipLaunchKernelGGL(mf_gather, dim3(int((ndofs + 255) / 256)), dim3(256), 0, s, p, ndofs);
   }
+  void launch_mf_gather_dot(const MfParams &p, int64_t ndofs, const double *dotv, double *partials, int grid, int64_t own0,
+                            int64_t own_n, hipStream_t s)
+  {
+    hipLaunchKernelGGL(mf_gather_dot, dim3(grid), dim3(256), 0, s, p, ndofs, dotv, partials, own0, own_n);
+  }
+  void launch_mf_diag(const MfParams &p, double *slots6, int32_t cell_count, hipStream_t s)
+  {
+    if (cell_count <= 0)
+      return;
+    MfParams q  = p;
+    q.count     = cell_count;
+    q.xcd_chunk = (cell_count + 7) / 8; // as mf_spmv: an XCD takes a contiguous run of cells
+    if (q.cellbox)
+      hipLaunchKernelGGL(mf_diag<true>, dim3(q.xcd_chunk * 8), dim3(64), 0, s, q, slots6);
+    else
+      hipLaunchKernelGGL(mf_diag<false>, dim3(q.xcd_chunk * 8), dim3(64), 0, s, q, slots6);
+  }
+  void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const uint8_t *cmask, const int32_t *diagpos,
+                             double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s)
+  {
+    hipLaunchKernelGGL(mf_diag_gather, dim3(int((nnodes + 255) / 256)), dim3(256), 0, s, slots6, slot_base, cmask, diagpos, blk,
+                       dinv, dinv_blk, sym6, nnodes);
+  }
 
   void launch_ebe_spmv(const EbeParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s, hipEvent_t ev_start,
                        hipEvent_t ev_stop)
@@ -5805,6 +6089,14 @@ namespace mi
       hipLaunchKernelGGL((extract_dinv_blk<3>), dim3(grid), dim3(256), 0, s, vals, diagpos, dinv, sym6, nnodes);
     else
       hipLaunchKernelGGL((extract_dinv_blk<2>), dim3(grid), dim3(256), 0, s, vals, diagpos, dinv, (double *)nullptr, nnodes);
+  }
+  void launch_gather_diag_blocks(int dim, const double *vals, const int32_t *diagpos, double *out, int64_t nnodes, hipStream_t s)
+  {
+    const int64_t n = nnodes * dim * dim;
+    if (dim == 3)
+      hipLaunchKernelGGL((gather_diag_blocks<3>), dim3(int((n + 255) / 256)), dim3(256), 0, s, vals, diagpos, out, nnodes);
+    else
+      hipLaunchKernelGGL((gather_diag_blocks<2>), dim3(int((n + 255) / 256)), dim3(256), 0, s, vals, diagpos, out, nnodes);
   }
   void launch_blk_apply(int dim, double *out, const double *a, const double *dinv, int64_t nnodes, hipStream_t s)
   {

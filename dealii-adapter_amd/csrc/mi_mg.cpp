@@ -626,7 +626,7 @@ namespace mi_detail
     const size_t nl = c0->mg->levels.size();
     int          rc;
     for (mi_ctx *m : T.members)
-      if (m->mg->block && !m->d_dinv_blk) // switched on after the fine tangent was assembled
+      if (m->mg->block && !m->d_dinv_blk && !m->mf_fine) // switched on after the fine tangent was assembled
         {
           HIPCHK(m, hipMalloc((void **)&m->d_dinv_blk, size_t(m->mesh.nnodes) * m->dim * m->dim * sizeof(double)));
           if (!m->d_dinv_sym6 && m->dim == 3)
@@ -712,6 +712,8 @@ namespace mi_detail
       for (mi_ctx *m : T.members)
         {
           const mi_ctx *lc = m->mg->levels[l].ctx;
+          if (lc->mf_fine) // no assembled rows to fuse an epilogue into (the matrix-free gather takes the step instead)
+            return false;
           if (lc->spmv_variant != 3 || (mg0.fuse == 1 && lc->mesh.nnodes > mg0.fuse_max_nodes))
             return false;
         }

@@ -35,7 +35,8 @@ namespace Nonlinear_Elasticity
         if (mi_get_timings(device->ctx(), &t) == MI_OK)
           {
             static const char *names[MI_T_COUNT] = {"assemble cells", "assemble total", "SpMV (CG)", "CG vector kernels",
-                                                    "CG total",       "Newmark",        "step (host wall)", "sliced-ELL copy"};
+                                                    "CG total",       "Newmark",        "step (host wall)", "diagonal blocks",
+                                                    "residual pass",  "SpMV (smoother)", "matrix-free launch"};
             std::cout << "\nDevice timings (ms, launches):" << std::endl;
             for (int i = 0; i < MI_T_COUNT; ++i)
               std::cout << "  " << std::left << std::setw(20) << names[i] << std::right << std::setw(12) << std::fixed

@@ -233,6 +233,10 @@ int mi_vec_set(mi_ctx *ctx, int which, const double *host, int64_t n);
 /* tangent as scalar CSR (host arrays: rowptr n_dofs+1 (int64), col nnz (int32), val nnz) */
 int mi_matrix_get_csr(mi_ctx *ctx, int64_t *rowptr, int32_t *col, double *val);
 int mi_spmv(mi_ctx *ctx, const double *x_host, double *y_host); /* y = K x through the device kernel */
+/* the dim x dim diagonal block of every node of the current tangent (host array [n_nodes][dim * dim], row-major, node order of
+ * the reference) under the constraint rule of the assembly (nonlinear_elasticity.cc:760-774): out of the assembled tangent or,
+ * with "fine_level" 1, as formed from the point records.  One process only (single or emulated slabs). */
+int mi_get_diagonal_blocks(mi_ctx *ctx, double *blocks);
 
 /* per-kernel-class device timings from HIP events on the context's stream */
 enum
@@ -244,7 +248,8 @@ enum
   MI_T_CG_TOTAL,
   MI_T_NEWMARK,
   MI_T_STEP,               /* whole mi_newmark_step                           */
-  MI_T_SELL_COPY,          /* block-CSR -> sliced-ELL copy before the first product with a new tangent */
+  MI_T_ASSEMBLE_DIAG,      /* matrix-free fine level ("fine_level" 1): diagonal blocks from the point records, per tangent
+                              (this slot was the block-CSR -> sliced-ELL copy until round 2; no such copy exists)  */
   MI_T_ASSEMBLE_RESIDUAL,  /* all colours of one residual-only pass (mi_assemble_residual)              */
   MI_T_SPMV_PRECOND,       /* fine-level products of the multigrid preconditioner, per product                */
   MI_T_EBE_LAUNCH,         /* single launches of ebe_spmv (one colour of one element-tangent product), timed from
@@ -282,6 +287,13 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *  correct_face_F       0 | 1                      Neumann pull-back with F of CELL point fq (the reference's quirk,    MI_CORRECT_FACE_F
  *                                                  :825-827) | with F at the face point
  *  OPERATOR FORMS
+ *  fine_level           0 | 1                      3D Q2: the fine level assembled (global tangent + sell_spmv: the     -
+ *                                                  north-star path) | matrix-free end to end: a tangent assembly writes
+ *                                                  point records, residual and the nodes' diagonal blocks only; the CG's
+ *                                                  product, residual / start-vector products and the smoother run on
+ *                                                  mf_spmv; the assembled tangent's memory is released.  Same results
+ *                                                  (nonlinear_elasticity.cc:1044-1087, 1153-1191); excludes
+ *                                                  "solver_type" 1, "precond_storage" 32 and matrix export
  *  smoother_operator    2 | 1 | 0                  fine-level products of the smoother on 3D Q2 slabs > 100 k nodes:    MI_EBE
  *                                                  matrix-free from the assembly's point records | stored element
  *                                                  tangents | assembled matrix
