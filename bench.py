@@ -420,7 +420,10 @@ def main():
             assemblies += info.assemblies
         barrier()
         elapsed = time.perf_counter() - t0
+        per_rank = [elapsed]
         if world > 1:
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, elapsed)  # every rank's own clock over the window (control plane, gloo)
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -429,7 +432,7 @@ def main():
                                                         "cg_iterations", "cg_solves", "mg_refresh")}
         cnt["mg_refresh_every"] = G.get_tuning("mg_refresh_every")
         r = {"G": G, "elapsed": elapsed, "lin_its_last": lin_its_last, "counts": cnt, "newton": newton, "cg_its": cg_its, "assemblies": assemblies, "nz": nz,
-             "tm": G.timings(), "comm": G.comm_info()}
+             "tm": G.timings(), "comm": G.comm_info(), "per_rank_s": per_rank}
         return r
 
     R = measure(args.scaling, n, args.steps, args.warmup, uid)
@@ -477,7 +480,8 @@ def main():
                  "%d slabs cut along %s (one per GPU; automatic choice: the direction with most cell layers, ties -> z), ghost-cell "
                  "redundant assembly, RCCL send/recv halo + all-reduce" % (world, " xyz"[G.get_tuning("cut_axis")])),
                 "team_size": R["comm"][0],
-                "rccl_ranks": R["comm"][1],
+                "rccl_ranks": R["comm"][1],  # ncclCommCount of the library's communicator (0: no RCCL in this run)
+                "per_rank_ms_per_step": [1e3 * t / args.steps for t in R["per_rank_s"]],  # each rank's own clock; value uses the max
                 "newton_iterations_per_step": R["newton"] / args.steps,
                 "cg_iterations_per_step": R["cg_its"] / args.steps,
                 "assemblies_per_step": R["assemblies"] / args.steps,
@@ -507,7 +511,8 @@ def main():
                                             "refreshes_in_timed_steps": R["counts"]["mg_refresh"]},
                 "ms_assembly_per_step": tm["assemble_total"][0] / args.steps,
                 "ms_cg_per_step": tm["cg_total"][0] / args.steps,
-                "ms_sell_copy_per_step": tm["sell_copy"][0] / args.steps,
+                "ms_diagonal_blocks_per_step": tm["assemble_diag"][0] / args.steps,  # matrix-free fine level only
+                "fine_level": args.fine_level,
                 "ms_assemble_cells_per_assembly": tm["assemble_cells"][0] / max(tm["assemble_cells"][1], 1),
                 "ms_assemble_residual_only_pass": tm["assemble_residual"][0] / max(tm["assemble_residual"][1], 1),
                 "tangent_assemblies_per_step": tm["assemble_cells"][1] / args.steps,
@@ -551,7 +556,7 @@ def main():
         step_bytes = (spmv_n / args.steps * spmv_bytes(G.nnodes, nnzb, 3) +
                       tm["spmv_precond"][1] / args.steps * (ebe_bytes if ebe else spmv_bytes(G.nnodes, nnzb, 3)) +
                       tm["assemble_cells"][1] / args.steps * asm_bytes +
-                      tm["assemble_residual"][1] / args.steps * res_bytes + tm["sell_copy"][1] / args.steps * 16 * G.nnz +
+                      tm["assemble_residual"][1] / args.steps * res_bytes +
                       120 * G.n) / share
         out["config"]["smoother_operator"] = (
             "matrix-free from the quadrature-point records of the assembly (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 2
@@ -670,38 +675,55 @@ def main():
                                    "cg_iterations_per_step": W["cg_its"] / args.steps}
         del W
     if world == 1 and args.slabs == 1:
-        # the other start vectors, measured beside the headline (3 steps each): zero for every solve, and the reference's
-        # (the previous Newton update, nonlinear_elasticity.cc:419,472)
+        # Further measurements beside the headline, each over the SAME step window as the headline (the same warm-up
+        # steps, the same ramp phase, the same coarse-operator refreshes inside the window): `steps` / `warmup` in every
+        # sub-object say so.  (Until round 5 these ran 3 steps after 1 warm-up and were indicative only.)
+        def side(**kw):
+            S = measure(args.scaling, n, args.steps, args.warmup, None, **kw)
+            r = {"ms_per_step": 1e3 * S["elapsed"] / args.steps, "value": S["G"].n * args.steps / S["elapsed"],
+                 "cg_iterations_per_step": S["cg_its"] / args.steps, "cg_iterations_last_step": S["lin_its_last"],
+                 "newton_iterations_per_step": S["newton"] / args.steps, "steps": args.steps, "warmup": args.warmup,
+                 "window": "the headline's: steps %d..%d of the ramp" % (args.warmup + 1, args.warmup + args.steps),
+                 "ms_assembly_per_step": S["tm"]["assemble_total"][0] / args.steps, "ms_cg_per_step": S["tm"]["cg_total"][0] / args.steps}
+            tmS = S["tm"]
+            del S
+            return r, tmS
+
+        # the other start vectors: zero for every solve, and the reference's (the previous Newton update,
+        # nonlinear_elasticity.cc:419,472)
         for other in ("zero", "previous-update", "previous-step"):
             if other == args.cg_start or (other == "previous-step" and args.cg_start == "extrapolated"):
                 continue
-            S = measure(args.scaling, n, 3, 1, None, cg_start=other)
-            out["config"]["with_cg_start_" + other.replace("-", "_")] = {
-                "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"], "cg_iterations_per_step": S["cg_its"] / 3,
-                "cg_iterations_last_step": S["lin_its_last"], "steps": 3, "warmup": 1}
-            del S
+            out["config"]["with_cg_start_" + other.replace("-", "_")], _ = side(cg_start=other)
         if args.smoother_precision == "f64" and args.smoother_operator == "matrix-free" and n >= 24:
             # opt-in A/B beside the headline: the smoother's matrix-free products in fp32 (preconditioner-only change)
-            S = measure(args.scaling, n, 3, 1, None, smoother_precision="f32")
-            out["config"]["with_smoother_precision_f32"] = {
-                "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"],
-                "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1,
-                "note": "opt-in, not the headline: fp32 arithmetic and records in the smoother's fine-level products only"}
-            del S
-        if args.cg_operator == "assembled" and n >= 24:
+            out["config"]["with_smoother_precision_f32"], _ = side(smoother_precision="f32")
+            out["config"]["with_smoother_precision_f32"]["note"] = (
+                "opt-in, not the headline: fp32 arithmetic and records in the smoother's fine-level products only")
+        if args.cg_operator == "assembled" and args.fine_level == "assembled" and n >= 24:
             # opt-in A/B beside the headline: the CG's own product on the element tangents too (no sliced-ELL copy);
             # not the default because north_star names the product on the assembled matrix
-            S = measure(args.scaling, n, 3, 1, None, cg_operator="element")
-            out["config"]["with_cg_operator_element"] = {
-                "ms_per_step": 1e3 * S["elapsed"] / 3, "value": S["G"].n * 3 / S["elapsed"],
-                "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1}
-            del S
+            out["config"]["with_cg_operator_element"], _ = side(cg_operator="element")
+        if args.fine_level == "assembled" and n >= 8:
+            # Round 6: the fine level matrix-free END TO END -- no assembled fine tangent: a tangent assembly = residual pass
+            # that also writes the point records + the nodes' diagonal blocks from them (mf_diag); the CG's product, residual
+            # and start-vector products and the smoother all on mf_spmv.  Same converged steps (oracle tests parametrised
+            # over it).  `value` stays on the north-star path (global CSR + sell_spmv); this is the second number.
+            r, tmS = side(fine_level="matrix-free")
+            r["ms_tangent_pass_records_residual"] = tmS["assemble_cells"][0] / max(tmS["assemble_cells"][1], 1)
+            r["ms_diagonal_blocks"] = tmS["assemble_diag"][0] / max(tmS["assemble_diag"][1], 1)
+            r["ms_cg_product"] = tmS["spmv"][0] / max(tmS["spmv"][1], 1)
+            r["tangent_assemblies_per_step"] = tmS["assemble_cells"][1] / args.steps
+            r["note"] = ("tuning \"fine_level\" 1 (bench.py --fine-level matrix-free): no global fine tangent is assembled or "
+                         "stored (7.6 GB at 5 M DoFs released); not the headline because north_star names the CSR + SpMV path")
+            out["config"]["with_matrix_free_fine_level"] = r
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         # the GPU on the CPU sample's own configuration, beside it
         if args.cpu_cells != n or args.slabs != 1:
             S = measure("strong", args.cpu_cells, 3, 1, None)
             gpu_same = {"value": S["G"].n * 3 / S["elapsed"], "ms_per_step": 1e3 * S["elapsed"] / 3, "n_dofs": S["G"].n,
-                        "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1}
+                        "cg_iterations_per_step": S["cg_its"] / 3, "steps": 3, "warmup": 1,
+                        "window": "steps 2..4 of the ramp (the CPU leg times the first step of the same mesh)"}
             del S
         else:
             gpu_same = {"value": out["value"], "ms_per_step": out["ms_per_step"], "n_dofs": out["config"]["n_dofs"]}

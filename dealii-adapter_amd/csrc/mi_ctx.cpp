@@ -1065,6 +1065,7 @@ namespace mi_detail
     // (pays while one CU can stream the matrix from the L2 faster than three launches take: ~130 GB/s vs ~18 us,
     // i.e. up to ~1 MB of matrix values; measured with tools/small_case_latency.py)
     if (!dist && !use_mg && c0->small_cg && max_it > 0 && (c0->spmv_variant == 3 || c0->active_sell_vals) &&
+        !(c0->mf_fine && !c0->active_sell_vals) && // (the one-launch solver streams the assembled rows)
         c0->mesh.sell_nblk64 * 64 * int64_t(c0->dim * c0->dim) * 8 <= SMALL_CG_MAX_MATRIX_BYTES)
       {
         mi::launch_cg_small(c0->dim, sell_params(c0, nullptr, nullptr, nullptr, nullptr, nullptr), cgs[0],

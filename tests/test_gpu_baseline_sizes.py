@@ -75,7 +75,7 @@ def test_oracle_reproduces_config2_fixture():
 
 
 def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, slabs=1, cut_axis=0, dist_nodes=None,
-               smoother_precision=64):
+               smoother_precision=64, fine_level=0):
     g = _g()
     n = int(g[name + "_cells"])
     # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
@@ -92,6 +92,9 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, s
     G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
     if smoother_precision != 64:
         G.set_tuning("smoother_precision", smoother_precision)
+    if fine_level:  # round 6: no assembled fine tangent -- records + residual + diagonal blocks, every product on mf_spmv
+        G.set_tuning("fine_level", 1)
+        assert G.get_tuning("fine_level") == 1
     ids = g[name + "_nodes"]
     for s, trac in enumerate(g[name + "_traction"]):
         G.set_interface_traction(trac)
@@ -105,8 +108,11 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, s
         for k, which in ((1, M.V_V), (2, M.V_A)):
             assert _relfun(G.get(which), g[name + "_fun"][s][k]) < tol_va
     # 3D Q2: the matrix-free smoother was what ran; the other elements smooth with the assembled matrix
-    if slabs == 1:  # (a slab of a quarter of this block is below the size at which the matrix-free form is chosen)
+    if slabs == 1 or fine_level:  # (a slab of a quarter of this block is below the size at which the matrix-free form is chosen)
         assert G.get_tuning("smoother_operator_active") == (2 if (dim, degree) == (3, 2) else 0)
+    if fine_level:  # nothing was assembled: no matrix to export
+        with pytest.raises(M.MiError):
+            G.csr()
     assert _rel(G.get(M.V_V).reshape(-1, dim)[ids], g[name + "_v"]) < tol_va
     assert _rel(G.get(M.V_A).reshape(-1, dim)[ids], g[name + "_a"]) < tol_va  # amplified by 1/dt^2
     G.close()
@@ -146,6 +152,20 @@ def test_gpu_fp32_smoother_products_against_the_oracle(name, slabs):
     [REF nonlinear_elasticity.cc:1171-1174] stay fp64, so the converged steps are the oracle's to the same tolerances as with
     the fp64 smoother (Newton tables equal, displacement 1e-8, velocity / acceleration 1e-6).  Not the headline setting."""
     _nonlinear(name, 1e-8, 1e-6, 2, slabs=slabs, smoother_precision=32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,slabs,cut_axis,start,distorted",
+                         [("blk24", 1, 0, 0, False), ("blk24", 1, 0, 2, False), ("blk24d", 1, 0, 2, True), ("blk24", 3, 1, 2, False),
+                          ("cfg3", 1, 0, 2, False), ("cfg3", 4, 0, 2, False), ("cfg4s", 1, 0, 2, False), ("cfg4s", 8, 0, 2, False)])
+def test_gpu_matrix_free_fine_level_against_the_oracle(name, slabs, cut_axis, start, distorted):
+    """round 6, tuning "fine_level" 1: the fine level keeps NO assembled tangent -- a tangent assembly is the residual pass
+    that writes the point records plus the nodes' diagonal blocks formed from them (mf_diag), and the CG's product, the
+    residual / start-vector products and the smoother all run on mf_spmv.  Same fixtures, same tolerances, same Newton
+    tables as the assembled path (the oracle's steps [REF nonlinear_elasticity.cc:410-499, 1044-1087, 1153-1191]): boxes and
+    distorted cells, one slab and decomposed (the CG's matrix-free product around the halo exchange), BASELINE
+    configurations 3 and 4 on 1 and 4 / 8 slabs."""
+    _nonlinear(name, 1e-8, 1e-6, start, distorted=distorted, slabs=slabs, cut_axis=cut_axis, fine_level=1)
 
 
 @pytest.mark.gpu

@@ -28,9 +28,10 @@ def _pair(dim, degree, reps, perturb_amp=0.0, seed=0, roles=None, **kw):
         perturb = perturb_amp * 0.1 * np.random.default_rng(seed).standard_normal((nverts, dim))
     if roles is None:
         roles = [O.FACE_CLAMPED] + [O.FACE_INTERFACE] * 5
+    gkw = {k: kw.pop(k) for k in ("slabs", "cut_axis") if k in kw}  # the device side alone: emulated slabs
     d = O.make_desc(dim=dim, degree=degree, reps=reps, lo=lo, hi=hi, face_role=roles, **kw)
     P = O.Problem(d, perturb)
-    G = M.Context(dim=dim, degree=degree, reps=reps, lo=lo, hi=hi, face_role=roles, perturb=perturb, **kw)
+    G = M.Context(dim=dim, degree=degree, reps=reps, lo=lo, hi=hi, face_role=roles, perturb=perturb, **kw, **gkw)
     return P, G
 
 
@@ -223,6 +224,92 @@ def test_element_kernel_variants_agree():
         assert np.abs(y - ref[0]).max() / np.abs(ref[0]).max() < 1e-13, v
         assert np.abs(r - ref[1]).max() / np.abs(ref[1]).max() < 1e-13, v
         assert abs(rn - ref[2]) / ref[2] < 1e-13
+
+
+def _diag_blocks_of(K, dim):
+    """[n_nodes, dim, dim] diagonal blocks of a scipy CSR matrix"""
+    nn = K.shape[0] // dim
+    D, base = np.zeros((nn, dim, dim)), np.arange(nn) * dim
+    for i in range(dim):
+        for j in range(dim):
+            D[:, i, j] = np.asarray(K[base + i, base + j]).ravel()
+    return D
+
+
+@pytest.mark.parametrize("perturb_amp,reps,slabs", [(0.0, (4, 3, 5), 1), (0.05, (4, 3, 5), 1), (0.05, (3, 3, 7), 2), (0.0, (2, 1, 1), 1)])
+def test_matrix_free_fine_level_against_the_oracle(perturb_amp, reps, slabs):
+    """round 6, tuning "fine_level" 1: nothing of the fine tangent is assembled.  What the level keeps of it -- the residual,
+    the operator (every product through mf_spmv from the point records, constrained rows / columns and their diagonal
+    rule included) and the nodes' diagonal blocks formed from the records (mf_diag; |K_e(i,i)| on the diagonal of a
+    constrained dof, its row and column dropped: deal.II's distribute_local_to_global as the scatter applies it
+    [REF nonlinear_elasticity.cc:760-774, 1011-1023]) -- against the oracle's assembled system; boxes and distorted cells,
+    clamped and z-clamped faces, one slab and two; the converged Newton update of a Jacobi-PCG on that operator too."""
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+    P, G = _pair(3, 2, reps, perturb_amp=perturb_amp, seed=21, roles=roles, body_force=(0.0, -9.81, 2.0), slabs=slabs)
+    G.set_tuning("fine_level", 1)
+    with pytest.raises(M.MiError):  # no tangent yet: a product has nothing to multiply with
+        G.spmv(np.ones(G.n))
+    rng = np.random.default_rng(23)
+    for rnd in range(2):
+        _randomise_state(P, G, seed=22 + rnd)
+        P.update_acceleration()
+        P.assemble()
+        G.update_acceleration()
+        rn = G.assemble()
+        K = P.csr()
+        assert abs(rn - P.residual_norm()) / P.residual_norm() < 1e-12
+        assert _relmax(G.get(M.V_RHS), P.vec(O.V_RHS)) < TOL_ASM
+        D_o, D_g = _diag_blocks_of(K, 3), G.diagonal_blocks()
+        assert _relmax(D_g, D_o) < TOL_ASM
+        cons = P.constrained.reshape(-1, 3)
+        for c in range(3):  # constrained dofs: unit row / column up to the kept diagonal, exactly
+            assert np.all(D_g[cons[:, c], c, (c + 1) % 3] == 0) and np.all(D_g[cons[:, c], (c + 2) % 3, c] == 0)
+        x = rng.standard_normal(G.n)
+        y = G.spmv(x)
+        assert _relmax(y, K @ x) < 1e-13
+        assert np.array_equal(G.spmv(x), y)  # fixed summation order
+        assert G.assemble_residual() == rn and _relmax(G.get(M.V_RHS), P.vec(O.V_RHS)) < TOL_ASM
+        assert np.array_equal(G.spmv(x), y)  # the residual-only pass left the tangent's records alone
+    with pytest.raises(M.MiError):
+        G.csr()
+    G.set_tuning("precond", 0)
+    rc, its, res = G.cg_solve(1e-12, 4 * G.n)
+    rc_o, its_o, _ = P.solve_linear(O.SOLVER_CG_JACOBI, tol_lin=1e-12, max_it_mult=4.0)
+    assert rc == 0 and rc_o == 0
+    assert _relmax(G.get(M.V_NEWTON), P.vec(O.V_NEWTON)) < TOL_SOL
+    # ... and back: the assembled level returns with the next assembly
+    G.set_tuning("fine_level", 0)
+    G.assemble()
+    if slabs == 1:  # (matrix export: undecomposed meshes only)
+        assert _relmax(G.csr().data, K.data) < TOL_ASM
+    assert _relmax(G.spmv(x), K @ x) < 1e-13
+    assert _relmax(G.diagonal_blocks(), D_o) < TOL_ASM
+
+
+def test_fp32_smoother_records_follow_the_kernel_that_wrote_them():
+    """only the sum-factorised kernel writes the fp32 point records; with the node-pair kernel ("asm_variant" 9)
+    the opt-in fp32 smoother product must fall back to the fp64 records instead of multiplying with stale / uninitialised
+    fp32 ones -- the preconditioned solve converges to the same update either way"""
+    reps = (6, 6, 6)
+    G = M.Context(dim=3, degree=2, reps=reps)
+    G.set_tuning("precond", 1)
+    G.set_tuning("element_tangents", 2)
+    G.set_tuning("smoother_precision", 32)
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    ref = None
+    for v in (9, 0):
+        G.set_tuning("asm_variant", v)
+        G.newton_begin_step()
+        G.update_acceleration()
+        G.assemble()
+        rc, its, res = G.cg_solve(1e-10, 2 * G.n)
+        assert rc == 0 and 0 < its < 40, (v, its)
+        du = G.get(M.V_NEWTON)
+        assert np.all(np.isfinite(du))
+        if ref is None:
+            ref = (du, its)
+        else:
+            assert _relmax(du, ref[0]) < 1e-7 and abs(its - ref[1]) <= 2
 
 
 @pytest.mark.parametrize("form", [1, 2])
