@@ -222,6 +222,10 @@ namespace mi_detail
     p.ke      = c->d_ke;
     p.qrec    = c->d_qrec;
     p.qrec32  = (c->d_qrec && c->smoother_precision == 32) ? c->d_qrec32 : nullptr;
+    p.cellbox = c->d_cellbox;
+    p.from_records = c->d_qrec ? c->asm_split : 0;
+    if (p.from_records) // both kernels of the pair take the node ids by lattice arithmetic (as mf_spmv)
+      p.lat = c->lat;
     p.inverted = c->d_sc + SC_INVERTED;
     p.correct_face_F = c->correct_face_F;
     p.axmap    = 0;
@@ -2720,6 +2724,8 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         c->team->overlap = value;
       else if (k == "asm_variant" && value >= 0 && value <= 9)
         m->asm_variant = value;
+      else if (k == "asm_split" && value >= 0 && value <= 2) // 3D Q2 with point records: point pass + tangent from the records (1, default) | one fused kernel
+        m->asm_split = value;
       else if (k == "mg_refresh_every" && value >= 1 && value <= 1000)
         m->mg_refresh_every = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))

@@ -227,6 +227,7 @@ struct mi_ctx
   bool                  mg_stale = true; // the coarse operators belong to an older state than the fine tangent
   bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
   int                   asm_variant = 0;
+  int                   asm_split = 1;   // 3D Q2, point records present: the tangent in two kernels (round 6; 0: the fused kernel of round 5)
   int                   mg_lag   = 1;    // 1: keep the coarse operators over the Newton iterations of one step
   // ... and over time steps: refreshed at the first solve of every k-th step, or before the next solve when one
   // needed a quarter (at least 2) more iterations than the first solve after the last refresh (mg_its_ref)

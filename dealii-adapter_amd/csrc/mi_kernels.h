@@ -63,6 +63,8 @@ namespace mi
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
     CellLattice     lat;    // 3D Q2: node ids by arithmetic (ncol == 0: read conn)
+    const double   *cellbox;  // [ncells][4] = 1/hx, 1/hy, 1/hz, hx hy hz when every local cell is an axis-parallel box, else null
+    int32_t         from_records; // 3D Q2, records present: tangent in two kernels -- point pass, then the tangent from its records
     int32_t         correct_face_F; // Neumann term: 0 (default) = the reference's pull-back with the deformation gradient of CELL
                                     // quadrature point fq (nonlinear_elasticity.cc:825-827), 1 = F at the
                                     // face quadrature point itself (the physically consistent pull-back; the oracle's switch)

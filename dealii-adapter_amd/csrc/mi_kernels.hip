@@ -787,11 +787,20 @@ namespace mi
   __global__ __launch_bounds__(RES_ONLY ? 64 : 256, RES_ONLY ? 4 : 3) void assemble_q2sf(AsmParams prm)
   {
     constexpr bool V2 = !RES_ONLY && (XV & 4) != 0, SLIM = !RES_ONLY && (XV & 128) != 0;
+    // bit 8 (round 6, the default where point records exist): the tangent FROM THE RECORDS.  The residual pass (RES_ONLY,
+    // one wave per cell at mf_spmv's occupancy) has gathered, differentiated and written F, J^(-2/3), 1/J of every point; this
+    // kernel starts there: ALL FOUR waves recompute the material response of the cell's 64 points from the records (lane =
+    // point, the assembly's own function, ~350 instructions), each writes a quarter of the 45 fields, and the contractions
+    // begin after ~5 k clocks instead of behind one wave's 18.8 k-clock chain of gather, gradients, kinematics and fields;
+    // wave 0 then builds the block table beside the contractions.  No residual here.
+    constexpr bool REC = !RES_ONLY && (XV & 256) != 0;
+    constexpr bool RECW0 = !RES_ONLY && (XV & 512) != 0; // (see wave 0)
+    static_assert(!REC || (V2 && SLIM), "the record form builds on the 45-field kernel with the branch-free scatter");
     constexpr int NPC = 27, FS = 66, NF = V2 ? 46 : 82; // field stride (padded: fields of different ij on different banks), fields
     constexpr int PS = 20, PW = 9 * PS, AO = 552;
     constexpr int MASSF = NF - 1;                       // the mass field
     __shared__ __attribute__((aligned(16))) double s_C[RES_ONLY ? 2 : (NF * FS > 9 * EBE_NBLK ? NF * FS : 9 * EBE_NBLK)]; // later the element tangent [9][378]
-    __shared__ __attribute__((aligned(16))) double s_w[768 + 216];              // wave 0's scratch (as in mf_spmv)
+    __shared__ __attribute__((aligned(16))) double s_w[REC ? 2 : 768 + 216];    // wave 0's scratch (as in mf_spmv)
     __shared__ uint64_t s_tab[V2 ? NPC * NPC : 1];                              // V2: the block table (wave 3 builds it during the prologue)
     __shared__ int  s_conn[NPC];
     __shared__ int2 s_ri[RES_ONLY ? 1 : NPC]; // rowinfo of the cell's nodes (where their rows are in the global matrix)
@@ -957,11 +966,192 @@ namespace mi
     }
     };
 
+    if constexpr (REC)
+      {
+        // ================================================================= every wave: the fields from the point records
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        double    rec[MF_NREC];
+        {
+          const double *__restrict__ rp = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
+#pragma unroll
+          for (int f = 0; f < MF_NREC; ++f)
+            rec[f] = rp[f * 64];
+        }
+        int2 ri_l = make_int2(0, 0);
+        int  cm_l = 0;
+        if (tid < NPC) // wave 0: where the cell's rows are (for the block table it builds beside the contractions); kept in
+          {            // registers until the fields are out, so that the loads travel beside the arithmetic
+            int32_t node;
+            if (prm.lat.ncol > 0)
+              {
+                const int32_t node0 = lattice_node0(prm.lat, cell);
+                const int     k9 = lane / 9, r9 = lane - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
+                node               = node0 + i3 + j3 * prm.lat.nn0 + k9 * prm.lat.nn01;
+              }
+            else
+              node = prm.conn[cell * NPC + lane];
+            ri_l = prm.rowinfo[node];
+            cm_l = prm.cmask[node] & 7;
+          }
+        const int    qz = lane >> 4;
+        const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
+        double       Mr[9], detJ;
+        double       Finv[9], tauq[6], tisoq[6], cII, cS;
+        neo_hooke_from_F<3>(rec, det3x3(rec), rec[9], rec[10], prm.mu, prm.kappa, Finv, tauq, tisoq, cII, cS);
+        if (prm.cellbox) // every local cell an axis-parallel box: 1/h and the volume
+          {
+            const double *__restrict__ cb = prm.cellbox + cell * 4;
+            const double rx = cb[0], ry = cb[1], rz = cb[2];
+            detJ            = cb[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+              {
+                Mr[k]     = rx * Finv[k];
+                Mr[3 + k] = ry * Finv[3 + k];
+                Mr[6 + k] = rz * Finv[6 + k];
+              }
+          }
+        else
+          {
+            const double *__restrict__ cv = prm.cverts + cell * 24;
+            const double xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
+            double       verts[24], Jm[9], Ji[9];
+#pragma unroll
+            for (int k = 0; k < 24; ++k)
+              verts[k] = cv[k];
+            q1_jacobian<3>(verts, xiq, Jm);
+            detJ = det3x3(Jm);
+            inv3x3(Jm, detJ, Ji);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < 3; ++j)
+                Mr[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+          }
+        const double wr = detJ * wq;
+        const double Tq[3][3]  = {{tauq[0], tauq[3], tauq[4]}, {tauq[3], tauq[1], tauq[5]}, {tauq[4], tauq[5], tauq[2]}};
+        const double Tiq[3][3] = {{tisoq[0], tisoq[3], tisoq[4]}, {tisoq[3], tisoq[1], tisoq[5]}, {tisoq[4], tisoq[5], tisoq[2]}};
+        const double cs2       = 0.5 * cS;
+        double       Tm[3][3], A[3][3], B[3][3], E[3][3], MT[3][3], Sk[3][3] = {};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            {
+              Tm[k][i] = (-2.0 / 3.0) * (Mr[k * 3] * Tiq[0][i] + Mr[k * 3 + 1] * Tiq[1][i] + Mr[k * 3 + 2] * Tiq[2][i]);
+              MT[k][i] = Mr[k * 3] * Tq[0][i] + Mr[k * 3 + 1] * Tq[1][i] + Mr[k * 3 + 2] * Tq[2][i]; // (M tau)_ki
+            }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+            {
+              A[k][i] = wr * (cII * Mr[k * 3 + i] + Tm[k][i]);
+              B[k][i] = wr * Mr[k * 3 + i];
+              E[k][i] = (wr * cs2) * Mr[k * 3 + i];
+            }
+        // the fields of the pair (i, j), i <= j (for i == j: k <= l, with S_kl on top) -- the expressions of the fused kernel
+        auto emit_pair = [&](auto I_, auto J_) __attribute__((always_inline)) {
+          constexpr int i = decltype(I_)::value, j = decltype(J_)::value;
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+              {
+                if (i == j && k > l)
+                  continue;
+                double c = A[k][i] * Mr[l * 3 + j] + B[k][i] * Tm[l][j] + E[k][j] * Mr[l * 3 + i];
+                if (i == j)
+                  c += Sk[k][l];
+                s_C[q2sf_field(i, j, k, l) * FS + lane] = c;
+              }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (wv == 0) // 18 fields (this wave has no contraction tables to set up)
+          {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+              for (int l = k; l < 3; ++l)
+                Sk[k][l] = E[k][0] * Mr[l * 3] + E[k][1] * Mr[l * 3 + 1] + E[k][2] * Mr[l * 3 + 2] +
+                           wr * (MT[k][0] * Mr[l * 3] + MT[k][1] * Mr[l * 3 + 1] + MT[k][2] * Mr[l * 3 + 2]);
+            emit_pair(I0{}, I0{});
+            emit_pair(I1{}, I1{});
+            emit_pair(I2{}, I2{});
+          }
+        else if (wv == 1)
+          {
+            emit_pair(I0{}, I1{});
+            s_C[MASSF * FS + lane] = prm.alpha1 * prm.rho * wr;
+          }
+        else if (wv == 2)
+          emit_pair(I0{}, I2{});
+        else
+          emit_pair(I1{}, I2{});
+        if (tid < NPC)
+          {
+            s_ri[lane] = ri_l;
+            s_cm[lane] = cm_l;
+          }
+      }
     if (tid < 64)
       {
+       if constexpr (!REC)
+       {
         // ================================================================= wave 0: quadrature points
         if constexpr (!RES_ONLY && (XV & 2) != 0)
           __builtin_amdgcn_s_setprio(3);
+        double tiso[6], cII, cS;
+        if constexpr (RECW0)
+          {
+            // bit 9: wave 0 ALONE starts from the point records (no gather, no gradients, no kinematics: the point pass has
+            // done them) and forms all 45 fields as in the fused kernel; waves 1-3 carry no extra arithmetic
+            double rec[MF_NREC], Finv[9], detJ;
+            {
+              const double *__restrict__ rp = prm.qrec + cell * int64_t(MF_NREC * 64) + lane;
+#pragma unroll
+              for (int f = 0; f < MF_NREC; ++f)
+                rec[f] = rp[f * 64];
+            }
+            const int    qz = lane >> 4;
+            const double wq = prm.tab1d[24 + (lane & 3)] * prm.tab1d[24 + ((lane >> 2) & 3)] * prm.tab1d[24 + qz];
+            neo_hooke_from_F<3>(rec, det3x3(rec), rec[9], rec[10], prm.mu, prm.kappa, Finv, tau, tiso, cII, cS);
+            if (prm.cellbox)
+              {
+                const double *__restrict__ cb = prm.cellbox + cell * 4;
+                const double rx = cb[0], ry = cb[1], rz = cb[2];
+                detJ            = cb[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                  {
+                    M[k]     = rx * Finv[k];
+                    M[3 + k] = ry * Finv[3 + k];
+                    M[6 + k] = rz * Finv[6 + k];
+                  }
+              }
+            else
+              {
+                const double *__restrict__ cv = prm.cverts + cell * 24;
+                const double xiq[3] = {prm.tab1d[28 + (lane & 3)], prm.tab1d[28 + ((lane >> 2) & 3)], prm.tab1d[28 + qz]};
+                double       verts[24], Jm[9], Ji[9];
+#pragma unroll
+                for (int k = 0; k < 24; ++k)
+                  verts[k] = cv[k];
+                q1_jacobian<3>(verts, xiq, Jm);
+                detJ = det3x3(Jm);
+                inv3x3(Jm, detJ, Ji);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                  for (int j = 0; j < 3; ++j)
+                    M[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+              }
+            w = detJ * wq;
+          }
+        else
+          {
         const int     qz = lane >> 4;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -1008,7 +1198,6 @@ namespace mi
           }
         MI_STAMPW(8, 0); // gradients at the points
         // ---- geometry, kinematics, material at this point (nonlinear_elasticity.cc:927-934)
-        double tiso[6], cII, cS;
         {
           const double *__restrict__ cv = prm.cverts + cell * 24;
           double verts[24], Jm[9], Ji[9], gu[9], Finv[9], J, Fq[9], Jmq, rJq;
@@ -1053,6 +1242,7 @@ namespace mi
                   }
               }
         }
+          } // !RECW0
         MI_STAMPW(9, 0); // material
         const double T[3][3]  = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
         // ---- coefficient fields for the tangent waves
@@ -1104,6 +1294,7 @@ namespace mi
             s_C[MASSF * FS + lane] = prm.alpha1 * prm.rho * w;
           }
         MI_STAMPW(10, 0); // fields stored
+       } // !REC
       }
     else if constexpr (!RES_ONLY)
       {
@@ -1122,7 +1313,7 @@ namespace mi
             phi2[1][q]      = prm.tab1d[12 + q * 3 + a2];
           }
         mflag = (ci == cj) ? 1.0 : 0.0;
-        if constexpr (V2)
+        if constexpr (V2 && !REC)
           if (tid >= 192) // wave 3, idle until barrier (1) otherwise: where the 729 node-pair blocks of this cell go
             {
               int32_t node;
@@ -1150,6 +1341,15 @@ namespace mi
     if constexpr (!RES_ONLY)
       __syncthreads(); // (1) fields complete -- the one barrier every wave of the workgroup passes, outside the role branches
     MI_STAMP(1);
+    if constexpr (REC)
+      {
+        if (tid < 64) // wave 0, beside the contractions: the block table (its row info arrived with the records)
+          build_table(s_tab);
+      }
+    else if constexpr (RECW0)
+      {
+      }
+    else
     if (tid < 64)
       {
         const double T[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
@@ -5689,6 +5889,16 @@ namespace mi
             case 0: // sum factorised (default): 4 waves per cell, 41 kB LDS
               if (p.residual_only)
                 hipLaunchKernelGGL((assemble_q2sf<true, 0>), dim3(p.cell_count), dim3(64), 0, s, p);
+              else if (p.qrec && p.from_records)
+                {
+                  // round 6: the point pass (gather, gradients, kinematics, records, residual: one wave per cell), then the
+                  // tangent from the records
+                  hipLaunchKernelGGL((assemble_q2sf<true, 0>), dim3(p.cell_count), dim3(64), 0, s, p);
+                  if (p.from_records == 2) // wave 0 alone forms the fields from the records
+                    hipLaunchKernelGGL((assemble_q2sf<false, 644>), dim3(p.cell_count), dim3(256), 0, s, p);
+                  else                     // every wave a quarter of them
+                    hipLaunchKernelGGL((assemble_q2sf<false, 388>), dim3(p.cell_count), dim3(256), 0, s, p);
+                }
               else
                 hipLaunchKernelGGL((assemble_q2sf<false, 132>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;

@@ -224,6 +224,22 @@ def test_element_kernel_variants_agree():
         assert np.abs(y - ref[0]).max() / np.abs(ref[0]).max() < 1e-13, v
         assert np.abs(r - ref[1]).max() / np.abs(ref[1]).max() < 1e-13, v
         assert abs(rn - ref[2]) / ref[2] < 1e-13
+    # round 6, the default where point records exist: the tangent in two kernels -- the point pass (the residual kernel,
+    # which also writes F, J^(-2/3), 1/J of every point) and the tangent FROM those records (every wave of the workgroup
+    # recomputes the material response, a quarter of the fields each); against the fused kernel ("asm_split" 0)
+    G.set_tuning("asm_variant", 0)
+    G.set_tuning("element_tangents", 2)
+    K = {}
+    for split in (0, 1):
+        G.set_tuning("asm_split", split)
+        rn = G.assemble()
+        K[split] = (G.csr().data.copy(), G.get(M.V_RHS), rn, G.spmv(x))
+        G.set_tuning("spmv_variant", 4)  # the matrix-free product from the records either kernel left
+        assert np.abs(G.spmv(x) - K[split][3]).max() / np.abs(K[split][3]).max() < 1e-13
+        G.set_tuning("spmv_variant", 3)
+    assert np.abs(K[1][0] - K[0][0]).max() / np.abs(K[0][0]).max() < 1e-13
+    assert np.array_equal(K[1][1], K[0][1]) and K[1][2] == K[0][2]  # the residual: the same instruction stream
+    assert np.abs(K[1][3] - ref[0]).max() / np.abs(ref[0]).max() < 1e-13
 
 
 def _diag_blocks_of(K, dim):
