@@ -49,7 +49,7 @@ def spmv_bytes(nnodes, nnzb, dim, generated_columns=None):
     per row instead --, 4 bytes of row bookkeeping per row, x read once, y written once (the fused dot's second read
     of p is not credited)"""
     if generated_columns is None:
-        generated_columns = os.environ.get("MI_SELL_ICOL", "1") != "0"
+        generated_columns = True  # the library's default ("sell_icol" 1)
     n = nnodes * dim
     index_bytes = 8 * nnodes if generated_columns else 4 * nnzb
     return 8 * nnzb * dim * dim + index_bytes + 4 * (nnodes + 1) + 8 * n + 8 * n
@@ -235,6 +235,63 @@ def cpu_baseline(cells, its_a, its_b, budget_s, config4):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- HBM traffic (PMC counters)
+PMC_COUNTERS = ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "WRITE_SIZE")
+
+
+def pmc_reduce(root):
+    """per kernel (name + grid): launches and HBM bytes per launch from the per-counter rocprofv3 passes under `root`.
+    gfx950 corrections of the MI355X guide (HBM / rocprofv3 section; checked on the streaming calibration kernel in round 1):
+    read bytes = TCC_EA0_RDREQ_sum x 128 B - TCC_EA0_RDREQ_32B_sum x 96 B, write bytes = WRITE_SIZE x 1 KiB"""
+    import csv
+    import glob
+    import re
+    from collections import defaultdict
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                name = re.sub(r"^void ", "", re.sub(r"\(.*$", "", row["Kernel_Name"]))
+                acc["%s grid=%s" % (name, row.get("Grid_Size", "?"))][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    out = {}
+    for k, cs in acc.items():
+        if not all(c in cs for c in PMC_COUNTERS):
+            continue
+        c = {n: sum(v) / len(v) for n, v in cs.items()}
+        rd = c["TCC_EA0_RDREQ_sum"] * 128.0 - c["TCC_EA0_RDREQ_32B_sum"] * 96.0
+        out[k] = {"launches": max(len(v) for v in cs.values()), "read_bytes": rd, "write_bytes": c["WRITE_SIZE"] * 1024.0,
+                  "bytes_per_launch": rd + c["WRITE_SIZE"] * 1024.0}
+    return out
+
+
+def pmc_traffic(cells, budget_s):
+    """LIVE in the default run (round 6; `roofline.traffic` was null until round 5): one Newmark step of the headline
+    configuration in three CHILD processes under `rocprofv3 --pmc <counter>` -- one counter per pass, nothing but --pmc, as the
+    MI355X guide prescribes -- started while this process has not touched the GPU.  Returns (per-kernel dict or None, note)."""
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    t0 = time.time()
+    root = tempfile.mkdtemp(prefix="mi_pmc_", dir="/tmp")
+    me = os.path.abspath(__file__)
+    for c in PMC_COUNTERS:
+        left = budget_s - (time.time() - t0)
+        if left < 30:
+            return None, "wall-clock guard (%.0f s) reached before counter %s" % (budget_s, c)
+        cmd = ["rocprofv3", "--pmc", c, "--output-format", "csv", "-d", os.path.join(root, c), "--", "python3", me, "--pmc-child",
+               "--cells", str(cells), "--cpu-cells", "0"]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=left)
+        except subprocess.TimeoutExpired:
+            return None, "pass %s stopped by the wall-clock guard" % c
+        if r.returncode != 0:
+            return None, "pass %s: exit code %d: %s" % (c, r.returncode, (r.stderr or "")[-300:])
+    red = pmc_reduce(root)
+    shutil.rmtree(root, ignore_errors=True)
+    return (red or None), ("three passes in %.0f s" % (time.time() - t0) if red else "no counter rows found")
+
+
 # ---------------------------------------------------------------------------------------------- GPU side
 def free_port():
     s = socket.socket()
@@ -323,6 +380,8 @@ def main():
                          "assembly + CG+Jacobi and CG+SSOR solves, ~5 minutes on a 64-core socket), which the default run includes")
     ap.add_argument("--cpu-config4", action="store_true", help=argparse.SUPPRESS)  # (round 3's opt-in; now the default)
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # child of pmc_traffic(): one step, no output
+    ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic passes (three child runs under rocprofv3 --pmc)")
     args = ap.parse_args()
 
     if args.cpu_worker:  # child of cpu_baseline(): CPU only
@@ -341,6 +400,11 @@ def main():
         its_a, its_b = (int(x) for x in args.cpu_its.split(","))
         budget = float(os.environ.get("MI_BENCH_CPU_BUDGET_S", "900"))
         cpu_leg = cpu_baseline(args.cpu_cells, its_a, its_b, budget, not args.no_cpu_config4 and args.cells == 59)
+
+    # ... and so do the counter passes for `roofline.traffic`: children under rocprofv3, this process still GPU-free
+    pmc, pmc_note = None, "not collected (N > 1, --slabs, --no-pmc or a child itself)"
+    if rank == 0 and world == 1 and args.slabs == 1 and not args.no_pmc and not args.pmc_child and args.cells >= 24:
+        pmc, pmc_note = pmc_traffic(args.cells, float(os.environ.get("MI_BENCH_PMC_BUDGET_S", "300")))
 
     import torch
     import torch.distributed as dist
@@ -381,7 +445,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None, smoother_precision=None, fine_level=None):
+    def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None, smoother_precision=None, fine_level=None,
+                diag_lag=None):
         """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
         nz = cells * parts if scaling == "weak" else cells
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
@@ -390,8 +455,6 @@ def main():
         G.set_tuning("smoother_operator", {"matrix-free": 2, "element": 1, "assembled": 0}[args.smoother_operator])
         G.set_tuning("cg_warm_start", {"zero": 0, "previous-update": 1, "previous-step": 2, "extrapolated": 3}[cg_start or args.cg_start])
         G.set_tuning("cg_operator", 1 if (cg_operator or args.cg_operator) == "element" else 0)
-        if os.environ.get("MI_CG_FUSED_DOT"):
-            G.set_tuning("cg_fused_dot", int(os.environ["MI_CG_FUSED_DOT"]))
         G.set_tuning("precond", 1 if args.precond == "mg" else 0)
         if args.precond_storage == "f32":
             G.set_tuning("precond_storage", 32)
@@ -399,6 +462,7 @@ def main():
             G.set_tuning("smoother_precision", 32)
         if (fine_level or args.fine_level) == "matrix-free":
             G.set_tuning("fine_level", 1)
+            G.set_tuning("mf_diag_lag", 0 if diag_lag == 0 else 1)  # (1: what the executable sets beside MI_FINE_LEVEL=1)
 
         def one_step(k):
             ramp = min(1.0, (k + 1) / 10.0)
@@ -435,6 +499,9 @@ def main():
              "tm": G.timings(), "comm": G.comm_info(), "per_rank_s": per_rank}
         return r
 
+    if args.pmc_child:  # one Newmark step of the headline configuration under the counters, nothing to report
+        measure(args.scaling, n, 1, 0, None)
+        return
     R = measure(args.scaling, n, args.steps, args.warmup, uid)
     G, elapsed, tm, nz = R["G"], R["elapsed"], R["tm"], R["nz"]
     out = None
@@ -634,6 +701,35 @@ def main():
             G.set_tuning("spmv_variant", 3)
             out["roofline"]["calibration_stream_read"] = {"ms": ms_cal, "GB": 8 * G.nnz / 1e9,
                                                           "GB_per_s": 8 * G.nnz / ms_cal / 1e6}
+        # `traffic`: HBM bytes per launch from the counter passes of THIS run (children started at the top of main)
+        def live_traffic(prefix, min_bytes):
+            rows = [v for k, v in (pmc or {}).items() if k.startswith(prefix) and v["bytes_per_launch"] >= min_bytes]
+            if not rows:
+                return None
+            n_l = sum(v["launches"] for v in rows)
+            return sum(v["bytes_per_launch"] * v["launches"] for v in rows) / n_l, n_l
+
+        how_live = ("LIVE: `rocprofv3 --pmc <counter> -- python3 bench.py --pmc-child` (one Newmark step of this configuration), one "
+                    "child process per counter before this process touched the GPU; TCC_EA0_RDREQ_sum x 128 B - "
+                    "TCC_EA0_RDREQ_32B_sum x 96 B + WRITE_SIZE x 1 KiB (MI355X guide, gfx950 corrections); " + pmc_note)
+        cgp = out["roofline"].get("cg_product", out["roofline"])
+        dom = out["roofline"] if "cg_product" in out["roofline"] else None
+        t_cg = live_traffic("mi::sell_spmv<3, true, true", 1e9) if args.cg_operator == "assembled" and args.fine_level == "assembled" else None
+        if t_cg:
+            cgp["traffic"], cgp["traffic_launches"] = t_cg
+            cgp["traffic_ratio_to_algorithmic"] = t_cg[0] / cgp["bytes_per_launch"]
+            cgp["traffic_source"] = how_live
+        t_dom = live_traffic("mi::mf_spmv" if form == 2 else "mi::ebe_spmv", 0.5e9 if single else 0.0) if dom is not None else None
+        if t_dom:
+            dom["traffic"], dom["traffic_launches"] = t_dom
+            dom["traffic_ratio_to_algorithmic"] = t_dom[0] / dom["bytes_per_launch"]
+            dom["traffic_source"] = how_live
+        elif dom is not None or not t_cg:
+            out["roofline"]["traffic_note"] = "traffic is null: " + pmc_note
+        t_asm = live_traffic("mi::assemble_q2sf<false", 0.0)
+        if t_asm:
+            out["roofline"]["assemble_q2sf_traffic"] = {"bytes_per_colour_launch": t_asm[0], "launches": t_asm[1],
+                                                        "bytes_per_tangent_assembly": 8 * t_asm[0], "source": how_live}
         pmc_file = os.path.join(ROOT, "profiles", "r05", "pmc_bench_n59.json")
         if world == 1 and args.slabs == 1 and n == 59 and os.path.exists(pmc_file):
             # NOT a measurement of this run: per-launch HBM traffic of the same command under `rocprofv3 --pmc`
@@ -714,6 +810,14 @@ def main():
             r["ms_diagonal_blocks"] = tmS["assemble_diag"][0] / max(tmS["assemble_diag"][1], 1)
             r["ms_cg_product"] = tmS["spmv"][0] / max(tmS["spmv"][1], 1)
             r["tangent_assemblies_per_step"] = tmS["assemble_cells"][1] / args.steps
+            r["diagonal_blocks"] = ("formed at the first tangent of a time step and kept over its Newton iterations (\"mf_diag_lag\" 1, a "
+                                    "preconditioner-side policy like the coarse operators' lag); every tangent: see "
+                                    "with_matrix_free_fine_level_diagonal_every_tangent")
+            r2, tm2 = side(fine_level="matrix-free", diag_lag=0)
+            r2["ms_diagonal_blocks"] = tm2["assemble_diag"][0] / max(tm2["assemble_diag"][1], 1)
+            r2["diagonal_block_passes_per_step"] = tm2["assemble_diag"][1] / args.steps
+            out["config"]["with_matrix_free_fine_level_diagonal_every_tangent"] = r2
+            r["diagonal_block_passes_per_step"] = tmS["assemble_diag"][1] / args.steps
             r["note"] = ("tuning \"fine_level\" 1 (bench.py --fine-level matrix-free): no global fine tangent is assembled or "
                          "stored (7.6 GB at 5 M DoFs released); not the headline because north_star names the CSR + SpMV path")
             out["config"]["with_matrix_free_fine_level"] = r

@@ -195,7 +195,7 @@ namespace mi_detail
     // node ids by arithmetic: measured 2 % SLOWER in assemble_q2sf (7.93 against 7.79 ms per tangent, same process: three
     // workgroups per CU already hide the connectivity load), 4 % faster in mf_spmv -- so only the product uses it;
     // MI_ASM_CELL_LATTICE=1 switches it on here for A/B
-    static const bool asm_lat = getenv("MI_ASM_CELL_LATTICE") && atoi(getenv("MI_ASM_CELL_LATTICE")) != 0;
+    static const bool asm_lat = mi::exp_env("MI_ASM_CELL_LATTICE") && atoi(mi::exp_env("MI_ASM_CELL_LATTICE")) != 0;
     if (asm_lat)
       p.lat = c->lat;
     p.conn   = c->d_conn;
@@ -810,8 +810,15 @@ namespace mi_detail
     const bool q2sf = c->dim == 3 && c->degree == 2 && (p.variant == 0 || (p.variant >= 3 && p.variant <= 8));
     c->ke_valid     = (c->d_ke && q2sf && !c->mf_fine) || c->d_qrec;
     c->qrec32_valid = p.qrec32 != nullptr && q2sf;
+    if (mf_tangent && c->mf_diag_lag && c->mf_diag_fresh) // the step's first tangent formed the blocks: kept ("mf_diag_lag")
+      {
+        HIPCHK(c, hipGetLastError());
+        c->mg_stale = true;
+        return MI_OK;
+      }
     if (mf_tangent)
       {
+        c->mf_diag_fresh = true;
         mi::MfParams f{};
         f.qrec = c->d_qrec, f.tab1d = c->d_tab, f.cverts = c->d_cverts, f.cellbox = c->d_cellbox, f.dst = c->d_mf_dst;
         f.mu = c->mat.mu, f.kappa = c->kappa, f.mass = c->alpha[1] * c->mat.rho;
@@ -937,6 +944,7 @@ namespace mi_detail
         HIPCHK(c, hipMemsetAsync(c->d_vals, 0, c->vals_doubles * sizeof(double), c->stream));
       }
     c->mf_fine      = on ? 1 : 0;
+    c->mf_diag_fresh = false;
     c->ke_valid     = false;
     c->qrec32_valid = false;
     c->vals32_stale = true;
@@ -1178,7 +1186,17 @@ namespace mi_detail
       return rc;
     if (use_mg && !single && (rc = precondition(true, true)))
       return rc;
-    if (!single || !dist) // (single-reduction form on a team: |b|^2 arrives with the first iteration's all-reduce)
+    if (single && dist && max_it <= 0)
+      {
+        // no iteration will bring |b|^2 and ||r0||^2: reduce them now, so that the final check below reports this solve's
+        // residual against this solve's tolerance
+        for (size_t k = 0; k < R; ++k)
+          mi::launch_reduce_to_totals(cgs[k].part_rr, T.members[k]->grid_vec, T.members[k]->d_sc + SC_TOT, nullptr, 0, nullptr, nullptr,
+                                      T.members[k]->stream);
+        if ((rc = team_allreduce(T, SC_TOT, 4)))
+          return rc;
+      }
+    if (!single || !dist || max_it <= 0) // (single-reduction form on a team: |b|^2 arrives with the first iteration's all-reduce)
       for (size_t k = 0; k < R; ++k)
         mi::launch_cg_set_tolerance(cgs[k], T.members[k]->part(4), tol, T.members[k]->stream);
 
@@ -1450,7 +1468,7 @@ namespace mi_detail
             c->lat_built.rows = c->d_lat_rows;
             c->lat_rows_host  = rows;
           }
-        if (!(getenv("MI_CELL_LATTICE") && atoi(getenv("MI_CELL_LATTICE")) == 0))
+        if (!(mi::exp_env("MI_CELL_LATTICE") && atoi(mi::exp_env("MI_CELL_LATTICE")) == 0))
           c->lat = c->lat_built;
       }
     c->n     = m.ndofs;
@@ -1551,8 +1569,8 @@ namespace mi_detail
       const int64_t nin = m.sell_nslices_interior, nbd = m.sell_nslices - nin;
       constexpr int64_t W = mi::SELL_WPB; // one wavefront per slice, W wavefronts per workgroup ...
       // ... unless the launch is small: then one WORKGROUP per slice (sell_spmv_split), decided by the slice count alone
-      const bool use_split = !(getenv("MI_SELL_SPLIT") && atoi(getenv("MI_SELL_SPLIT")) == 0);
-      const int  split_max = getenv("MI_SELL_SPLIT_MAX") ? atoi(getenv("MI_SELL_SPLIT_MAX")) : mi::SELL_SPLIT_MAX_SLICES; // A/B
+      const bool use_split = !(mi::exp_env("MI_SELL_SPLIT") && atoi(mi::exp_env("MI_SELL_SPLIT")) == 0);
+      const int  split_max = mi::exp_env("MI_SELL_SPLIT_MAX") ? atoi(mi::exp_env("MI_SELL_SPLIT_MAX")) : mi::SELL_SPLIT_MAX_SLICES; // A/B
       c->split_int      = use_split && nin > 0 && nin <= split_max;
       c->split_bnd      = use_split && nbd > 0 && nbd <= split_max;
       c->grid_spmv_bnd  = c->split_bnd ? int(nbd) : int(std::min<int64_t>(MAX_PART / 4, (nbd + W - 1) / W));
@@ -1563,17 +1581,17 @@ namespace mi_detail
     }
     for (int64_t nd = 0; nd < m.nnodes; ++nd)
       c->maxrow = std::max(c->maxrow, int(m.rowptr[size_t(nd) + 1] - m.rowptr[size_t(nd)]));
-    if (const char *v = getenv("MI_SPMV_VARIANT"))
+    if (const char *v = mi::exp_env("MI_SPMV_VARIANT"))
       c->spmv_variant = atoi(v);
-    if (const char *v = getenv("MI_SELL_UNROLL"))
+    if (const char *v = mi::exp_env("MI_SELL_UNROLL"))
       c->sell_unroll = atoi(v);
-    if (const char *v = getenv("MI_SELL_ICOL"))
+    if (const char *v = mi::exp_env("MI_SELL_ICOL"))
       c->sell_icol = atoi(v) != 0;
-    if (const char *v = getenv("MI_CG_WARM_START"))
+    if (const char *v = mi::exp_env("MI_CG_WARM_START"))
       c->cg_warm_start = std::min(3, std::max(0, atoi(v)));
-    if (const char *v = getenv("MI_SMALL_CG"))
+    if (const char *v = mi::exp_env("MI_SMALL_CG"))
       c->small_cg = atoi(v) != 0;
-    if (const char *v = getenv("MI_CG_SINGLE_REDUCTION"))
+    if (const char *v = mi::exp_env("MI_CG_SINGLE_REDUCTION"))
       c->cg_single_reduction = std::min(1, std::max(-1, atoi(v)));
     return MI_OK;
   }
@@ -1762,7 +1780,7 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
           hipEventCreateWithFlags(&T->ev_ready, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&T->ev_halo, hipEventDisableTiming) != hipSuccess)
         return bail(MI_EHIP, "cannot create the communication stream");
-      if (const char *e = getenv("MI_HALO_OVERLAP"))
+      if (const char *e = mi::exp_env("MI_HALO_OVERLAP"))
         T->overlap = atoi(e) != 0;
     }
   const int first = emulated ? 0 : (comm ? comm->rank : 0), count = emulated ? nranks : 1;
@@ -1780,12 +1798,12 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
     // fixed ~0.8 ms per CG iteration whatever the size; measured crossover with Jacobi-PCG at 73k dofs,
     // tools/small_case_latency.py); below that Jacobi.  mi_set_tuning("precond") / MI_PRECOND override.
     int precond = T->n_global >= 75000 ? 1 : 0;
-    if (const char *e = getenv("MI_PRECOND"))
+    if (const char *e = mi::exp_env("MI_PRECOND"))
       precond = atoi(e) != 0;
     for (mi_ctx *m : T->members)
       {
         m->precond = precond;
-        if (const char *e = getenv("MI_MG_REFRESH_EVERY"))
+        if (const char *e = mi::exp_env("MI_MG_REFRESH_EVERY"))
           m->mg_refresh_every = std::max(1, atoi(e));
         if (precond == 1)
           {
@@ -1799,11 +1817,11 @@ int mi_ctx_create(const mi_mesh_desc *md, const mi_material_desc *mat, const mi_
   // enough for the unfused smoother (small problems run the fused smoother on the assembled matrix)
   for (mi_ctx *m : T->members)
     {
-      if (const char *e = getenv("MI_EBE"))
+      if (const char *e = mi::exp_env("MI_EBE"))
         m->ebe = std::max(0, std::min(2, atoi(e)));
-      if (const char *e = getenv("MI_MF_SINGLE_LAUNCH"))
+      if (const char *e = mi::exp_env("MI_MF_SINGLE_LAUNCH"))
         m->mf_slots = atoi(e) != 0;
-      if (const char *e = getenv("MI_CORRECT_FACE_F")) // the executables' "--correct-face-F" (SURVEY section 9); default: the reference's quirk
+      if (const char *e = mi::exp_env("MI_CORRECT_FACE_F")) // the executables' "--correct-face-F" (SURVEY section 9); default: the reference's quirk
         m->correct_face_F = atoi(e) != 0;
       const int rc = ensure_element_tangents(m);
       if (rc != MI_OK)
@@ -2038,6 +2056,7 @@ int mi_newton_begin_step(mi_ctx *c)
     {
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_SOLUTION_DELTA), 0, size_t(m->n) * sizeof(double), m->stream));
       HIPCHK(m, hipMemsetAsync(m->vec(MI_V_NEWTON_UPDATE), 0, size_t(m->n) * sizeof(double), m->stream));
+      m->mf_diag_fresh = false; // ("mf_diag_lag": the step's first tangent forms the diagonal blocks again)
       // new time step: refresh the coarse operators at its first solve ("mg_refresh_every" k: at every k-th step)
       if (m->mg_steps_since_refresh + 1 >= m->mg_refresh_every)
         m->mg_force = true;
@@ -2649,6 +2668,12 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
                          (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
                          (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
         return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
+      if (k == "mf_diag_lag" && (value == 0 || value == 1))
+        {
+          m->mf_diag_lag   = value;
+          m->mf_diag_fresh = false;
+          continue;
+        }
       if (k == "fine_level" && (value == 0 || value == 1))
         {
           const int rc = set_fine_level(m, value);
@@ -2723,9 +2748,21 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
       else if (k == "halo_overlap" && (value == 0 || value == 1))
         c->team->overlap = value;
       else if (k == "asm_variant" && value >= 0 && value <= 9)
-        m->asm_variant = value;
-      else if (k == "asm_split" && value >= 0 && value <= 2) // 3D Q2 with point records: point pass + tangent from the records (1, default) | one fused kernel
-        m->asm_split = value;
+        {
+#ifndef MI_EXPERIMENTS
+          if (value >= 3 && value <= 8)
+            return fail(c, MI_EINVAL, "asm_variant %d is an A/B instantiation of the experiments build (make EXPERIMENTS=1)", value);
+#endif
+          m->asm_variant = value;
+        }
+      else if (k == "asm_split" && value >= 0 && value <= 2) // 3D Q2 with point records: the fused kernel (0) | point pass + tangent
+        {                                                     // from the records, all waves (1) / wave 0 (2): profiles/r06/asm_split_ab_n59.txt
+#ifndef MI_EXPERIMENTS
+          if (value != 0)
+            return fail(c, MI_EINVAL, "asm_split %d is an A/B instantiation of the experiments build (make EXPERIMENTS=1)", value);
+#endif
+          m->asm_split = value;
+        }
       else if (k == "mg_refresh_every" && value >= 1 && value <= 1000)
         m->mg_refresh_every = value;
       else if (k == "mg_lag" && (value == 0 || value == 1))
@@ -2744,8 +2781,19 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
         m->cg_speculate = value;
       else if (k == "cg_single_reduction" && value >= -1 && value <= 1)
         m->cg_single_reduction = value;
-      else if (k == "mg_dist_nodes" && value >= -1) // before "precond" 1 builds the hierarchy
-        m->mg_dist_nodes = value;
+      else if ((k == "mg_dist_nodes" && value >= -1) || (k == "mg_coarsest" && value >= 1 && value <= 64) ||
+               (k == "mg_dense" && (value == 0 || value == 1)))
+        {
+          // shape of the multigrid hierarchy: node count from which a team's first coarsened level is cut into slabs, cells per
+          // direction at which the coarsening stops, exact solve on the coarsest level.  An existing hierarchy is rebuilt.
+          (k == "mg_dist_nodes" ? m->mg_dist_nodes : k == "mg_coarsest" ? m->mg_coarsest : m->mg_dense) = value;
+          if (m->mg)
+            {
+              const int rc = mg_setup(m);
+              if (rc)
+                return fail(c, rc, "%s", m->err.c_str());
+            }
+        }
       else if (k == "cg_speculate_margin" && value >= 0 && value <= 16)
         m->cg_speculate_margin = value;
       else if (k == "halo_skip" && (value == 0 || value == 1))
@@ -2814,6 +2862,18 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = (m->mf_slots && m->d_mf_yc) ? 1 : 0;
   else if (k == "fine_level")
     *value = m->mf_fine;
+  else if (k == "mf_diag_lag")
+    *value = m->mf_diag_lag;
+  else if (k == "experiments") // 1: built with -DMI_EXPERIMENTS (environment hooks and A/B kernel instantiations compiled in)
+#ifdef MI_EXPERIMENTS
+    *value = 1;
+#else
+    *value = 0;
+#endif
+  else if (k == "sell_icol")
+    *value = m->sell_icol;
+  else if (k == "asm_variant")
+    *value = m->asm_variant;
   else if (k == "cell_lattice")
     *value = m->lat.ncol > 0 ? 1 : 0;
   else if (k == "cut_axis") // the box direction the slabs are cut along: 1 / 2 / 3 = x / y / z, 0: not decomposed
@@ -2907,7 +2967,7 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_launch = double(ms) / std::max(1, reps);
-  if (getenv("MI_MF_STAMPS") && c->spmv_variant == 4 && element_form(c) == 2 && c->mf_slots && c->d_mf_yc && c->d_cellbox)
+  if (mi::exp_env("MI_MF_STAMPS") && c->spmv_variant == 4 && element_form(c) == 2 && c->mf_slots && c->d_mf_yc && c->d_cellbox)
     {
       // diagnostic: where a wavefront of the matrix-free product spends its life (shader-clock stamps of lane 0 at the
       // stage boundaries), averaged over all cells of one launch
@@ -2972,7 +3032,7 @@ int mi_bench_assemble(mi_ctx *c, int reps, double *ms_per_assembly)
   hipEventDestroy(a);
   hipEventDestroy(b);
   *ms_per_assembly = double(ms) / std::max(1, reps);
-  if (getenv("MI_ASM_STAMPS") && !c->mf_fine && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 8)))
+  if (mi::exp_env("MI_ASM_STAMPS") && !c->mf_fine && c->dim == 3 && c->degree == 2 && (c->asm_variant == 0 || (c->asm_variant >= 3 && c->asm_variant <= 8)))
     {
       // diagnostic: where a workgroup of the sum-factorised element kernel spends its life (shader-clock stamps of one
       // tangent wave at the phase boundaries), averaged over the cells of the first colour

@@ -157,7 +157,8 @@ struct mi_ctx
   int       cg_r0_unassembled = 1; // A h of a predicted start vector by the matrix-free product where available ("cg_r0_operator")
   bool      unassembled_now = false; // (set around that one product)
   int64_t   mg_dist_nodes = -1;       // multigrid: node count from which the first coarsened level of a team is distributed
-                                      // (-1: the default of mi_mg.cpp / MI_MG_DIST_NODES; read by mg_setup)
+                                      // (-1: the default of mi_mg.cpp; read by mg_setup; tuning "mg_dist_nodes")
+  int64_t   mg_coarsest = -1, mg_dense = -1; // tuning "mg_coarsest" / "mg_dense": Multigrid::coarsest_reps / dense (-1: defaults)
   int       cg_single_reduction = -1; // multigrid-PCG in the single-reduction form (one all-reduce per iteration): -1 = on
                                       // teams of several slabs, 0 never, 1 always (cg_run)
   int       cg_speculate_margin = 0;  // expected iterations left to polled ones: 0 = the default (two)
@@ -169,6 +170,11 @@ struct mi_ctx
   // from those records (mf_diag); the CG's product, start-vector and residual products and the smoother all run on
   // mf_spmv; d_vals is released.  Same results as the assembled level [REF nonlinear_elasticity.cc:1044-1087, 1153-1191].
   int       mf_fine = 0;
+  // "mf_diag_lag" 1 (what bench.py and the executable set beside "fine_level" 1): the diagonal blocks -- the smoother's D,
+  // the Jacobi diagonal -- are formed at the FIRST tangent of a time step and kept over its Newton iterations, as the coarse
+  // operators are ("mg_lag"); a preconditioner-side policy: the operator (records) and the residual are always current
+  int       mf_diag_lag = 0;
+  bool      mf_diag_fresh = false; // the blocks belong to this time step (cleared by mi_newton_begin_step)
   double   *d_diag_blk   = nullptr; // [nnodes][9] diagonal blocks under the assembled matrix's constraint rule
   double   *d_diag_slots = nullptr; // [ncells * 27][6] the cells' contributions (slot order = processing order)
   int32_t  *d_diagpos_mf = nullptr; // [nnodes] the node's own id where it has a row here, else -1: d_diag_blk read as `vals`
@@ -227,7 +233,8 @@ struct mi_ctx
   bool                  mg_stale = true; // the coarse operators belong to an older state than the fine tangent
   bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
   int                   asm_variant = 0;
-  int                   asm_split = 1;   // 3D Q2, point records present: the tangent in two kernels (round 6; 0: the fused kernel of round 5)
+  int                   asm_split = 0;   // experiments build: 3D Q2 with point records: the tangent in two kernels (1 / 2; measured
+                                         // slower than the fused kernel, profiles/r06/asm_split_ab_n59.txt)
   int                   mg_lag   = 1;    // 1: keep the coarse operators over the Newton iterations of one step
   // ... and over time steps: refreshed at the first solve of every k-th step, or before the next solve when one
   // needed a quarter (at least 2) more iterations than the first solve after the last refresh (mg_its_ref)

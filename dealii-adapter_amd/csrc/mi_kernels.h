@@ -3,8 +3,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdlib.h>
+
 namespace mi
 {
+  // Environment switches are EXPERIMENT hooks (A/B runs, diagnostics of tools/): the release library reads none -- its
+  // numerics and solver path do not change with the caller's environment; every supported switch is a mi_set_tuning key.
+  // -DMI_EXPERIMENTS (make EXPERIMENTS=1 -> libmi_elasticity_exp.so, what tools/profile_round.sh builds) compiles the hooks
+  // and the extra kernel instantiations they select.
+#ifdef MI_EXPERIMENTS
+  inline const char *exp_env(const char *name) { return getenv(name); }
+#else
+  inline const char *exp_env(const char *) { return nullptr; }
+#endif
+
   // Node ids of a cell WITHOUT reading the connectivity (round 4).  The mesh is a lattice: the cell at colour-sorted
   // position pos belongs to colour col (begin[col] <= pos < begin[col+1]), is the r-th cell (x fastest) of that colour's
   // sub-lattice of mx x my x mz cells, and its first node is  base + rx sx + ry sy + rz sz;  local node (i, j, k) of a

@@ -5889,6 +5889,7 @@ namespace mi
             case 0: // sum factorised (default): 4 waves per cell, 41 kB LDS
               if (p.residual_only)
                 hipLaunchKernelGGL((assemble_q2sf<true, 0>), dim3(p.cell_count), dim3(64), 0, s, p);
+#ifdef MI_EXPERIMENTS
               else if (p.qrec && p.from_records)
                 {
                   // round 6: the point pass (gather, gradients, kinematics, records, residual: one wave per cell), then the
@@ -5899,9 +5900,11 @@ namespace mi
                   else                     // every wave a quarter of them
                     hipLaunchKernelGGL((assemble_q2sf<false, 388>), dim3(p.cell_count), dim3(256), 0, s, p);
                 }
+#endif
               else
                 hipLaunchKernelGGL((assemble_q2sf<false, 132>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
+#ifdef MI_EXPERIMENTS // (A/B instantiations: profiles/r05/asm_ab_*.txt, profiles/r06/asm_split_ab_n59.txt)
             case 3: // A/B: the kernel of round 4 (81 fields, block table by wave 0 behind the residual, branching scatter)
               hipLaunchKernelGGL((assemble_q2sf<false, 0>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
@@ -5920,6 +5923,7 @@ namespace mi
             case 8: // A/B: round 4 + pipelined contraction
               hipLaunchKernelGGL((assemble_q2sf<false, 1>), dim3(p.cell_count), dim3(256), 0, s, p);
               break;
+#endif
             case 9: // node-pair form (the default until round 2): 16.4 ms per assembly at 5 M DoFs
               launch_asm_sel<3, 2, 2, 256, 8>(p, s);
               break;
@@ -6087,7 +6091,7 @@ namespace mi
   {
     if (cell_count <= 0)
       return;
-    static const bool xcd = !(getenv("MI_MF_XCD") && atoi(getenv("MI_MF_XCD")) == 0);
+    static const bool xcd = !(exp_env("MI_MF_XCD") && atoi(exp_env("MI_MF_XCD")) == 0);
     MfParams          q   = p;
     q.count               = cell_count;
     q.xcd_chunk           = xcd ? (cell_count + 7) / 8 : 0;
@@ -6097,15 +6101,20 @@ namespace mi
                            (q.cellbox ? mf_spmv<true, false, true> : mf_spmv<false, false, true>)) :
                    (q.yc ? (q.cellbox ? mf_spmv<true, true, false> : mf_spmv<false, true, false>) :
                            (q.cellbox ? mf_spmv<true, false, false> : mf_spmv<false, false, false>));
+#ifdef MI_EXPERIMENTS
     if (q.stamps) // diagnostic: the production shape only (boxes, one launch, lattice ids or not)
       kern = q.lat.ncol > 0 ? mf_spmv<true, true, true, 1> : mf_spmv<true, true, false, 1>;
-    static const bool occ5 = getenv("MI_MF_OCC") && atoi(getenv("MI_MF_OCC")) == 5; // A/B: five waves per SIMD (spills)
+    static const bool occ5 = exp_env("MI_MF_OCC") && atoi(exp_env("MI_MF_OCC")) == 5; // A/B: five waves per SIMD (spills)
     if (occ5 && q.yc && q.cellbox && q.lat.ncol > 0 && !q.stamps)
       kern = mf_spmv<true, true, true, 0, 5>;
-    static const int dbg = getenv("MI_MF_DBG") ? atoi(getenv("MI_MF_DBG")) : 0; // timing-only ablations (wrong results)
+    static const int dbg = exp_env("MI_MF_DBG") ? atoi(exp_env("MI_MF_DBG")) : 0; // timing-only ablations (wrong results)
     if (dbg && q.yc && q.cellbox && q.lat.ncol > 0)
       kern = dbg == 2 ? mf_spmv<true, true, true, 2> : dbg == 4 ? mf_spmv<true, true, true, 4> : dbg == 8 ? mf_spmv<true, true, true, 8> :
              dbg == 14 ? mf_spmv<true, true, true, 14> : dbg == 6 ? mf_spmv<true, true, true, 6> : kern;
+#else
+    constexpr bool occ5 = false;
+    constexpr int  dbg  = 0;
+#endif
     // opt-in: fp32 arithmetic on fp32 records (the production shape; MfParams::qrec32 set by the caller for smoother products only)
     if (q.qrec32 && !occ5 && !dbg && !q.stamps && q.yc && q.cellbox && q.lat.ncol > 0)
       kern = mf_spmv<true, true, true, 0, 4, float>;
@@ -6129,13 +6138,13 @@ namespace mi
     if (hbw >= BAND_MAXH)
       return -1;
     // factorisations of narrow bands (the reference's 2D geometries) run on the LDS-window kernel; MI_BAND_LDS=0: never (A/B)
-    static const bool lds_ok = !(getenv("MI_BAND_LDS") && atoi(getenv("MI_BAND_LDS")) == 0);
+    static const bool lds_ok = !(exp_env("MI_BAND_LDS") && atoi(exp_env("MI_BAND_LDS")) == 0);
     const bool far = hbw + BAND_NB > BAND_LDS_W;
     if (factor && lds_ok && hbw + BAND_NB <= BAND_LDS_W + BAND_FAR_MAX)
       {
         // MI_BAND_DBG (diagnostic): phase clocks of thread 0 of the first two factorisations, printed after a
         // synchronisation; the solve itself is the production one (stamps only), the buffer lives for the call
-        static const bool   dbg_on = getenv("MI_BAND_DBG") != nullptr;
+        static const bool   dbg_on = exp_env("MI_BAND_DBG") != nullptr;
         static int          shown  = 0;
         unsigned long long *d_dbg  = nullptr;
         if (dbg_on && shown < 2 && hipMalloc((void **)&d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)

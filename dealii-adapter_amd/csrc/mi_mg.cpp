@@ -351,7 +351,7 @@ namespace mi_detail
           if (!(nw > 0.0) || !std::isfinite(nw))
             return fail(c0, MI_EINVAL, "multigrid: power iteration broke down on level %d", int(l));
           lam = nw;
-          if (getenv("MI_MG_VERBOSE"))
+          if (mi::exp_env("MI_MG_VERBOSE"))
             fprintf(stderr, "mg level %d power iteration %d: |D^-1 A v| = %.6f\n", int(l), it, nw);
           if (first && it >= 1) // iteration 0 only normalises the start vector
             {
@@ -450,44 +450,48 @@ namespace mi_detail
     mg_destroy(c);
     Multigrid *mg = new Multigrid;
     c->mg         = mg;
-    if (const char *e = getenv("MI_MG_NU"))
+    if (const char *e = mi::exp_env("MI_MG_NU"))
       mg->nu = std::max(1, atoi(e));
-    if (const char *e = getenv("MI_MG_NU_COARSE"))
+    if (const char *e = mi::exp_env("MI_MG_NU_COARSE"))
       mg->nu_coarse = std::max(1, atoi(e));
-    if (const char *e = getenv("MI_MG_NU_L1"))
+    if (const char *e = mi::exp_env("MI_MG_NU_L1"))
       mg->nu_level1 = std::max(0, atoi(e));
-    if (const char *e = getenv("MI_MG_FUSE"))
+    if (const char *e = mi::exp_env("MI_MG_FUSE"))
       mg->fuse = std::min(2, std::max(0, atoi(e)));
-    if (const char *e = getenv("MI_MG_FUSE_MAX_NODES"))
+    if (const char *e = mi::exp_env("MI_MG_FUSE_MAX_NODES"))
       mg->fuse_max_nodes = std::max(0, atoi(e));
-    if (const char *e = getenv("MI_MG_THREE_TERM"))
+    if (const char *e = mi::exp_env("MI_MG_THREE_TERM"))
       mg->three_term = atoi(e) != 0;
-    if (const char *e = getenv("MI_MG_BLOCK"))
+    if (const char *e = mi::exp_env("MI_MG_BLOCK"))
       mg->block = atoi(e) != 0;
-    if (const char *e = getenv("MI_MG_KIND"))
+    if (const char *e = mi::exp_env("MI_MG_KIND"))
       mg->kind = atoi(e) == 4 ? 4 : 1;
-    if (const char *e = getenv("MI_MG_RATIO"))
+    if (const char *e = mi::exp_env("MI_MG_RATIO"))
       mg->smooth_ratio = std::max(2.0, atof(e));
-    if (const char *e = getenv("MI_MG_COARSEST"))
+    if (const char *e = mi::exp_env("MI_MG_COARSEST"))
       mg->coarsest_reps = std::max(1, atoi(e));
-    if (const char *e = getenv("MI_MG_DENSE"))
+    if (const char *e = mi::exp_env("MI_MG_DENSE"))
       mg->dense = atoi(e) != 0;
-    if (const char *e = getenv("MI_MG_SAFETY"))
+    if (const char *e = mi::exp_env("MI_MG_SAFETY"))
       mg->lmax_safety = std::max(1.0, atof(e));
-    if (const char *e = getenv("MI_MG_POWER_ITS"))
+    if (const char *e = mi::exp_env("MI_MG_POWER_ITS"))
       mg->power_its_update = std::max(1, atoi(e));
-    if (const char *e = getenv("MI_MG_FACTOR"))
+    if (const char *e = mi::exp_env("MI_MG_FACTOR"))
       mg->coarsen_factor = std::max(2, atoi(e));
-    if (const char *e = getenv("MI_MG_COARSE_DEGREE"))
+    if (const char *e = mi::exp_env("MI_MG_COARSE_DEGREE"))
       mg->coarse_degree = std::max(1, atoi(e));
-    if (const char *e = getenv("MI_MG_COARSE_RATIO"))
+    if (const char *e = mi::exp_env("MI_MG_COARSE_RATIO"))
       mg->coarse_ratio = std::max(2.0, atof(e));
-    if (const char *e = getenv("MI_MG_RESTRICT_FUSE"))
+    if (const char *e = mi::exp_env("MI_MG_RESTRICT_FUSE"))
       mg->restrict_fuse = atoi(e) != 0;
-    if (const char *e = getenv("MI_MG_DIST_NODES"))
+    if (const char *e = mi::exp_env("MI_MG_DIST_NODES"))
       mg->dist_nodes = std::max<int64_t>(0, atoll(e));
     if (c->mg_dist_nodes >= 0)
       mg->dist_nodes = c->mg_dist_nodes;
+    if (c->mg_coarsest >= 1)
+      mg->coarsest_reps = int(c->mg_coarsest);
+    if (c->mg_dense >= 0)
+      mg->dense = int(c->mg_dense);
     MgLevel L0;
     L0.ctx = c;
     mg->levels.push_back(L0);

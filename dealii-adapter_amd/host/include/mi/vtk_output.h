@@ -1,9 +1,13 @@
 // Legacy-VTK output in the spirit of DataOut + Postprocessor + MappingQEulerian of the reference
 // (nonlinear_elasticity.cc:1215-1254, postprocessor.h:46-111): one patch per cell with (p+1)^dim points on the
-// DISPLACED mesh, split into p^dim linear sub-cells; point data "displacement" (vector) and the dim*dim scalars
-// strain_xx, strain_xy, ... = sym(grad u), with the gradient taken in the mapping used for output (the displaced
-// configuration, as DataOut does when it is given the Eulerian mapping).  Points are duplicated per cell, so the
-// strain is cell-wise discontinuous exactly as in deal.II patches.
+// DISPLACED mesh; point data "displacement" (vector) and the dim*dim scalars strain_xx, strain_xy, ... = sym(grad u),
+// with the gradient taken in the mapping used for output (the displaced configuration, as DataOut does when it is
+// given the Eulerian mapping).  Points are duplicated per cell, so the strain is cell-wise discontinuous exactly as in
+// deal.II patches.
+// Cells (round 6): ONE higher-order cell per patch, VTK_LAGRANGE_QUADRILATERAL (70) / VTK_LAGRANGE_HEXAHEDRON (72) with
+// the patch's (p+1)^dim points listed in VTK's Lagrange order, as the reference's `flags.write_higher_order_cells = true`
+// makes DataOut write them (nonlinear_elasticity.cc:1222-1225, linear_elasticity.cc:599; needs ParaView >= 5.5, :1221).
+// higher_order = false: the patch split into p^dim linear sub-cells (types 9 / 12; rounds 1-5), for older readers.
 #pragma once
 #include <cmath>
 #include <fstream>
@@ -12,6 +16,7 @@
 #include <vector>
 
 #include "device_vector.h"
+#include "vtk_lagrange.h"
 
 namespace mi
 {
@@ -102,7 +107,8 @@ namespace mi
   // EVERY rank of a decomposed run has to call this: mi_get_node_coords and mi_vec_get assemble global views through
   // team collectives (ncclAllReduce under RCCL), which hang or pair up with the wrong collective when only one rank
   // enters them.  write = false (ranks > 0): take part in the gathers, write nothing.
-  inline void write_vtk(const Device &dev, int dim, int p, const int reps[3], const std::string &path, bool write = true)
+  inline void write_vtk(const Device &dev, int dim, int p, const int reps[3], const std::string &path, bool write = true,
+                        bool higher_order = true)
   {
     const int64_t       nn = mi_n_nodes(dev.ctx()), n = mi_n_dofs(dev.ctx());
     std::vector<double> xyz(size_t(nn) * dim), u(size_t(n), 0.0);
@@ -219,6 +225,26 @@ namespace mi
     out << "POINTS " << npts << " double\n";
     for (int64_t i = 0; i < npts; ++i)
       out << pts[size_t(i) * 3] << ' ' << pts[size_t(i) * 3 + 1] << ' ' << pts[size_t(i) * 3 + 2] << '\n';
+    if (higher_order)
+      {
+        // one Lagrange cell per patch: the patch's points (stored lexicographically, x fastest) in VTK's order
+        std::vector<int> perm((size_t)npc, 0); // perm[vtk position] = lexicographic point of the patch
+        for (int a = 0; a < npc; ++a)
+          perm[size_t(vtk_detail::lagrange_index(dim, p, a % np1, (a / np1) % np1, dim == 3 ? a / (np1 * np1) : 0))] = a;
+        out << "CELLS " << ncells << ' ' << ncells * (npc + 1) << '\n';
+        for (int64_t c = 0; c < ncells; ++c)
+          {
+            out << npc;
+            for (int a = 0; a < npc; ++a)
+              out << ' ' << c * npc + perm[size_t(a)];
+            out << '\n';
+          }
+        out << "CELL_TYPES " << ncells << '\n';
+        for (int64_t c = 0; c < ncells; ++c)
+          out << (dim == 2 ? 70 : 72) << '\n'; // VTK_LAGRANGE_QUADRILATERAL / VTK_LAGRANGE_HEXAHEDRON
+      }
+    else
+      {
     out << "CELLS " << nsub << ' ' << nsub * (nv + 1) << '\n';
     for (int64_t c = 0; c < ncells; ++c)
       for (int k = 0; k < (dim == 3 ? p : 1); ++k)
@@ -235,6 +261,7 @@ namespace mi
     out << "CELL_TYPES " << nsub << '\n';
     for (int64_t c = 0; c < nsub; ++c)
       out << (dim == 2 ? 9 : 12) << '\n';
+      }
     out << "POINT_DATA " << npts << "\nVECTORS displacement double\n";
     for (int64_t i = 0; i < npts; ++i)
       out << disp[size_t(i) * 3] << ' ' << disp[size_t(i) * 3 + 1] << ' ' << disp[size_t(i) * 3 + 2] << '\n';

@@ -120,7 +120,8 @@ namespace Linear_Elasticity
     std::ostringstream name;
     name << "solution-" << std::setw(3) << std::setfill('0') << time.get_timestep() / interval << ".vtk";
     // all ranks: the global views behind the output are gathered by team collectives; rank 0 writes the file
-    mi::write_vtk(*device, dim, int(parameters.poly_degree), mesh_desc.reps, parameters.output_folder + "/" + name.str(), mi::host_rank() == 0);
+    mi::write_vtk(*device, dim, int(parameters.poly_degree), mesh_desc.reps, parameters.output_folder + "/" + name.str(), mi::host_rank() == 0,
+                  !std::getenv("MI_VTK_LINEAR_CELLS")); // higher-order cells as the reference (:1222-1225); the switch: linear sub-cells
     timer.leave_subsection("Output results");
   }
 

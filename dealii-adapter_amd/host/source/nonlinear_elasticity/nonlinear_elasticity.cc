@@ -1,5 +1,6 @@
 #include "nonlinear_elasticity.h"
 
+#include <algorithm>
 #include <cmath>
 #include <fstream>
 #include <iomanip>
@@ -193,8 +194,20 @@ namespace Nonlinear_Elasticity
     // a time-stepping run: the j-th linear solve of a step starts from the solution of the j-th solve of the previous
     // step (the reference starts from its previous Newton update, :419 / :472 -- the same stopping rule either way,
     // fewer iterations this way); MI_CG_WARM_START=0|1 selects zero / the reference's start vector instead
-    if (!std::getenv("MI_CG_WARM_START"))
-      device->check(mi_set_tuning(device->ctx(), "cg_warm_start", 2), "mi_set_tuning");
+    // (switches of this PROGRAM, handed on as tuning keys: the library itself reads no environment variable)
+    {
+      const char *e = std::getenv("MI_CG_WARM_START");
+      device->check(mi_set_tuning(device->ctx(), "cg_warm_start", e ? std::max(0, std::min(3, std::atoi(e))) : 2), "mi_set_tuning");
+      if (const char *f = std::getenv("MI_CORRECT_FACE_F")) // "--correct-face-F" (SURVEY section 9); default: the reference's quirk
+        device->check(mi_set_tuning(device->ctx(), "correct_face_F", std::atoi(f) != 0), "mi_set_tuning");
+      if (const char *f = std::getenv("MI_FINE_LEVEL")) // 1: the fine level matrix-free end to end (3D Q2 meshes)
+        {
+          if (std::atoi(f) != 0 && mi_set_tuning(device->ctx(), "fine_level", 1) != MI_OK)
+            std::cout << "MI_FINE_LEVEL ignored: " << mi_last_error(device->ctx()) << std::endl;
+          else if (std::atoi(f) != 0)
+            device->check(mi_set_tuning(device->ctx(), "mf_diag_lag", 1), "mi_set_tuning");
+        }
+    }
 
     std::cout << "Triangulation:"
               << "\n\t Number of active cells: " << mi_n_cells(device->ctx())
@@ -368,7 +381,8 @@ namespace Nonlinear_Elasticity
     std::ostringstream name;
     name << "solution-" << std::setw(3) << std::setfill('0') << time.get_timestep() / interval << ".vtk";
     // all ranks: the global views behind the output are gathered by team collectives; rank 0 writes the file
-    mi::write_vtk(*device, dim, int(degree), mesh_desc.reps, parameters.output_folder + "/" + name.str(), mi::host_rank() == 0);
+    mi::write_vtk(*device, dim, int(degree), mesh_desc.reps, parameters.output_folder + "/" + name.str(), mi::host_rank() == 0,
+                  !std::getenv("MI_VTK_LINEAR_CELLS")); // higher-order cells as the reference (:1222-1225); the switch: linear sub-cells
     std::cout << "\t Output written to " << name.str() << " \n" << std::endl;
     timer.leave_subsection("Output results");
   }

@@ -19,6 +19,7 @@
 #include <adapter/adapter.h>
 #include <adapter/parameters.h>
 #include <adapter/time_handler.h>
+#include <mi/vtk_lagrange.h>
 
 static int g_fail = 0;
 #define CHECK(cond)                                                          \
@@ -118,8 +119,45 @@ subsection precice configuration
 end
 )";
 
+// VTK's node order of Lagrange cells (higher-order output, nonlinear_elasticity.cc:1222-1225): a bijection for every
+// order, the linear cell's order at order 1, and the 27 positions of the quadratic hexahedron by name
+static void test_vtk_lagrange_order()
+{
+  for (int dim = 2; dim <= 3; ++dim)
+    for (int order = 1; order <= 4; ++order)
+      {
+        const int         n1 = order + 1, npc = dim == 2 ? n1 * n1 : n1 * n1 * n1;
+        std::vector<int> seen((size_t)npc, 0);
+        for (int a = 0; a < npc; ++a)
+          {
+            const int v = mi::vtk_detail::lagrange_index(dim, order, a % n1, (a / n1) % n1, dim == 3 ? a / (n1 * n1) : 0);
+            CHECK(v >= 0 && v < npc);
+            if (v >= 0 && v < npc)
+              ++seen[size_t(v)];
+          }
+        for (int v = 0; v < npc; ++v)
+          CHECK(seen[size_t(v)] == 1);
+      }
+  auto L3 = [](int i, int j, int k) { return mi::vtk_detail::lagrange_index(3, 2, i, j, k); };
+  // corners: the linear hexahedron's order
+  CHECK(L3(0, 0, 0) == 0 && L3(2, 0, 0) == 1 && L3(2, 2, 0) == 2 && L3(0, 2, 0) == 3);
+  CHECK(L3(0, 0, 2) == 4 && L3(2, 0, 2) == 5 && L3(2, 2, 2) == 6 && L3(0, 2, 2) == 7);
+  // edge midpoints: bottom face x y x y, top face, the four vertical edges (x0y0, x1y0, x0y1, x1y1)
+  CHECK(L3(1, 0, 0) == 8 && L3(2, 1, 0) == 9 && L3(1, 2, 0) == 10 && L3(0, 1, 0) == 11);
+  CHECK(L3(1, 0, 2) == 12 && L3(2, 1, 2) == 13 && L3(1, 2, 2) == 14 && L3(0, 1, 2) == 15);
+  CHECK(L3(0, 0, 1) == 16 && L3(2, 0, 1) == 17 && L3(0, 2, 1) == 18 && L3(2, 2, 1) == 19);
+  // face centres x- x+ y- y+ z- z+, body centre
+  CHECK(L3(0, 1, 1) == 20 && L3(2, 1, 1) == 21 && L3(1, 0, 1) == 22 && L3(1, 2, 1) == 23 && L3(1, 1, 0) == 24 && L3(1, 1, 2) == 25);
+  CHECK(L3(1, 1, 1) == 26);
+  auto L2 = [](int i, int j) { return mi::vtk_detail::lagrange_index(2, 3, i, j, 0); };
+  CHECK(L2(0, 0) == 0 && L2(3, 0) == 1 && L2(3, 3) == 2 && L2(0, 3) == 3);
+  CHECK(L2(1, 0) == 4 && L2(2, 0) == 5 && L2(3, 1) == 6 && L2(3, 2) == 7 && L2(1, 3) == 8 && L2(2, 3) == 9 && L2(0, 1) == 10 && L2(0, 2) == 11);
+  CHECK(L2(1, 1) == 12 && L2(2, 1) == 13 && L2(1, 2) == 14 && L2(2, 2) == 15);
+}
+
 int main()
 {
+  test_vtk_lagrange_order();
   // every file the tests write goes into a scratch directory of their own (under $TMPDIR), removed at the end
   std::string scratch = std::string(std::getenv("TMPDIR") ? std::getenv("TMPDIR") : "/tmp") + "/mi_test_host_XXXXXX";
   if (!mkdtemp(scratch.data()) || chdir(scratch.c_str()) != 0)

@@ -51,3 +51,21 @@ def test_product_does_not_reference_the_oracle(built):
                 assert "liboracle" not in txt and "elasticity_oracle" not in txt, os.path.join(root, f)
     deps = subprocess.run(["ldd", M.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+def test_release_library_reads_no_environment_switch(built):
+    """round 6: a library a maintainer links into `elasticity` must not change its numerics or its solver path with the caller's
+    environment.  Every switch is a mi_set_tuning key; the environment hooks of rounds 1-5 (MI_MG_*, MI_MF_*, MI_PRECOND, ...) and
+    the A/B kernel instantiations they select compile only under -DMI_EXPERIMENTS (make EXPERIMENTS=1 ->
+    libmi_elasticity_exp.so, what tools/profile_round.sh builds).  MI_DEVICE, MI_PROFILE and the rank-identity variables belong
+    to the host executables (dealii-adapter_amd/host), not to the library."""
+    import re
+    src = os.path.join(M.PKG_DIR, "csrc")
+    n = sum(len(re.findall(r"\bgetenv\s*\(", open(os.path.join(src, f), errors="ignore").read())) for f in os.listdir(src))
+    assert n <= 6, n  # (one: inside mi::exp_env, under #ifdef MI_EXPERIMENTS)
+    blob = open(M.LIB_PATH, "rb").read()
+    names = {n for n in re.findall(rb"MI_[A-Z][A-Z0-9_]{2,}", blob)
+             if not n.startswith((b"MI_V_", b"MI_T_", b"MI_E", b"MI_OK"))}  # (enumerators quoted in error texts)
+    assert names == set(), names  # no variable name survives in the release build
+    out = subprocess.run(["nm", "-D", "--undefined-only", M.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out.split()  # the library itself does not even import getenv (libraries it links may)

@@ -80,12 +80,9 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, s
     n = int(g[name + "_cells"])
     # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
     perturb = 0.08 / n * np.random.default_rng(77).standard_normal(((n + 1) ** 3, 3)) if distorted else None
-    if dist_nodes is not None:  # read when the hierarchy is built (context creation above 75 k dofs)
-        os.environ["MI_MG_DIST_NODES"] = str(dist_nodes)
-    try:
-        G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb, slabs=slabs, cut_axis=cut_axis)
-    finally:
-        os.environ.pop("MI_MG_DIST_NODES", None)
+    G = M.Context(dim=dim, degree=degree, reps=(n,) * dim, perturb=perturb, slabs=slabs, cut_axis=cut_axis)
+    if dist_nodes is not None:  # (the hierarchy exists since the context's creation above 75 k dofs: the key rebuilds it)
+        G.set_tuning("mg_dist_nodes", dist_nodes)
     assert G.get_tuning("precond") == 1  # multigrid: the default above 75 k dofs
     if slabs > 1:  # levels cut into slabs: fine + Q1 on the same cells (+ the first coarsened level when forced / big enough)
         assert G.get_tuning("mg_distributed_levels") == (2 if degree > 1 else 1) + (1 if dist_nodes == 0 else 0)
@@ -95,6 +92,7 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, s
     if fine_level:  # round 6: no assembled fine tangent -- records + residual + diagonal blocks, every product on mf_spmv
         G.set_tuning("fine_level", 1)
         assert G.get_tuning("fine_level") == 1
+        G.set_tuning("mf_diag_lag", 1 if fine_level == 2 else 0)  # 2: the policy bench.py and the executable run with
     ids = g[name + "_nodes"]
     for s, trac in enumerate(g[name + "_traction"]):
         G.set_interface_traction(trac)
@@ -137,7 +135,7 @@ def test_gpu_24cube_block_decomposed_against_the_oracle(slabs, cut_axis):
 @pytest.mark.gpu
 @pytest.mark.parametrize("slabs,cut_axis", [(3, 0), (4, 2), (2, 1)])
 def test_gpu_24cube_block_with_a_distributed_first_coarsened_level(slabs, cut_axis):
-    """round 5: past a size threshold the first COARSENED multigrid level (12^3 cells here, forced by MI_MG_DIST_NODES=0) is
+    """round 5: past a size threshold the first COARSENED multigrid level (12^3 cells here, forced by tuning "mg_dist_nodes" 0) is
     cut into slabs of its own instead of being replicated on every slab: cuts induced by the finer level's, restriction and
     coarse state through partial results on ghost planes (team_halo_accumulate), prolongation of the owned planes from
     the slab's own box.  Same fixture, same tolerances as the replicated hierarchy: against the oracle."""
@@ -155,17 +153,20 @@ def test_gpu_fp32_smoother_products_against_the_oracle(name, slabs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,slabs,cut_axis,start,distorted",
-                         [("blk24", 1, 0, 0, False), ("blk24", 1, 0, 2, False), ("blk24d", 1, 0, 2, True), ("blk24", 3, 1, 2, False),
-                          ("cfg3", 1, 0, 2, False), ("cfg3", 4, 0, 2, False), ("cfg4s", 1, 0, 2, False), ("cfg4s", 8, 0, 2, False)])
-def test_gpu_matrix_free_fine_level_against_the_oracle(name, slabs, cut_axis, start, distorted):
+@pytest.mark.parametrize("name,slabs,cut_axis,start,distorted,mode",
+                         [("blk24", 1, 0, 0, False, 1), ("blk24", 1, 0, 2, False, 2), ("blk24d", 1, 0, 2, True, 2), ("blk24", 3, 1, 2, False, 1),
+                          ("cfg3", 1, 0, 2, False, 1), ("cfg3", 1, 0, 2, False, 2), ("cfg3", 4, 0, 2, False, 2),
+                          ("cfg4s", 1, 0, 2, False, 1), ("cfg4s", 1, 0, 2, False, 2), ("cfg4s", 8, 0, 2, False, 2)])
+def test_gpu_matrix_free_fine_level_against_the_oracle(name, slabs, cut_axis, start, distorted, mode):
     """round 6, tuning "fine_level" 1: the fine level keeps NO assembled tangent -- a tangent assembly is the residual pass
     that writes the point records plus the nodes' diagonal blocks formed from them (mf_diag), and the CG's product, the
     residual / start-vector products and the smoother all run on mf_spmv.  Same fixtures, same tolerances, same Newton
     tables as the assembled path (the oracle's steps [REF nonlinear_elasticity.cc:410-499, 1044-1087, 1153-1191]): boxes and
     distorted cells, one slab and decomposed (the CG's matrix-free product around the halo exchange), BASELINE
-    configurations 3 and 4 on 1 and 4 / 8 slabs."""
-    _nonlinear(name, 1e-8, 1e-6, start, distorted=distorted, slabs=slabs, cut_axis=cut_axis, fine_level=1)
+    configurations 3 and 4 on 1 and 4 / 8 slabs.  mode 2: with "mf_diag_lag" 1 -- the diagonal blocks (smoother side only)
+    formed at the first tangent of a time step and kept over its Newton iterations: the policy bench.py's
+    with_matrix_free_fine_level and the executable (MI_FINE_LEVEL=1) run with."""
+    _nonlinear(name, 1e-8, 1e-6, start, distorted=distorted, slabs=slabs, cut_axis=cut_axis, fine_level=mode)
 
 
 @pytest.mark.gpu

@@ -34,21 +34,21 @@ def fake_lib():
                                                           (3, 2, 2, "9,4", 1, 0), (4, 3, 2, "9,2,2", 0, 2)])
 def test_rank_threads_through_the_rccl_branch(fake_lib, world, dim, p, reps, overlap, ebe):
     """ebe = 1 / 2: the multigrid smoother on the stored element tangents / matrix-free, as on big meshes"""
-    _run_ranks(world, dim, p, reps, overlap, ebe, {})
+    _run_ranks(world, dim, p, reps, overlap, ebe, -1)
 
 
 @pytest.mark.parametrize("world,dim,p,reps", [(3, 3, 2, "3,3,13"), (4, 3, 1, "4,3,17"), (3, 2, 2, "4,19"), (2, 3, 2, "9,3,3")])
 def test_rank_threads_with_a_distributed_first_coarsened_level(fake_lib, world, dim, p, reps):
     """round 5: the first COARSENED multigrid level cut into slabs of its own (cuts induced by the finer level's; restriction
     and state through partial results on ghost planes, team_halo_accumulate) -- forced on these small meshes by
-    MI_MG_DIST_NODES=0; the same checks as above: every rank the same bits, the emulated slabs to 1e-9, one GPU to the
+    tuning "mg_dist_nodes" 0; the same checks as above: every rank the same bits, the emulated slabs to 1e-9, one GPU to the
     linear tolerance, iteration counts within one"""
-    _run_ranks(world, dim, p, reps, 1, 0, {"MI_MG_DIST_NODES": "0"})
+    _run_ranks(world, dim, p, reps, 1, 0, 0)
 
 
-def _run_ranks(world, dim, p, reps, overlap, ebe, env):
+def _run_ranks(world, dim, p, reps, overlap, ebe, dist_nodes):
     out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap),
-                          str(ebe)], capture_output=True, text=True, timeout=900, env=dict(os.environ, **env))
+                          str(ebe), str(dist_nodes)], capture_output=True, text=True, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, (out.stdout[-2000:], out.stderr[-3000:])
     r = json.loads(lines[-1])
@@ -60,9 +60,9 @@ def _run_ranks(world, dim, p, reps, overlap, ebe, env):
     for k, v in r["vs_emulated"].items():
         assert v < 1e-9, (k, v, r)  # same slabs, same reduction order up to the all-reduce's summation
     # levels cut into slabs: the fine level (+ the Q1 level on the same cells for degree > 1), + the first coarsened level
-    # where MI_MG_DIST_NODES forces it
+    # where "mg_dist_nodes" 0 forces it
     base = 2 if p > 1 else 1
-    assert r["mg_dist_levels"] == [base + (1 if env else 0)] * 2 + [0], r["mg_dist_levels"]
+    assert r["mg_dist_levels"] == [base + (1 if dist_nodes == 0 else 0)] * 2 + [0], r["mg_dist_levels"]
     for its in r["its_ranks"]:
         assert its == r["its_ranks"][0]
         assert all(abs(a - b) <= 1 for a, b in zip(its, r["its_emulated"]))

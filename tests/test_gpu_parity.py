@@ -212,7 +212,9 @@ def test_element_kernel_variants_agree():
     G.update_acceleration()
     x = rng.standard_normal(G.n)
     ref = None
-    for v in (0, 3, 4, 5, 6, 7, 8, 9, 1, 2):
+    # (3-8 and the two-kernel forms below are A/B instantiations of the experiments build: make EXPERIMENTS=1 + MI_LIB)
+    exp = G.get_tuning("experiments") == 1
+    for v in (0, 3, 4, 5, 6, 7, 8, 9, 1, 2) if exp else (0, 9, 1, 2):
         G.set_tuning("asm_variant", v)
         rn = G.assemble()
         y, r = G.spmv(x), G.get(M.V_RHS)
@@ -230,16 +232,23 @@ def test_element_kernel_variants_agree():
     G.set_tuning("asm_variant", 0)
     G.set_tuning("element_tangents", 2)
     K = {}
-    for split in (0, 1):
+    if not exp:
+        with pytest.raises(M.MiError):
+            G.set_tuning("asm_split", 1)
+        with pytest.raises(M.MiError):
+            G.set_tuning("asm_variant", 5)
+        return
+    for split in (0, 1, 2):
         G.set_tuning("asm_split", split)
         rn = G.assemble()
         K[split] = (G.csr().data.copy(), G.get(M.V_RHS), rn, G.spmv(x))
         G.set_tuning("spmv_variant", 4)  # the matrix-free product from the records either kernel left
         assert np.abs(G.spmv(x) - K[split][3]).max() / np.abs(K[split][3]).max() < 1e-13
         G.set_tuning("spmv_variant", 3)
-    assert np.abs(K[1][0] - K[0][0]).max() / np.abs(K[0][0]).max() < 1e-13
-    assert np.array_equal(K[1][1], K[0][1]) and K[1][2] == K[0][2]  # the residual: the same instruction stream
-    assert np.abs(K[1][3] - ref[0]).max() / np.abs(ref[0]).max() < 1e-13
+    for split in (1, 2):
+        assert np.abs(K[split][0] - K[0][0]).max() / np.abs(K[0][0]).max() < 1e-13
+        assert np.array_equal(K[split][1], K[0][1]) and K[split][2] == K[0][2]  # the residual: the same instruction stream
+        assert np.abs(K[split][3] - ref[0]).max() / np.abs(ref[0]).max() < 1e-13
 
 
 def _diag_blocks_of(K, dim):
@@ -382,15 +391,15 @@ def test_matrix_free_product_in_one_launch_is_bitwise_the_coloured_update():
         assert _relmax(y1, G.spmv(x)) < 1e-13
 
 
-def test_exact_coarsest_level_solve_against_the_polynomial(monkeypatch):
+def test_exact_coarsest_level_solve_against_the_polynomial():
     """the dense inverse on the coarsest multigrid level (2^3 cells) against round 1's degree-12 polynomial on a one-cell
     level: a preconditioner at least as good (iterations) and the same converged solution"""
     res = {}
     for dense in (1, 0):
-        if not dense:
-            monkeypatch.setenv("MI_MG_DENSE", "0")
-            monkeypatch.setenv("MI_MG_COARSEST", "1")
         G = M.Context(dim=3, degree=2, reps=(12, 10, 8))
+        if not dense:  # (keys of the hierarchy's shape: set before "precond" 1 builds it, or it is rebuilt)
+            G.set_tuning("mg_dense", 0)
+            G.set_tuning("mg_coarsest", 1)
         G.set_tuning("precond", 1)
         G.set_interface_traction((0.0, -2e3, 0.0))
         G.newton_begin_step()

@@ -85,6 +85,13 @@ def test_executable_nonlinear_explicit_2d(tmp_path):
     for section in ("Setup system", "Assemble linear system", "Linear solver", "Advance adapter", "Output results"):
         assert section in stdout
     assert os.path.exists(tmp_path / "out" / "solution-000.vtk")
+    # 2D: one VTK_LAGRANGE_QUADRILATERAL (70) per cell with (p+1)^2 points (nonlinear_elasticity.cc:1222-1225)
+    vtk = open(tmp_path / "out" / "solution-000.vtk").read().split("\n")
+    p1 = int(get("Polynomial degree")) + 1
+    k = next(i for i, l in enumerate(vtk) if l.startswith("CELL_TYPES"))
+    assert int(vtk[k].split()[1]) == P.ncells and set(vtk[k + 1:k + 1 + P.ncells]) == {"70"}
+    k = next(i for i, l in enumerate(vtk) if l.startswith("CELLS"))
+    assert all(int(l.split()[0]) == p1 * p1 and len(l.split()) == p1 * p1 + 1 for l in vtk[k + 1:k + 1 + P.ncells])
     # machine-readable step log next to the Newton table
     import json
     steps = [json.loads(l) for l in open(tmp_path / "out" / "steps.jsonl")]
@@ -266,6 +273,19 @@ def test_executable_nonlinear_3d(tmp_path, name, windows, traction):
     if name == "block_neo_3d_q2":
         _check_vtk(tmp_path / "out" / "solution-000.vtk", P, zero=True)
         _check_vtk(tmp_path / "out" / "solution-001.vtk", P, zero=False)  # timestep 2 / Output interval 2
+        # the switch back to linear sub-cells (readers older than ParaView 5.5, :1221): p^3 = 8 hexahedra (12) per patch,
+        # same points and fields
+        sub = tmp_path / "linear"
+        sub.mkdir()
+        _run_case(name, "elasticity3d", sub, env={"MI_VTK_LINEAR_CELLS": "1"})
+        a = open(tmp_path / "out" / "solution-001.vtk").read().split("\n")
+        b = open(sub / "out" / "solution-001.vtk").read().split("\n")
+        kb = next(i for i, l in enumerate(b) if l.startswith("CELL_TYPES"))
+        assert int(b[kb].split()[1]) == 8 * P.ncells and set(b[kb + 1:kb + 1 + 8 * P.ncells]) == {"12"}
+        ia, ib = (next(i for i, l in enumerate(t) if l.startswith("CELLS")) for t in (a, b))
+        assert a[:ia] == b[:ib]  # header and points
+        ja, jb = (next(i for i, l in enumerate(t) if l.startswith("POINT_DATA")) for t in (a, b))
+        assert a[ja:] == b[jb:]  # fields
 
 
 def test_executable_on_emulated_slabs(tmp_path):
@@ -322,6 +342,33 @@ def test_launcher_ends_all_ranks_when_one_fails(tmp_path):
     assert out.returncode == 1 and "out of range" in out.stderr
 
 
+def _check_vtk_lagrange_cells(txt, ref, ncells, npc):
+    """round 6 (f-3's last gap): ONE higher-order cell per patch, as `flags.write_higher_order_cells = true` makes DataOut
+    write them [REF nonlinear_elasticity.cc:1222-1225]: type 72 = VTK_LAGRANGE_HEXAHEDRON, (p+1)^3 = 27 point ids each -- a
+    permutation of the patch's own points -- in VTK's Lagrange order, checked GEOMETRICALLY on the reference coordinates of
+    the listed points: 8 corners in the linear hexahedron's order, 12 edge midpoints (bottom face x y x y, top face, the
+    vertical edges (x0,y0) (x1,y0) (x0,y1) (x1,y1)), 6 face centres (x- x+ y- y+ z- z+), the body centre"""
+    i = next(k for k, l in enumerate(txt) if l.startswith("CELLS"))
+    n, size = (int(v) for v in txt[i].split()[1:3])
+    assert n == ncells and size == ncells * (npc + 1)
+    cells = np.array([l.split() for l in txt[i + 1:i + 1 + n]], dtype=np.int64)
+    assert cells.shape == (ncells, npc + 1) and np.all(cells[:, 0] == npc)
+    j = next(k for k, l in enumerate(txt) if l.startswith("CELL_TYPES"))
+    assert int(txt[j].split()[1]) == ncells and all(int(t) == 72 for t in txt[j + 1:j + 1 + ncells])
+    # unit-cell position (0, 1/2, 1 per direction) of every VTK slot of the quadratic Lagrange hexahedron
+    c8 = [(0, 0, 0), (2, 0, 0), (2, 2, 0), (0, 2, 0), (0, 0, 2), (2, 0, 2), (2, 2, 2), (0, 2, 2)]
+    e12 = [(1, 0, 0), (2, 1, 0), (1, 2, 0), (0, 1, 0), (1, 0, 2), (2, 1, 2), (1, 2, 2), (0, 1, 2),
+           (0, 0, 1), (2, 0, 1), (0, 2, 1), (2, 2, 1)]
+    f6 = [(0, 1, 1), (2, 1, 1), (1, 0, 1), (1, 2, 1), (1, 1, 0), (1, 1, 2)]
+    want = np.array(c8 + e12 + f6 + [(1, 1, 1)])
+    for c in range(ncells):
+        ids = cells[c, 1:]
+        assert sorted(ids) == list(range(c * npc, (c + 1) * npc))  # a permutation of the patch
+        X = ref[ids]
+        lo, hi = X.min(0), X.max(0)
+        assert np.array_equal(np.rint(2 * (X - lo) / (hi - lo)).astype(int), want), c
+
+
 def _check_vtk(path, P, zero):
     """patch-wise VTK with displacement + strain_ij scalars (postprocessor.h:46-111)"""
     txt = open(path).read().split("\n")
@@ -337,6 +384,7 @@ def _check_vtk(path, P, zero):
         if l.startswith("SCALARS strain_"):
             fields[l.split()[1]] = np.array(txt[k + 2:k + 2 + npts], dtype=float)
     assert sorted(fields) == sorted("strain_" + a + b for a in "xyz" for b in "xyz")
+    _check_vtk_lagrange_cells(txt, pts - disp, ncells, npc)
     if zero:
         assert np.all(disp == 0) and all(np.all(f == 0) for f in fields.values())
         return
