@@ -381,6 +381,9 @@ def main():
     ap.add_argument("--cpu-config4", action="store_true", help=argparse.SUPPRESS)  # (round 3's opt-in; now the default)
     ap.add_argument("--cpu-worker", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # child of pmc_traffic(): one step, no output
+    ap.add_argument("--no-sides", action="store_true",
+                    help="profiling runs: skip the further measurements beside the headline (config.with_*), so that a kernel trace "
+                         "of the process holds the kernels of ONE path")
     ap.add_argument("--no-pmc", action="store_true", help="skip the live HBM-traffic passes (three child runs under rocprofv3 --pmc)")
     args = ap.parse_args()
 
@@ -770,7 +773,7 @@ def main():
                                    "workload": "%dx%dx%d cells (%d^3 per GPU)" % (n, n, W["nz"], n),
                                    "cg_iterations_per_step": W["cg_its"] / args.steps}
         del W
-    if world == 1 and args.slabs == 1:
+    if world == 1 and args.slabs == 1 and not args.no_sides:
         # Further measurements beside the headline, each over the SAME step window as the headline (the same warm-up
         # steps, the same ramp phase, the same coarse-operator refreshes inside the window): `steps` / `warmup` in every
         # sub-object say so.  (Until round 5 these ran 3 steps after 1 warm-up and were indicative only.)

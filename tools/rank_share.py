@@ -10,11 +10,14 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 M = importlib.import_module("dealii-adapter_amd")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 59
 counts = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
-for N in counts:
+for fine, N in [(f, c) for f in (0, 1) for c in counts]:  # (round 6: also with the fine level matrix-free, "fine_level" 1)
     nz = n if N == 1 else int(math.ceil(n / N)) + 1
     G = M.Context(dim=3, degree=2, reps=(n, n, nz), hi=(1.0, 1.0, nz / n))
     G.set_tuning("cg_warm_start", 2)
     G.set_tuning("precond", 1)
+    if fine:
+        G.set_tuning("fine_level", 1)
+        G.set_tuning("mf_diag_lag", 1)
     steps, warm = 8, 2
     its = 0
     for k in range(warm + steps):
@@ -28,6 +31,6 @@ for N in counts:
             its += info.lin_its_total
     G.get_interface_displacement()  # (synchronises)
     dt = (time.perf_counter() - t0) / steps
-    print("N = %d: slab of %d x %d x %d cells (%d DoFs): %.2f ms per step, %.1f CG iterations per step" % (
+    print(("matrix-free fine level, " if fine else "") + "N = %d: slab of %d x %d x %d cells (%d DoFs): %.2f ms per step, %.1f CG iterations per step" % (
         N, n, n, nz, G.n, 1e3 * dt, its / steps), flush=True)
     G.close()
