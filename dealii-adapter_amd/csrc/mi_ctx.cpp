@@ -789,11 +789,25 @@ namespace mi_detail
       p.qrec = nullptr, p.qrec32 = nullptr;
     mi_ctx       *c0 = c->team->members[0];
     const int     t0 = tic(c0, residual_only ? MI_T_ASSEMBLE_RESIDUAL : MI_T_ASSEMBLE_CELLS);
+    // matrix-free fine level: the point pass over ALL cells in one launch (residual into the cells' slots, summed per node in
+    // processing order: the product's slots and its order), then the Neumann faces colour by colour on the summed vector
+    const bool one_launch = c->mf_fine && c->mf_point_slots && c->d_mf_yc;
+    if (one_launch)
+      {
+        p.lat        = c->lat; // node ids by arithmetic, as mf_spmv
+        p.cell_begin = 0;
+        p.cell_count = int32_t(c->mesh.ncells);
+        p.res_slots  = c->d_mf_yc; // (the product's slot array: no product is in flight during an assembly)
+        p.slot_dst   = c->d_mf_dst;
+        mi::launch_point_pass_slots(p, c->stream);
+        mi::launch_residual_gather(c->d_mf_yc, c->d_mf_slot_base, c->d_cmask, c->vec(MI_V_SYSTEM_RHS), int64_t(c->mesh.nnodes) * 3,
+                                   c->stream);
+      }
     for (int col = 0; col < c->mesh.ncolours; ++col)
       {
         p.cell_begin = c->mesh.colour_begin[col];
         p.cell_count = int32_t(c->mesh.colour_begin[col + 1] - c->mesh.colour_begin[col]);
-        if (mi::launch_assemble_cells(c->dim, c->degree, p, c->stream))
+        if (!one_launch && mi::launch_assemble_cells(c->dim, c->degree, p, c->stream))
           return fail(c, MI_EINVAL, "no assembly kernel for dim=%d degree=%d", c->dim, c->degree);
         const int fb = int(c->mesh.iface_colour_begin[col]);
         const int fc = int(c->mesh.iface_colour_begin[col + 1]) - fb;
@@ -2668,6 +2682,11 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
                          (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
                          (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
         return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
+      if (k == "mf_point_slots" && (value == 0 || value == 1)) // matrix-free fine level: point pass in one launch (1) | eight colour launches
+        {
+          m->mf_point_slots = value;
+          continue;
+        }
       if (k == "mf_diag_lag" && (value == 0 || value == 1))
         {
           m->mf_diag_lag   = value;

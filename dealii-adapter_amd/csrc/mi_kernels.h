@@ -75,6 +75,9 @@ namespace mi
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
     CellLattice     lat;    // 3D Q2: node ids by arithmetic (ncol == 0: read conn)
+    double         *res_slots; // matrix-free fine level, point pass in one launch: [nslots][3] the cells' residual entries ...
+    const int32_t  *slot_dst;  // ... at slot_dst[cell][27] (MfParams::dst); xcd_chunk: cells per XCD of that launch
+    int32_t         xcd_chunk;
     const double   *cellbox;  // [ncells][4] = 1/hx, 1/hy, 1/hz, hx hy hz when every local cell is an axis-parallel box, else null
     int32_t         from_records; // 3D Q2, records present: tangent in two kernels -- point pass, then the tangent from its records
     int32_t         correct_face_F; // Neumann term: 0 (default) = the reference's pull-back with the deformation gradient of CELL
@@ -262,6 +265,11 @@ namespace mi
   // matrix-free fine level (round 6): the nodes' diagonal blocks from the point records -- every cell into its own slots
   // [nslots][6] (MfParams::dst), then summed per node under the assembled matrix's constraint rule (see mf_diag)
   void launch_mf_diag(const MfParams &p, double *slots6, int32_t cell_count, hipStream_t s);
+  // the matrix-free fine level's point pass over ALL cells in one launch (assemble_q2sf<true> with the residual into slots:
+  // AsmParams::res_slots / slot_dst; cell_begin = 0, cell_count = all) and the sum of the slots into system_rhs
+  void launch_point_pass_slots(const AsmParams &p, hipStream_t s);
+  void launch_residual_gather(const double *slots3, const int32_t *slot_base, const uint8_t *cmask, double *rhs, int64_t ndofs,
+                              hipStream_t s);
   void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const uint8_t *cmask, const int32_t *diagpos,
                              double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s);
   // gather fused with the smoother's Chebyshev step (d != null: x += d in place) or residual (d == null: yres = b - K x)

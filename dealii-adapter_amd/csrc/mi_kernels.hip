@@ -809,7 +809,19 @@ namespace mi
                                               // scatter then skips the per-entry masking: all but the boundary cells)
     typedef const volatile __attribute__((address_space(3))) double *lds_cvp;
     const int     tid  = int(threadIdx.x);
-    const int64_t cell = prm.cell_begin + blockIdx.x;
+    // RES_ONLY bit 10 (round 6, the matrix-free fine level's point pass): ALL cells in one launch -- the 81 residual
+    // entries of a cell go to the cell's own slots (AsmParams::res_slots at the slots of MfParams::dst, as the matrix-free
+    // product's results) instead of being subtracted from system_rhs colour by colour; residual_gather sums them per node in
+    // processing order.  Workgroups of one XCD take a contiguous run of cells (as mf_spmv).
+    constexpr bool RSLOTS = RES_ONLY && (XV & 1024) != 0;
+    int64_t        cell   = prm.cell_begin + blockIdx.x;
+    if constexpr (RSLOTS)
+      {
+        const int64_t local = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
+        if (local >= prm.cell_count)
+          return;
+        cell = prm.cell_begin + local;
+      }
     // 1D tables (uniform)
     double S[4][3], D[4][3];
 #pragma unroll
@@ -1448,6 +1460,11 @@ namespace mi
                   {
                     rv = fma(D[qx][i], ed[qx], rv);
                     rv = fma(S[qx][i], es[qx], rv);
+                  }
+                if constexpr (RSLOTS)
+                  {
+                    prm.res_slots[int64_t(prm.slot_dst[cell * NPC + lkj * 3 + i]) * 3 + lc] = rv;
+                    continue;
                   }
                 const int32_t A = s_conn[lkj * 3 + i];
                 if (!((prm.cmask[A] >> lc) & 1))
@@ -3432,6 +3449,26 @@ namespace mi
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       dinv[n * 3 + c] = diagpos[n] >= 0 ? 1.0 / A[c * 4] : 0.0;
+  }
+
+  // system_rhs from the cells' residual slots (point pass in one launch): rhs = 0 - r_1 - r_2 - ... in slot order, the
+  // subtractions of the colour-by-colour update in their order; constrained rows get no rhs (:769-773).  One thread per dof.
+  __global__ __launch_bounds__(256) void residual_gather(const double *__restrict__ slots3, const int32_t *__restrict__ slot_base,
+                                                         const uint8_t *__restrict__ cmask, double *rhs, int64_t ndofs)
+  {
+    const int64_t g = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (g >= ndofs)
+      return;
+    const int64_t n = g / 3;
+    const int     c = int(g - n * 3);
+    double        s = 0.0;
+    if (!((cmask[n] >> c) & 1))
+      {
+        const int32_t b0 = slot_base[n], b1 = slot_base[n + 1];
+        for (int32_t k = b0; k < b1; ++k)
+          s = s - slots3[int64_t(k) * 3 + c];
+      }
+    rhs[g] = s;
   }
 
   // fp32-rounded copy of the value array for the multigrid smoother (opt-in "precond_storage" 32; same layout)
@@ -6241,6 +6278,19 @@ namespace mi
                             int64_t own_n, hipStream_t s)
   {
     hipLaunchKernelGGL(mf_gather_dot, dim3(grid), dim3(256), 0, s, p, ndofs, dotv, partials, own0, own_n);
+  }
+  void launch_point_pass_slots(const AsmParams &p, hipStream_t s)
+  {
+    if (p.cell_count <= 0)
+      return;
+    AsmParams q = p;
+    q.xcd_chunk = (p.cell_count + 7) / 8;
+    hipLaunchKernelGGL((assemble_q2sf<true, 1024>), dim3(q.xcd_chunk * 8), dim3(64), 0, s, q);
+  }
+  void launch_residual_gather(const double *slots3, const int32_t *slot_base, const uint8_t *cmask, double *rhs, int64_t ndofs,
+                              hipStream_t s)
+  {
+    hipLaunchKernelGGL(residual_gather, dim3(int((ndofs + 255) / 256)), dim3(256), 0, s, slots3, slot_base, cmask, rhs, ndofs);
   }
   void launch_mf_diag(const MfParams &p, double *slots6, int32_t cell_count, hipStream_t s)
   {

@@ -264,7 +264,8 @@ typedef struct
 int mi_set_profiling(mi_ctx *ctx, int enable);
 /* Run-time switches of a context (all its slabs).  None is needed for production use: the defaults are what bench.py and
  * the executables run, except "cg_warm_start", which both set to 2.  Unknown key or value out of range: MI_EINVAL.
- * Environment variables of the same meaning are read once at context creation (column "env").
+ * The library reads NO environment variable (round 6): the column "env" names the hook of the EXPERIMENTS build only
+ * (-DMI_EXPERIMENTS, make EXPERIMENTS=1 -> libmi_elasticity_exp.so: A/B runs of tools/), read once at context creation there.
  *
  *  key                  values (default first)     meaning                                                            env
  *  -------------------  -------------------------  -----------------------------------------------------------------  ----------------
@@ -294,6 +295,11 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  mf_spmv; the assembled tangent's memory is released.  Same results
  *                                                  (nonlinear_elasticity.cc:1044-1087, 1153-1191); excludes
  *                                                  "solver_type" 1, "precond_storage" 32 and matrix export
+ *  mf_diag_lag          0 | 1                      "fine_level" 1: diagonal blocks (smoother's D, Jacobi diagonal) at     -
+ *                                                  every tangent | at the first tangent of a time step, kept over its
+ *                                                  Newton iterations (what bench.py and the executable set)
+ *  mf_point_slots       1 | 0                      "fine_level" 1: the point pass (records + residual) over all cells in  -
+ *                                                  one launch, residual through the product's slots | eight colour launches
  *  smoother_operator    2 | 1 | 0                  fine-level products of the smoother on 3D Q2 slabs > 100 k nodes:    MI_EBE
  *                                                  matrix-free from the assembly's point records | stored element
  *                                                  tangents | assembled matrix
@@ -321,7 +327,11 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  Chronopoulos-Gear form): on teams of several slabs | never | always
  *  cg_speculate_margin  0 | 1..16                  expected iterations of a solve left to polled ones (0: two)          -
  *  mg_dist_nodes        -1 | n                     node count from which the first coarsened multigrid level of a team   MI_MG_DIST_NODES
- *                                                  is cut into slabs of its own (default 65,536; set before "precond")
+ *                                                  is cut into slabs of its own (default 65,536); an existing hierarchy
+ *                                                  is rebuilt
+ *  mg_coarsest          4 | 1..64                  cells per direction at which the multigrid coarsening stops            MI_MG_COARSEST
+ *  mg_dense             1 | 0                      exact dense solve on the coarsest level (<= 384 dofs) | polynomial     MI_MG_DENSE
+ *                                                  (both keys rebuild an existing hierarchy)
  *  mg_restrict_fuse     1 | 0                      the restriction takes the coarse level's first smoother step | a     MI_MG_RESTRICT_FUSE
  *                                                  launch of its own (same bits)
  *  KERNEL A/B (timing, tests)
@@ -334,14 +344,15 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *  small_cg             1 | 0                      matrices <= 1 MiB: whole Jacobi-PCG in one launch | three launches   MI_SMALL_CG
  *                                                  per iteration
  *  asm_variant          0 | 9 | 1,2 | 3 | 4-8      3D Q2 element kernel: sum factorised | node-pair form | its chunk    -
- *                                                  sizes | the sum-factorised kernel as of round 4 | round-5 A/B
- *                                                  combinations (pipelined contraction, prologue priority, parts of
- *                                                  the default alone; profiles/r05/asm_ab_*.txt)
+ *                                                  sizes | experiments build only: the sum-factorised kernel as of
+ *                                                  round 4 | round-5 A/B combinations (profiles/r05/asm_ab_*.txt)
+ *  asm_split            0 | 1 | 2                  experiments build only: the tangent as point pass + tangent kernel    -
+ *                                                  from the point records (profiles/r06/asm_split_ab_n59.txt: slower)
  *  mg_fuse              1 | 0 | 2                  smoother update fused into the product on small levels | never |     MI_MG_FUSE
  *                                                  always
  *  mg_scale_lmax_percent 10..400                   tests: spoil the eigenvalue estimates once                           -
  *
- * Further environment switches (read at creation; diagnostics): MI_MG_NU, MI_MG_NU_COARSE, MI_MG_RATIO, MI_MG_KIND,
+ * Further switches of the experiments build only (read at creation; diagnostics): MI_MG_NU, MI_MG_NU_COARSE, MI_MG_RATIO, MI_MG_KIND,
  * MI_MG_BLOCK, MI_MG_THREE_TERM, MI_MG_COARSEST, MI_MG_DENSE, MI_MG_FACTOR, MI_MG_SAFETY, MI_MG_POWER_ITS,
  * MI_MG_COARSE_DEGREE, MI_MG_COARSE_RATIO, MI_MG_FUSE_MAX_NODES, MI_MG_VERBOSE (multigrid parameters);
  * MI_MF_XCD (XCD-aware cell order of mf_spmv), MI_ASM_CELL_LATTICE, MI_ASM_STAMPS / MI_MF_STAMPS / MI_MF_DBG (phase stamps
