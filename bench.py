@@ -633,10 +633,12 @@ def main():
             else "unassembled symmetric element tangents (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 1
             else "assembled sliced-ELL matrix")
         out["config"]["ms_smoother_fine_product"] = tm["spmv_precond"][0] / max(tm["spmv_precond"][1], 1)
-        if args.cg_operator == "element" and ebe:
-            # A/B run: the CG's product is eight launches of the unassembled form too; quote it on those bytes
+        if (args.cg_operator == "element" or args.fine_level == "matrix-free") and ebe:
+            # A/B run / matrix-free fine level: the CG's product is the unassembled form too; quote it on those bytes
             cgp = out["roofline"]
-            cgp["kernel"] = "the CG's q = K p as eight launches of the smoother's unassembled product + a separate p.q reduction (A/B option)"
+            cgp["kernel"] = ("the CG's q = K p as mf_spmv (one launch over all cells) + mf_gather_dot (slot sum with the partials of p.q): "
+                             "the matrix-free fine level" if args.fine_level == "matrix-free" else
+                             "the CG's q = K p in the smoother's unassembled form + a separate p.q reduction (A/B option)")
             cgp["bytes_per_launch"] = ebe_bytes
             cgp["algorithmic_GB_per_launch"] = ebe_bytes / 1e9
             cgp["achieved"] = ebe_bytes / (spmv_avg_ms * 1e-3) / 1e9 if spmv_n else 0.0
@@ -696,7 +698,7 @@ def main():
             "GB_per_s": step_bytes / 1e9 / (ms_step * 1e-3), "frac": step_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
             "ms_fine_products_precond_per_step": tm["spmv_precond"][0] / args.steps,
             "ms_fine_products_cg_per_step": spmv_ms / args.steps}
-        if world == 1 and args.slabs == 1:
+        if world == 1 and args.slabs == 1 and args.fine_level == "assembled":
             # streaming calibration in the SAME process: a pure read of the 8*nnz-byte block-CSR value array (the box's
             # achievable HBM ceiling; boxes of the pool differ on the gather-heavy product, not on this kernel)
             G.set_tuning("spmv_variant", 13)

@@ -792,6 +792,7 @@ namespace mi_detail
     // matrix-free fine level: the point pass over ALL cells in one launch (residual into the cells' slots, summed per node in
     // processing order: the product's slots and its order), then the Neumann faces colour by colour on the summed vector
     const bool one_launch = c->mf_fine && c->mf_point_slots && c->d_mf_yc;
+    const bool faces_one_launch = c->face_slots && c->n_fn > 0;
     if (one_launch)
       {
         p.lat        = c->lat; // node ids by arithmetic, as mf_spmv
@@ -811,8 +812,16 @@ namespace mi_detail
           return fail(c, MI_EINVAL, "no assembly kernel for dim=%d degree=%d", c->dim, c->degree);
         const int fb = int(c->mesh.iface_colour_begin[col]);
         const int fc = int(c->mesh.iface_colour_begin[col + 1]) - fb;
-        if (mi::launch_neumann_faces(c->dim, c->degree, p, c->d_faces, fb, fc, c->stream))
+        if (!faces_one_launch && mi::launch_neumann_faces(c->dim, c->degree, p, c->d_faces, fb, fc, c->stream))
           return fail(c, MI_EINVAL, "no face kernel for dim=%d degree=%d", c->dim, c->degree);
+      }
+    if (faces_one_launch) // the Neumann term of ALL interface faces, then added to the summed vector node by node in entry order
+      {
+        p.face_slots = c->d_face_slots;
+        if (mi::launch_neumann_faces(c->dim, c->degree, p, c->d_faces, 0, int(c->mesh.iface_faces.size()), c->stream))
+          return fail(c, MI_EINVAL, "no face kernel for dim=%d degree=%d", c->dim, c->degree);
+        mi::launch_neumann_gather(c->dim, c->d_face_slots, c->d_fn_ids, c->d_fn_start, c->d_fn_src, c->d_cmask,
+                                  c->vec(MI_V_SYSTEM_RHS), c->n_fn, c->stream);
       }
     toc(c0, t0);
     if (residual_only)
@@ -1426,7 +1435,7 @@ namespace mi_detail
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
                     c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_qrec32, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_lat_rows,
-                    c->d_diag_blk, c->d_diag_slots, c->d_diagpos_mf,
+                    c->d_diag_blk, c->d_diag_slots, c->d_diagpos_mf, c->d_face_slots, c->d_fn_ids, c->d_fn_start, c->d_fn_src,
                     c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
                     c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
                     c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};
@@ -1520,6 +1529,39 @@ namespace mi_detail
           f.push_back(x.face);
         }
       UP(c->d_faces, f)
+      // per interface node: which (entry, local node) pairs contribute, in entry order (neumann_gather)
+      const int np1 = m.np1, npc = m.npc, dim = m.dim, p = m.p;
+      std::vector<std::pair<int32_t, int32_t>> pairs; // (node, entry * npc + a)
+      for (size_t e = 0; e < m.iface_faces.size(); ++e)
+        for (int a = 0; a < npc; ++a)
+          {
+            const int ai[3] = {a % np1, (a / np1) % np1, dim == 3 ? a / (np1 * np1) : 0};
+            bool      on = false;
+            for (int fc = 0; fc < 2 * dim; ++fc)
+              if ((m.iface_faces[e].face >> fc) & 1)
+                on = on || ai[fc >> 1] == ((fc & 1) ? p : 0);
+            if (on)
+              pairs.push_back({m.conn[size_t(m.iface_faces[e].cell) * npc + a], int32_t(e * npc + a)});
+          }
+      std::stable_sort(pairs.begin(), pairs.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+      std::vector<int32_t> ids, start(1, 0), src;
+      for (size_t k = 0; k < pairs.size(); ++k)
+        {
+          if (k == 0 || pairs[k].first != pairs[k - 1].first)
+            {
+              if (k)
+                start.push_back(int32_t(k));
+              ids.push_back(pairs[k].first);
+            }
+          src.push_back(pairs[k].second);
+        }
+      if (!pairs.empty())
+        start.push_back(int32_t(pairs.size()));
+      c->n_fn = int(ids.size());
+      UP(c->d_fn_ids, ids)
+      UP(c->d_fn_start, start)
+      UP(c->d_fn_src, src)
+      HIPCHK(c, hipMalloc((void **)&c->d_face_slots, std::max<size_t>(1, m.iface_faces.size() * size_t(npc) * dim) * sizeof(double)));
     }
     UP(c->d_tab, c->tab.packed())
     UP(c->d_sell_perm, m.sell_perm)
@@ -2682,6 +2724,11 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
                          (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
                          (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
         return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
+      if (k == "face_slots" && (value == 0 || value == 1)) // Neumann faces: one launch + gather (1) | colour by colour (0)
+        {
+          m->face_slots = value;
+          continue;
+        }
       if (k == "mf_point_slots" && (value == 0 || value == 1)) // matrix-free fine level: point pass in one launch (1) | eight colour launches
         {
           m->mf_point_slots = value;

@@ -114,6 +114,12 @@ struct mi_ctx
   // device memory
   int32_t  *d_conn = nullptr, *d_rowptr = nullptr, *d_col = nullptr, *d_diagpos = nullptr, *d_iface_nodes = nullptr,
           *d_faces = nullptr, *d_flags = nullptr;
+  // Neumann faces in one launch (round 6): the cells' face contributions [entries][npc * dim] and, per interface node, the
+  // list of (entry, local node) pairs that touch it (CSR over d_fn_ids), in entry order
+  double   *d_face_slots = nullptr;
+  int32_t  *d_fn_ids = nullptr, *d_fn_start = nullptr, *d_fn_src = nullptr;
+  int       n_fn = 0;
+  int       face_slots = 1; // tuning "face_slots": 1 one launch + gather (default), 0 eight colour launches
   int32_t  *d_rowinfo = nullptr; // [nnodes][2] where the row of a node starts in d_vals and its g-stride (mi::HostMesh::rowinfo)
   uint8_t  *d_rowwx = nullptr;   // [nnodes] x-width of the row's column box
   int32_t  *d_sell_wx = nullptr; // [nslices]

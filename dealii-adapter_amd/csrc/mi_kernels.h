@@ -75,6 +75,7 @@ namespace mi
     double         *ke;     // optional (3D Q2): the cell's masked element tangent, lower-triangle node-pair blocks, stored
                             // [cell][e = 0..8][block = a(a+1)/2 + b] -- the multigrid smoother's operator (see ebe_spmv)
     CellLattice     lat;    // 3D Q2: node ids by arithmetic (ncol == 0: read conn)
+    double         *face_slots; // Neumann faces in one launch: [entries][npc * dim] (see neumann_faces); null: colour by colour
     double         *res_slots; // matrix-free fine level, point pass in one launch: [nslots][3] the cells' residual entries ...
     const int32_t  *slot_dst;  // ... at slot_dst[cell][27] (MfParams::dst); xcd_chunk: cells per XCD of that launch
     int32_t         xcd_chunk;
@@ -249,6 +250,8 @@ namespace mi
   int  launch_assemble_cells(int dim, int degree, const AsmParams &p, hipStream_t s);
   int  launch_neumann_faces(int dim, int degree, const AsmParams &p, const int32_t *faces, int face_begin,
                             int face_count, hipStream_t s);
+  void launch_neumann_gather(int dim, const double *slots, const int32_t *node_ids, const int32_t *start, const int32_t *src,
+                             const uint8_t *cmask, double *rhs, int nnodes_if, hipStream_t s);
   void launch_spmv(int dim, const SpmvParams &p, int grid, hipStream_t s, int variant, int maxrow);
   void launch_sell_spmv(int dim, const SellParams &p, int grid, hipStream_t s, int unroll);
   void set_next_sell_launch_events(hipEvent_t start, hipEvent_t stop); // profiling: bracket exactly the next launch

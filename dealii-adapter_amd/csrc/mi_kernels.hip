@@ -1953,8 +1953,14 @@ namespace mi
     __shared__ double s_u[NPC * 3], s_t[NPC * 3], s_verts[NV * DIM];
     __shared__ int    s_conn[NPC];
     __shared__ double s_fq[NQF * 4]; // per face QP: referential traction (3) and unused
+    // AsmParams::face_slots (round 6): ALL interface faces in one launch -- a cell's contributions (its faces summed in the
+    // order below) go to the cell's slot [entry][NPC * DIM] instead of being added to system_rhs colour by colour;
+    // neumann_gather adds the slots of a node in entry order (deterministic, two launches instead of eight per assembly)
+    __shared__ double s_acc[NPC * DIM];
     const int     tid  = threadIdx.x;
     const int32_t cell = faces[2 * (face_begin + blockIdx.x)], fmask = faces[2 * (face_begin + blockIdx.x) + 1];
+    for (int i = tid; i < NPC * DIM; i += 64)
+      s_acc[i] = 0.0;
     for (int i = tid; i < NQ1 * NP1; i += 64)
       {
         s_N1[i]  = prm.tab1d[i];
@@ -2185,12 +2191,40 @@ namespace mi
               N *= s_N1[f2 * NP1 + ai[ax1]];
             s += N * s_fq[fq * 4 + c];
           }
+        if (prm.face_slots)
+          {
+            s_acc[i] += s; // (this thread alone touches entry i)
+            continue;
+          }
         const int32_t A = s_conn[a];
         if (!((prm.cmask[A] >> c) & 1))
           prm.rhs[int64_t(A) * DIM + c] += s;
       }
     __syncthreads(); // s_fq is reused by the next face
       }
+    if (prm.face_slots)
+      for (int i = tid; i < NPC * DIM; i += 64)
+        prm.face_slots[int64_t(face_begin + blockIdx.x) * (NPC * DIM) + i] = s_acc[i];
+  }
+
+  // system_rhs += the interface faces' contributions, node by node in entry order (see neumann_faces, face_slots): one
+  // thread per (interface node, component); src[j] = entry * NPC + local node of the j-th contribution of the node
+  template <int DIM>
+  __global__ __launch_bounds__(256) void neumann_gather(const double *__restrict__ slots, const int32_t *__restrict__ node_ids,
+                                                        const int32_t *__restrict__ start, const int32_t *__restrict__ src,
+                                                        const uint8_t *__restrict__ cmask, double *rhs, int nnodes_if)
+  {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nnodes_if * DIM)
+      return;
+    const int k = t / DIM, c = t - k * DIM;
+    const int32_t A = node_ids[k];
+    if ((cmask[A] >> c) & 1)
+      return;
+    double s = 0.0;
+    for (int32_t j = start[k]; j < start[k + 1]; ++j)
+      s += slots[int64_t(src[j]) * DIM + c];
+    rhs[int64_t(A) * DIM + c] += s;
   }
 
   // ------------------------------------------------------------------ row-per-wave product (cross-check variant)
@@ -6014,6 +6048,18 @@ namespace mi
     MI_NF(2, 4)
 #undef MI_NF
     return -1;
+  }
+
+  void launch_neumann_gather(int dim, const double *slots, const int32_t *node_ids, const int32_t *start, const int32_t *src,
+                             const uint8_t *cmask, double *rhs, int nnodes_if, hipStream_t s)
+  {
+    if (nnodes_if <= 0)
+      return;
+    const int grid = (nnodes_if * dim + 255) / 256;
+    if (dim == 3)
+      hipLaunchKernelGGL((neumann_gather<3>), dim3(grid), dim3(256), 0, s, slots, node_ids, start, src, cmask, rhs, nnodes_if);
+    else
+      hipLaunchKernelGGL((neumann_gather<2>), dim3(grid), dim3(256), 0, s, slots, node_ids, start, src, cmask, rhs, nnodes_if);
   }
 
   template <int D>

@@ -145,6 +145,52 @@ namespace mi_detail
         }
     }
 
+    // Would build_transfer accept the slabs of EVERY rank when the coarser level is cut along `induced`?  The decision to
+    // distribute that level must be the same on all ranks (each builds its own hierarchy; a rank that fell back to the
+    // replicated level while the others did not would pair up the wrong collectives), so it is taken from the cuts alone, for
+    // all ranks, with build_transfer's own index arithmetic along the cut direction: every OWNED finer plane prolongates
+    // from and restricts into the coarse slab's box, and a coarse node's state is served without a plane beyond the finer
+    // slab.  (explicit Team::cuts or lattices that do not nest can break the cover; the level then stays
+    // replicated instead of failing the multigrid setup.)
+    bool induced_cuts_cover(int dim, const mi_mesh_desc &g, const int *fine_reps, const int *fine_cuts, const int *coarse_reps,
+                            const std::vector<int> &induced, int size)
+    {
+      try
+        {
+          for (int r = 0; r < size; ++r)
+            {
+              const mi::SlabPartition F = mi::make_slab_partition(dim, 1, fine_reps, g.lo, g.hi, g.face_role, r, size, fine_cuts);
+              const mi::SlabPartition C = mi::make_slab_partition(dim, 1, coarse_reps, g.lo, g.hi, g.face_role, r, size, induced.data());
+              const int nf_loc = int(F.nnodes_local / F.plane_nodes), zoff = int(F.node_offset / F.plane_nodes),
+                        nf = int(F.nnodes_global / F.plane_nodes), own_lo = int(F.own_begin / F.plane_nodes),
+                        own_hi = int(F.own_end / F.plane_nodes);
+              const int nc = int(C.nnodes_local / C.plane_nodes), coff = int(C.node_offset / C.plane_nodes),
+                        nc_g = int(C.nnodes_global / C.plane_nodes);
+              std::vector<int32_t> gi0;
+              std::vector<double>  gw;
+              interp_table(nf, nc_g, gi0, gw);
+              for (int k = own_lo; k < own_hi; ++k)
+                {
+                  const int c0 = gi0[size_t(k + zoff)] - coff;
+                  if (c0 < 0 || c0 + (gw[size_t(k + zoff)] != 0.0 ? 1 : 0) >= nc)
+                    return false;
+                }
+              interp_table(nc_g, nf, gi0, gw);
+              for (int t = 0; t < nc; ++t)
+                {
+                  const int kl = gi0[size_t(t + coff)] - zoff;
+                  if (kl >= own_lo && kl < own_hi && kl + 1 >= nf_loc && gw[size_t(t + coff)] != 0.0)
+                    return false;
+                }
+            }
+        }
+      catch (const std::exception &)
+        {
+          return false;
+        }
+      return true;
+    }
+
     // Transfer tables between a fine context and a coarse GLOBAL context.  The fine context may be a slab: along the
     // decomposed (last) direction its local lattice index k corresponds to the global index k + zoff, and it owns
     // the local planes [own_lo, own_hi).  Ownership keeps sums over slabs free of double counting:
@@ -502,6 +548,7 @@ namespace mi_detail
     for (int guard = 0; guard < 24; ++guard)
       {
         const int prev_layers = reps[dim - 1];
+        const int prev_reps[3] = {reps[0], reps[1], reps[2]};
         bool      coarsened   = false;
         if (p > 1)
           p = 1;
@@ -553,6 +600,8 @@ namespace mi_detail
                 induced.push_back(r == size ? Lc : int((int64_t(F) * Lc) / Lf));
                 ok = r == 0 || induced[size_t(r)] > induced[size_t(r - 1)];
               }
+            if (ok) // (the same answer on every rank: from the cuts alone, for all ranks)
+              ok = induced_cuts_cover(dim, g, prev_reps, c->team->cuts.empty() ? nullptr : c->team->cuts.data(), reps, induced, size);
             if (!ok)
               induced.clear();
           }

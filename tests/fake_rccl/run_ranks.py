@@ -49,6 +49,8 @@ def scenario(G, M, kw, log):
     ids, _ = G.interface()
     out = {}
     G.set_tuning("halo_overlap", kw.get("overlap", 1))
+    if kw.get("fine"):  # no assembled fine tangent: every product of the level on mf_spmv, the CG's around its halo exchange
+        G.set_tuning("fine_level", 1)
     if kw.get("dist_nodes", -1) >= 0:  # shape of the hierarchy: before "precond" 1 builds it
         G.set_tuning("mg_dist_nodes", kw["dist_nodes"])
     for precond in (0, 1):
@@ -96,6 +98,7 @@ def main():
     overlap = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     ebe = int(sys.argv[6]) if len(sys.argv) > 6 else 0
     dist_nodes = int(sys.argv[7]) if len(sys.argv) > 7 else -1  # tuning "mg_dist_nodes" (-1: the library's default)
+    fine = int(sys.argv[8]) if len(sys.argv) > 8 else 0           # tuning "fine_level" (1: the fine level matrix-free, 3D Q2)
     M = load()
     hi = tuple(0.1 * r for r in reps)
     roles = [1, 7, 7, 7, 8, 7]
@@ -106,7 +109,7 @@ def main():
     def rank_main(r):
         try:
             G = M.Context(rank=r, world=world, unique_id=uid, **common)
-            results[r] = scenario(G, M, dict(overlap=overlap, ebe=ebe, rank=r, dist_nodes=dist_nodes), None)
+            results[r] = scenario(G, M, dict(overlap=overlap, ebe=ebe, rank=r, dist_nodes=dist_nodes, fine=fine), None)
             G.close()
         except BaseException as e:  # noqa: BLE001 -- reported to the parent test
             errors.append("rank %d: %r" % (r, e))
@@ -119,8 +122,8 @@ def main():
     if errors or any(t.is_alive() for t in threads):
         print(json.dumps({"ok": False, "errors": errors, "hung": [t.is_alive() for t in threads]}), flush=True)
         os._exit(1)
-    single = scenario(M.Context(**common), M, dict(ebe=ebe, dist_nodes=dist_nodes), None)
-    emu = scenario(M.Context(slabs=world, **common), M, dict(ebe=ebe, dist_nodes=dist_nodes), None)
+    single = scenario(M.Context(**common), M, dict(ebe=ebe, dist_nodes=dist_nodes, fine=fine), None)
+    emu = scenario(M.Context(slabs=world, **common), M, dict(ebe=ebe, dist_nodes=dist_nodes, fine=fine), None)
 
     def rel(a, b):
         return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(np.abs(np.asarray(b)).max(), 1e-300))

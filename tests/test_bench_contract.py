@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = pytest.mark.gpu
+gpu = pytest.mark.gpu
 
 
 def _run(args):
@@ -20,6 +20,7 @@ def _run(args):
     return json.loads(lines[0])
 
 
+@gpu
 def test_bench_json_line_contract():
     d = _run(["--cells", "8", "--steps", "2", "--warmup", "1", "--cpu-cells", "3"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -45,8 +46,20 @@ def test_bench_json_line_contract():
     w = r["whole_step"]
     assert w["fine_level_products_per_step"] >= d["config"]["cg_iterations_per_step"] and 0 < w["frac"] < 1
     assert d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 0 and d["config"]["team_size"] == 1
+    # round 6: the further measurements run over the headline's own step window and say so; the fine level matrix-free end
+    # to end is one of them (same Newton / CG iteration counts within one per step)
+    for k, v in d["config"].items():
+        if k.startswith("with_"):
+            assert (v["steps"], v["warmup"]) == (d["steps"], d["warmup"]) and "window" in v, k
+    mf = d["config"]["with_matrix_free_fine_level"]
+    assert mf["newton_iterations_per_step"] == d["config"]["newton_iterations_per_step"]
+    assert abs(mf["cg_iterations_per_step"] - d["config"]["cg_iterations_per_step"]) <= 1.0
+    assert mf["diagonal_block_passes_per_step"] == 1.0 and mf["tangent_assemblies_per_step"] >= 1.0
+    assert d["config"]["with_matrix_free_fine_level_diagonal_every_tangent"]["diagonal_block_passes_per_step"] == mf["tangent_assemblies_per_step"]
+    assert d["config"]["fine_level"] == "assembled" and d["config"]["per_rank_ms_per_step"] == [d["ms_per_step"]]
 
 
+@gpu
 def test_bench_gpus_2_as_a_bare_command():
     """`python bench.py --gpus N` is what the driver runs: with no WORLD_SIZE in the environment bench.py starts the
     N ranks itself (child processes, before anything touches the GPU) and relays rank 0's single JSON line.  On the
@@ -66,6 +79,7 @@ def test_bench_gpus_2_as_a_bare_command():
         assert out.returncode != 0 and "visible GPUs" in out.stderr
 
 
+@gpu
 def test_bench_options_and_smoke():
     d = _run(["--cells", "6", "--steps", "1", "--warmup", "1", "--cpu-cells", "0", "--slabs", "2", "--scaling", "strong",
               "--precond", "jacobi"])
@@ -78,6 +92,7 @@ def test_bench_options_and_smoke():
     assert out.returncode == 0 and "smoke ok" in out.stdout, out.stderr[-2000:]
 
 
+@gpu
 def test_bench_under_the_launcher_two_ranks_control_plane():
     """the driver starts N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.  A
     one-GPU box cannot host two RCCL ranks, so `--no-rccl` lets both ranks run their own copy of the problem: this
@@ -98,3 +113,15 @@ def test_bench_under_the_launcher_two_ranks_control_plane():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "replicas" and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * d["config"]["n_dofs"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+
+
+def test_launch_ranks_has_a_wall_clock_limit():
+    """verdict r05: a hung RCCL rendezvous on the first real multi-GPU run must not hang the bench.  `python bench.py --gpus N`
+    starts its ranks as a process group of their own and waits MI_BENCH_RANKS_TIMEOUT_S for them; past the limit the group is
+    ended and the bench exits 124.  (Runs without a GPU: with a limit of half a second the ranks are still importing.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MI_BENCH_RANKS_TIMEOUT_S"] = "0.5"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--no-rccl", "--cells", "6", "--steps", "1",
+                          "--warmup", "0", "--cpu-cells", "0"], cwd=ROOT, capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 124, (out.returncode, out.stderr[-500:])
+    assert "did not finish within" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]

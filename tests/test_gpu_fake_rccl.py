@@ -46,9 +46,18 @@ def test_rank_threads_with_a_distributed_first_coarsened_level(fake_lib, world, 
     _run_ranks(world, dim, p, reps, 1, 0, 0)
 
 
-def _run_ranks(world, dim, p, reps, overlap, ebe, dist_nodes):
+@pytest.mark.parametrize("world,reps,overlap", [(3, "3,3,7", 1), (2, "4,3,6", 0), (3, "7,2,3", 1)])
+def test_rank_threads_with_the_fine_level_matrix_free(fake_lib, world, reps, overlap):
+    """round 6, tuning "fine_level" 1 through the RCCL branch: no assembled fine tangent on any rank -- the CG's product is
+    mf_spmv in two launches around the ghost-plane send/recv (inner cell layers while the planes travel) + the gather with the
+    partials of p.q, the tangent pass writes records / residual / diagonal blocks of the local cells (ghost layer included);
+    every rank the same bits, the emulated slabs to 1e-9, one GPU to the linear tolerance, iteration counts within one"""
+    _run_ranks(world, 3, 2, reps, overlap, 2, -1, fine=1)
+
+
+def _run_ranks(world, dim, p, reps, overlap, ebe, dist_nodes, fine=0):
     out = subprocess.run([sys.executable, os.path.join(FAKE, "run_ranks.py"), str(world), str(dim), str(p), reps, str(overlap),
-                          str(ebe), str(dist_nodes)], capture_output=True, text=True, timeout=900)
+                          str(ebe), str(dist_nodes), str(fine)], capture_output=True, text=True, timeout=900)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert out.returncode == 0 and lines, (out.stdout[-2000:], out.stderr[-3000:])
     r = json.loads(lines[-1])

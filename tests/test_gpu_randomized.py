@@ -88,6 +88,74 @@ def test_random_configuration_newmark_step(seed):
         assert np.abs(G.get(k) - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-300), (seed, k)
 
 
+def _q2_3d_seeds(count, start=300):
+    """seeds whose random configuration is a 3D Q2 mesh (where the matrix-free fine level exists)"""
+    out, seed = [], start
+    while len(out) < count:
+        _, dim, p, *_ = _case(seed)
+        if dim == 3 and p == 2:
+            out.append(seed)
+        seed += 1
+    return out
+
+
+@pytest.mark.parametrize("seed", _q2_3d_seeds(12))
+def test_random_configuration_matrix_free_fine_level(seed):
+    """round 6: the same sweep over random 3D Q2 configurations (boxes of random shape, distorted cells, random boundary
+    roles incl. the z-clamp, random material / Newmark parameters / body force, 1-3 slabs) with the fine level matrix-free
+    (tuning "fine_level" 1): residual and operator action against the oracle's assembled system to 1e-11, the nodes' diagonal
+    blocks (mf_diag) to 1e-11, then one Newmark step against the oracle's (multigrid or Jacobi by the seed) to 1e-7"""
+    rng, dim, p, reps, lo, hi, roles, kw, perturb, slabs, h = _case(seed)
+    P = O.Problem(O.make_desc(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, **kw), perturb)
+    G = M.Context(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, perturb=perturb, slabs=slabs, **kw)
+    G.set_tuning("precond", seed % 2)
+    G.set_tuning("fine_level", 1)
+    G.set_tuning("mf_diag_lag", (seed // 2) % 2)
+    ids, _ = G.interface()
+    free = ~P.constrained
+    hp = h / p
+    state = {O.V_U: 0.02 * hp * rng.standard_normal(P.n) * free, O.V_DELTA: 0.01 * hp * rng.standard_normal(P.n) * free,
+             O.V_V_OLD: rng.standard_normal(P.n), O.V_A_OLD: 10 * rng.standard_normal(P.n)}
+    for k, v in state.items():
+        P.vec(k)[:] = v
+        G.set(k, v)
+    t = kw["mu"] * 1e-3 * rng.standard_normal((len(ids), dim))
+    P.set_interface_traction(t)
+    G.set_interface_traction(t)
+    P.update_acceleration()
+    P.assemble()
+    G.newton_begin_step()  # ("mf_diag_lag": a new step forms the diagonal blocks)
+    for k in (O.V_DELTA,):
+        G.set(k, state[k])
+    G.update_acceleration()
+    rn = G.assemble()
+    r_o = P.vec(O.V_RHS)
+    scale = max(np.abs(r_o).max(), 1e-300)
+    tag = "seed %d: reps %s slabs %d" % (seed, reps, slabs)
+    assert np.abs(G.get(M.V_RHS) - r_o).max() / scale < 1e-11, tag
+    assert abs(rn - P.residual_norm()) <= 1e-11 * max(P.residual_norm(), scale)
+    K = P.csr()
+    x = rng.standard_normal(P.n)
+    y_o = K @ x
+    assert np.abs(G.spmv(x) - y_o).max() / np.abs(y_o).max() < 1e-11, tag
+    nn, base = P.n // 3, np.arange(P.n // 3) * 3
+    D_o = np.stack([np.stack([np.asarray(K[base + i, base + j]).ravel() for j in range(3)], -1) for i in range(3)], -2)
+    assert np.abs(G.diagonal_blocks() - D_o).max() / np.abs(D_o).max() < 1e-11, tag
+    # a whole step from rest
+    P2 = O.Problem(O.make_desc(dim=dim, degree=p, reps=reps, lo=lo, hi=hi, face_role=roles, **kw), perturb)
+    for k in (M.V_U, M.V_DELTA, M.V_V_OLD, M.V_A_OLD, M.V_U_OLD, M.V_V, M.V_A, M.V_NEWTON):
+        G.set(k, np.zeros(G.n))
+    t = kw["mu"] * 2e-4 * rng.standard_normal((len(ids), dim))
+    P2.set_interface_traction(t)
+    G.set_interface_traction(t)
+    rc_o, info_o = P2.newmark_step(O.SOLVER_DIRECT if P2.n < 3000 else O.SOLVER_CG_SSOR, tol_lin=1e-13, max_it_mult=4.0)
+    rc, info = G.newmark_step(tol_lin=1e-12, max_it_mult=4.0)
+    assert rc_o == 0 and rc == 0 and info.converged == 1 and info.newton_iterations == info_o.newton_iterations, tag
+    for k in (M.V_U, M.V_V, M.V_A):
+        ref = P2.vec(k)
+        assert np.abs(G.get(k) - ref).max() <= 1e-7 * max(np.abs(ref).max(), 1e-300), (tag, k)
+
+
 @pytest.mark.parametrize("seed", range(100, 116))
 def test_random_linear_model(seed):
     """the linear theta-model on random configurations (incl. slabs): 3 steps with random coupling data, alternating

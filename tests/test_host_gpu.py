@@ -286,6 +286,11 @@ def test_executable_nonlinear_3d(tmp_path, name, windows, traction):
         assert a[:ia] == b[:ib]  # header and points
         ja, jb = (next(i for i, l in enumerate(t) if l.startswith("POINT_DATA")) for t in (a, b))
         assert a[ja:] == b[jb:]  # fields
+        # the executable's switch for the matrix-free fine level (tuning "fine_level" 1 + "mf_diag_lag" 1): same windows
+        mf = tmp_path / "mf"
+        mf.mkdir()
+        _, rows_mf = _run_case(name, "elasticity3d", mf, env={"MI_FINE_LEVEL": "1"})
+        _check_rows(rows_mf, exp, 3)
 
 
 def test_executable_on_emulated_slabs(tmp_path):
