@@ -25,7 +25,7 @@ for MODE in assembled matrix-free; do
   python3 tools/pmc_bench_reduce.py "$OUT/pmc_$TAG" > "$OUT/pmc_bench_${TAG}_n59.json"; rm -rf "$OUT/pmc_$TAG"
 done
 timeout 1500 python bench.py --steps 20 --warmup 5 2>"$OUT/bench_plain.err" | tail -1 > "$OUT/bench_plain_same_box_n59.json"
-timeout 600 python bench.py --steps 20 --warmup 5 --cpu-cells 0 --no-pmc --no-sides --fine-level matrix-free 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_matrix_free_fine_level.json"
+timeout 600 python bench.py --steps 20 --warmup 5 --cpu-cells 0 --no-sides --fine-level matrix-free 2>/dev/null | tail -1 > "$OUT/bench_plain_same_box_matrix_free_fine_level.json"
 timeout 600 python bench.py --steps 5 --warmup 2 --cpu-cells 0 --no-pmc --no-sides --cells 34 2>/dev/null | tail -1 > "$OUT/bench_n34_config3.json"
 timeout 600 python bench.py --steps 5 --warmup 2 --cpu-cells 0 --no-pmc --no-sides --cells 34 --fine-level matrix-free 2>/dev/null | tail -1 > "$OUT/bench_n34_config3_matrix_free_fine_level.json"
 timeout 600 python bench.py --cells 120 --steps 3 --warmup 1 --cpu-cells 0 --no-pmc --no-sides 2>/dev/null | tail -1 > "$OUT/bench_n120_42M_dofs.json"
