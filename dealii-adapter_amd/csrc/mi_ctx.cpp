@@ -223,6 +223,7 @@ namespace mi_detail
     p.qrec    = c->d_qrec;
     p.qrec32  = (c->d_qrec && c->smoother_precision == 32) ? c->d_qrec32 : nullptr;
     p.cellbox = c->d_cellbox;
+    p.box_geometry = c->asm_box_geometry;
     p.from_records = c->d_qrec ? c->asm_split : 0;
     if (p.from_records) // both kernels of the pair take the node ids by lattice arithmetic (as mf_spmv)
       p.lat = c->lat;
@@ -2724,6 +2725,11 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
                          (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
                          (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
         return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
+      if (k == "asm_box_geometry" && (value == 0 || value == 1)) // assemble_q2sf on meshes of boxes: geometry from 1/h | the trilinear map
+        {
+          m->asm_box_geometry = value;
+          continue;
+        }
       if (k == "face_slots" && (value == 0 || value == 1)) // Neumann faces: one launch + gather (1) | colour by colour (0)
         {
           m->face_slots = value;

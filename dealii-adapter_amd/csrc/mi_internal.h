@@ -241,6 +241,7 @@ struct mi_ctx
   bool                  mg_stale = true; // the coarse operators belong to an older state than the fine tangent
   bool                  mg_force = true; // rebuild them at the next solve (set at the start of every time step)
   int                   asm_variant = 0;
+  int                   asm_box_geometry = 1; // assemble_q2sf on a mesh of axis-parallel boxes: 1/h and the volume instead of the trilinear map
   int                   asm_split = 0;   // experiments build: 3D Q2 with point records: the tangent in two kernels (1 / 2; measured
                                          // slower than the fused kernel, profiles/r06/asm_split_ab_n59.txt)
   int                   mg_lag   = 1;    // 1: keep the coarse operators over the Newton iterations of one step

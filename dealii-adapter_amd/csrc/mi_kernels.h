@@ -80,6 +80,7 @@ namespace mi
     const int32_t  *slot_dst;  // ... at slot_dst[cell][27] (MfParams::dst); xcd_chunk: cells per XCD of that launch
     int32_t         xcd_chunk;
     const double   *cellbox;  // [ncells][4] = 1/hx, 1/hy, 1/hz, hx hy hz when every local cell is an axis-parallel box, else null
+    int32_t         box_geometry; // assemble_q2sf: take 1/h and the volume from cellbox where present (tuning "asm_box_geometry")
     int32_t         from_records; // 3D Q2, records present: tangent in two kernels -- point pass, then the tangent from its records
     int32_t         correct_face_F; // Neumann term: 0 (default) = the reference's pull-back with the deformation gradient of CELL
                                     // quadrature point fq (nonlinear_elasticity.cc:825-827), 1 = F at the

@@ -1211,27 +1211,56 @@ namespace mi
         MI_STAMPW(8, 0); // gradients at the points
         // ---- geometry, kinematics, material at this point (nonlinear_elasticity.cc:927-934)
         {
-          const double *__restrict__ cv = prm.cverts + cell * 24;
-          double verts[24], Jm[9], Ji[9], gu[9], Finv[9], J, Fq[9], Jmq, rJq;
+          double Ji[9], gu[9], Finv[9], J, Fq[9], Jmq, rJq, detJ;
+          if (prm.cellbox && prm.box_geometry) // every local cell an axis-parallel box (the reference's grids): 1/h and the volume,
+            {                                  // as mf_spmv takes them (round 6)
+              const double *__restrict__ cb = prm.cellbox + cell * 4;
 #pragma unroll
-          for (int k = 0; k < 24; ++k)
-            verts[k] = cv[k];
-          q1_jacobian<3>(verts, xiq, Jm);
-          const double detJ = det3x3(Jm);
-          inv3x3(Jm, detJ, Ji);
+              for (int k = 0; k < 9; ++k)
+                Ji[k] = 0.0;
+              Ji[0] = cb[0], Ji[4] = cb[1], Ji[8] = cb[2];
+              detJ  = cb[3];
 #pragma unroll
-          for (int i = 0; i < 3; ++i)
+              for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-              gu[i * 3 + j] = gxi[i][0] * Ji[0 * 3 + j] + gxi[i][1] * Ji[1 * 3 + j] + gxi[i][2] * Ji[2 * 3 + j];
+                for (int j = 0; j < 3; ++j)
+                  gu[i * 3 + j] = gxi[i][j] * Ji[j * 4];
+            }
+          else
+            {
+              const double *__restrict__ cv = prm.cverts + cell * 24;
+              double verts[24], Jm[9];
+#pragma unroll
+              for (int k = 0; k < 24; ++k)
+                verts[k] = cv[k];
+              q1_jacobian<3>(verts, xiq, Jm);
+              detJ = det3x3(Jm);
+              inv3x3(Jm, detJ, Ji);
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                  gu[i * 3 + j] = gxi[i][0] * Ji[0 * 3 + j] + gxi[i][1] * Ji[1 * 3 + j] + gxi[i][2] * Ji[2 * 3 + j];
+            }
           neo_hooke_qp<3>(gu, prm.mu, prm.kappa, Finv, J, tau, tiso, cII, cS, Fq, Jmq, rJq);
           if (!(J > 0.0)) // inverted element (nonlinear_elasticity.cc:935 asserts det F > 0)
             *prm.inverted = 1.0;
+          if (prm.cellbox && prm.box_geometry)
+            {
+#pragma unroll
+              for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                  M[i * 3 + j] = Ji[i * 4] * Finv[i * 3 + j];
+            }
+          else
+            {
 #pragma unroll
           for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j)
               M[i * 3 + j] = Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+            }
           w = detJ * wq; // JxW of the reference configuration
           // (RES_ONLY with records: the tangent pass of the matrix-free fine level, round 6 -- the residual-only pass of
           // the Newton convergence check hands in no record pointer)

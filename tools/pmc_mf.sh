@@ -1,5 +1,6 @@
 #!/bin/bash
 # Counters of the matrix-free fine-level product (mf_spmv) at the headline size: bash tools/pmc_mf.sh [kernel-substring]
+# PMC_SCRIPT="tools/r6_mf_fine_check.py 59" bash tools/pmc_mf.sh "mf_diag<"   -- another kernel of another python script
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (it exports GRAFT_REPO_ROOT); refusing to run from an unknown directory}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 K=${1:-mf_spmv}
@@ -10,7 +11,7 @@ for C in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" "SQ_ACTIVE_IN
          "SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_LEVEL_WAVES GRBM_GUI_ACTIVE" "TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_32B_sum" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
          "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 tools/time_element_products.py 59 2 > $OUT/p$i.log 2>&1 || echo "pass $i ($C) failed"
+  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 ${PMC_SCRIPT:-tools/time_element_products.py 59 2} > $OUT/p$i.log 2>&1 || echo "pass $i ($C) failed"
 done
 python3 - "$K" <<'PY'
 import csv, glob, sys, json
