@@ -3321,7 +3321,10 @@ namespace mi
   __global__ __launch_bounds__(64, 3) void mf_diag(MfParams prm, double *__restrict__ slots6)
   {
     constexpr int NPC = 27;
-    __shared__ __attribute__((aligned(16))) double sF[64 * DG_NF];
+    // (the two halves of the points two doubles apart in bank space: a wave's broadcast read touches ONE address per half, and
+    // without the pad both land on the same banks -- 34 % of the LDS cycles were conflicts, profiles/r06/pmc_counters_mf_diag_n59.json)
+    constexpr int DG_HALF = 32 * DG_NF + 2;
+    __shared__ __attribute__((aligned(16))) double sF[2 * DG_HALF];
     __shared__ double sR[NPC * 6];
     const int     lane = threadIdx.x;
     int64_t       cell = blockIdx.x;
@@ -3375,7 +3378,7 @@ namespace mi
         }
       const double w  = detJ * wq;
       const double pv = tau[0] - tiso[0]; // kappa/2 (J^2 - 1)
-      double      *o  = sF + lane * DG_NF;
+      double      *o  = sF + (lane >> 5) * DG_HALF + (lane & 31) * DG_NF;
 #pragma unroll
       for (int k = 0; k < 9; ++k)
         o[k] = M[k];
@@ -3408,8 +3411,9 @@ namespace mi
         Sz[z] = prm.tab1d[(2 * h + z) * 3 + (act ? a3 : 0)];
         Dz[z] = prm.tab1d[12 + (2 * h + z) * 3 + (act ? a3 : 0)];
       }
-    double K[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // xx yy zz xy xz yz
-    const double *__restrict__ fb = sF + h * (32 * DG_NF);
+    double K[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; // xx yy zz xy xz yz (the diagonal as sum of g_i v_i: doubled, + the isotropic part, at the end)
+    double Kiso = 0.0;
+    const double *__restrict__ fb = sF + h * DG_HALF;
 #pragma unroll
     for (int z = 0; z < 2; ++z)
 #pragma unroll
@@ -3432,14 +3436,18 @@ namespace mi
 #pragma unroll
               for (int j = 0; j < 3; ++j)
                 v[j] = fma(-f[16], t[j], f[15] * g[j]);
-              K[0] = fma(2.0 * g[0], v[0], K[0]) + dd;
-              K[1] = fma(2.0 * g[1], v[1], K[1]) + dd;
-              K[2] = fma(2.0 * g[2], v[2], K[2]) + dd;
+              Kiso += dd;
+              K[0] = fma(g[0], v[0], K[0]);
+              K[1] = fma(g[1], v[1], K[1]);
+              K[2] = fma(g[2], v[2], K[2]);
               K[3] = fma(g[0], v[1], fma(v[0], g[1], K[3]));
               K[4] = fma(g[0], v[2], fma(v[0], g[2], K[4]));
               K[5] = fma(g[1], v[2], fma(v[1], g[2], K[5]));
             }
         }
+#pragma unroll
+    for (int e = 0; e < 3; ++e)
+      K[e] = fma(2.0, K[e], Kiso);
     if (h == 1 && act)
 #pragma unroll
       for (int e = 0; e < 6; ++e)
