@@ -623,7 +623,14 @@ def main():
         ebe_bytes = G.ncells * (per_cell + 27 * 4 + 4) + 8 * G.n * 2
         asm_bytes = 8 * G.nnz + 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n + (G.ncells * per_cell if ebe else 0)
         res_bytes = 4 * G.ncells * 27 + 16 * G.ncells * 81 + 8 * G.n
-        step_bytes = (spmv_n / args.steps * spmv_bytes(G.nnodes, nnzb, 3) +
+        mf_level = args.fine_level == "matrix-free"
+        if mf_level:
+            # no tangent is written: a tangent pass = the point pass (gathers, records written, residual through the slots) ...
+            asm_bytes = 16 * G.ncells * 81 + G.ncells * per_cell + 2 * 8 * G.ncells * 81 + 8 * G.n
+            # ... + per diagonal-block pass: records read, the cells' slots written and read, the node data written
+            diag_bytes = G.ncells * per_cell + 2 * 48 * G.ncells * 27 + (72 + 72 + 48 + 24) * G.nnodes
+        cg_bytes = ebe_bytes if (mf_level or (args.cg_operator == "element" and ebe)) else spmv_bytes(G.nnodes, nnzb, 3)
+        step_bytes = (spmv_n / args.steps * cg_bytes + (tm["assemble_diag"][1] / args.steps * diag_bytes if mf_level else 0) +
                       tm["spmv_precond"][1] / args.steps * (ebe_bytes if ebe else spmv_bytes(G.nnodes, nnzb, 3)) +
                       tm["assemble_cells"][1] / args.steps * asm_bytes +
                       tm["assemble_residual"][1] / args.steps * res_bytes +

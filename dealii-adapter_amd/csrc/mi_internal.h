@@ -180,7 +180,7 @@ struct mi_ctx
   // the Jacobi diagonal -- are formed at the FIRST tangent of a time step and kept over its Newton iterations, as the coarse
   // operators are ("mg_lag"); a preconditioner-side policy: the operator (records) and the residual are always current
   int       mf_point_slots = 1; // the level's point pass (records + residual) over all cells in ONE launch, residual through the
-                                // product's slots (0: eight colour launches; same sums in the same order)
+                                // product's slots (0: eight colour launches; the cells' sums in the same order)
   int       mf_diag_lag = 0;
   bool      mf_diag_fresh = false; // the blocks belong to this time step (cleared by mi_newton_begin_step)
   double   *d_diag_blk   = nullptr; // [nnodes][9] diagonal blocks under the assembled matrix's constraint rule

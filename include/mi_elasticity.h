@@ -298,6 +298,10 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *  mf_diag_lag          0 | 1                      "fine_level" 1: diagonal blocks (smoother's D, Jacobi diagonal) at     -
  *                                                  every tangent | at the first tangent of a time step, kept over its
  *                                                  Newton iterations (what bench.py and the executable set)
+ *  face_slots           1 | 0                      Neumann term: all interface cells in one launch, contributions into    -
+ *                                                  slots, summed per node in entry order | eight colour launches
+ *  asm_box_geometry     1 | 0                      assemble_q2sf on meshes of axis-parallel boxes: 1/h and the volume     -
+ *                                                  (as mf_spmv) | the trilinear map inverted at every point
  *  mf_point_slots       1 | 0                      "fine_level" 1: the point pass (records + residual) over all cells in  -
  *                                                  one launch, residual through the product's slots | eight colour launches
  *  smoother_operator    2 | 1 | 0                  fine-level products of the smoother on 3D Q2 slabs > 100 k nodes:    MI_EBE
