@@ -46,7 +46,7 @@ def test_rank_threads_with_a_distributed_first_coarsened_level(fake_lib, world, 
     _run_ranks(world, dim, p, reps, 1, 0, 0)
 
 
-@pytest.mark.parametrize("world,reps,overlap", [(3, "3,3,7", 1), (2, "4,3,6", 0), (3, "7,2,3", 1)])
+@pytest.mark.parametrize("world,reps,overlap", [(3, "3,3,7", 1), (2, "4,3,6", 0), (3, "7,2,3", 1), (8, "3,3,17", 1)])
 def test_rank_threads_with_the_fine_level_matrix_free(fake_lib, world, reps, overlap):
     """round 6, tuning "fine_level" 1 through the RCCL branch: no assembled fine tangent on any rank -- the CG's product is
     mf_spmv in two launches around the ghost-plane send/recv (inner cell layers while the planes travel) + the gather with the
