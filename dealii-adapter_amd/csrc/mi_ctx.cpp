@@ -494,7 +494,7 @@ namespace mi_detail
               mi::launch_mf_gather_cheb(f, cheb->b, cheb->dinv, cheb->d, const_cast<double *>(x), y, cheb->c1, cheb->c2,
                                         c->own0 / 3, c->own_n / 3, c->stream);
             else if (ebe_for_cg) // the CG's q = K p: the slot sum and the partials of p.q in one launch
-              mi::launch_mf_gather_dot(f, int64_t(c->mesh.nnodes) * 3, dotv, partials, c->grid_vec, c->own0, c->own_n, c->stream);
+              mi::launch_mf_gather_dot(f, int64_t(c->mesh.nnodes) * 3, dotv, partials, c->grid_gdot, c->own0, c->own_n, c->stream);
             else
               mi::launch_mf_gather(f, int64_t(c->mesh.nnodes) * 3, c->stream);
           }
@@ -773,7 +773,9 @@ namespace mi_detail
   int enqueue_assembly(mi_ctx *c, bool residual_only)
   {
     // tangent_matrix = 0 (:1054) is implied: the first cell that touches a block stores instead of adding
-    HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SYSTEM_RHS), 0, size_t(c->n) * sizeof(double), c->stream)); // :1055
+    // (system_rhs = 0, :1055 -- except where residual_gather writes every entry of it: the one-launch point pass)
+    if (!(c->mf_fine && c->mf_point_slots && c->d_mf_yc))
+      HIPCHK(c, hipMemsetAsync(c->vec(MI_V_SYSTEM_RHS), 0, size_t(c->n) * sizeof(double), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sc + SC_INVERTED, 0, sizeof(double), c->stream));
     mi::AsmParams p  = asm_params(c);
     p.residual_only  = residual_only ? 1 : 0;
@@ -1067,7 +1069,13 @@ namespace mi_detail
         cg.flags    = m->d_flags;
         cg.n        = m->own_n;
         cg.npart    = m->grid_vec;
-        cg.npart_pq = (m->cg_fused_dot && !((m->cg_operator == 1 || m->mf_fine) && element_form(m) && !m->active_sell_vals)) ? m->grid_spmv : m->grid_vec;
+        {
+          // partials of p.q: one per workgroup of the kernel that forms them -- the fused product's, the matrix-free gather's
+          // (its own, wider grid), or the separate reduction's
+          const bool elem = (m->cg_operator == 1 || m->mf_fine) && element_form(m) && !m->active_sell_vals;
+          const bool one  = elem && element_form(m) == 2 && m->mf_slots && m->d_mf_yc;
+          cg.npart_pq     = !m->cg_fused_dot ? m->grid_vec : one ? m->grid_gdot : elem ? m->grid_vec : m->grid_spmv;
+        }
         cg.totals   = dist ? m->d_sc + SC_TOT : nullptr;
         cgs.push_back(cg);
       }
@@ -1622,6 +1630,8 @@ namespace mi_detail
     // launch geometry: vector kernels use a fixed grid so that reduction partials are deterministic;
     // SpMV: one wavefront per 64-row slice (measured best), grid-stride above MAX_PART workgroups
     c->grid_vec  = int(std::max<int64_t>(1, std::min<int64_t>(1024, (c->own_n + 255) / 256)));
+    // (mf_gather_dot walks two dependent loads per dof: eight dofs per thread keep enough of them in flight)
+    c->grid_gdot = int(std::max<int64_t>(1, std::min<int64_t>(MAX_PART / 2, (c->n + 2047) / 2048)));
     {
       const int64_t nin = m.sell_nslices_interior, nbd = m.sell_nslices - nin;
       constexpr int64_t W = mi::SELL_WPB; // one wavefront per slice, W wavefronts per workgroup ...

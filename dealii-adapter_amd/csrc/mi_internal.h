@@ -205,6 +205,7 @@ struct mi_ctx
   bool      newton_update_is_zero = false; // MI_V_NEWTON_UPDATE was cleared by the library and not written since
   bool      cg_breakdown = false; // the last solve stopped on a non-finite residual or p.Ap <= 0
 
+  int grid_gdot = 1; // workgroups (= partials) of mf_gather_dot
   int grid_vec = 0, grid_spmv = 0, grid_spmv_int = 0, grid_spmv_bnd = 0; // grid_spmv = _int + _bnd (partials)
   bool split_int = false, split_bnd = false; // small launch: one workgroup per slice (mi::sell_spmv_split)
   int spmv_variant = 3, maxrow = 0, sell_unroll = 5, xcd_remap = 0; // tuning: SpMV kernel (3 = sliced-ELL); longest block row
