@@ -29,6 +29,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector (non-MFMA) peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 MF_FLOPS_PER_LANE = 712.0  # FP64 flop per lane of a cell's wavefront in mf_spmv: (2 x 61.61 M FMA + 20.54 M MUL + 2.46 M ADD
 # wave instructions) x 64 lanes / (205,379 cells x 64 lanes), profiles/r05/pmc_counters_mf_spmv_n59.json
+MF27_FLOPS_PER_LANE = 642.0  # mf_spmv27, per lane of a wavefront of TWO cells: 2 x 267 FMA + 96 MUL + 12 ADD FP64 wave instructions
 CPU_FULL_RUN = os.path.join(ROOT, "profiles", "r02", "cpu_baseline_config3_full.json")  # unit counts of a whole CPU step (deterministic)
 
 
@@ -353,6 +354,11 @@ def main():
     ap.add_argument("--cg-operator", choices=["assembled", "element"], default="assembled",
                     help="A/B: the CG's own product on the assembled sliced-ELL matrix (default; the kernel the north star names) or "
                          "on the unassembled element tangents like the smoother's (then no sliced-ELL copy is made)")
+    ap.add_argument("--smoother-quadrature", type=int, choices=[3, 4], default=3,
+                    help="Gauss points per direction of the multigrid smoother's fine-level operator: 3 (the library's default since "
+                         "round 6: the full-order rule of Q2 elements, mf_spmv27 with two cells per wave; a preconditioner-side choice, "
+                         "all fp64 -- the CG's operator, the residuals and the assembly keep the reference's 4, qf_cell(p+2)) or 4; the "
+                         "default run reports the other one as config.with_smoother_quadrature_4")
     ap.add_argument("--fine-level", choices=["assembled", "matrix-free"], default="assembled",
                     help="assembled (default; the north-star path: global tangent scattered by colours + sell_spmv) or matrix-free: "
                          "no assembled fine tangent at all -- a tangent assembly writes point records, residual and the nodes' "
@@ -449,7 +455,7 @@ def main():
         torch.cuda.synchronize()
 
     def measure(scaling, cells, steps, warmup, uid_, cg_start=None, cg_operator=None, smoother_precision=None, fine_level=None,
-                diag_lag=None):
+                diag_lag=None, quadrature=None):
         """K timed Newmark steps on the cells^3 block (strong) or the cells x cells x parts*cells beam (weak)"""
         nz = cells * parts if scaling == "weak" else cells
         G = M.Context(dim=3, degree=2, reps=(cells, cells, nz), lo=(0, 0, 0), hi=(1, 1, nz / cells), mu=0.5e6, nu=0.4,
@@ -463,6 +469,7 @@ def main():
             G.set_tuning("precond_storage", 32)
         if (smoother_precision or args.smoother_precision) == "f32":
             G.set_tuning("smoother_precision", 32)
+        G.set_tuning("smoother_quadrature", quadrature or args.smoother_quadrature)
         if (fine_level or args.fine_level) == "matrix-free":
             G.set_tuning("fine_level", 1)
             G.set_tuning("mf_diag_lag", 0 if diag_lag == 0 else 1)  # (1: what the executable sets beside MI_FINE_LEVEL=1)
@@ -542,6 +549,7 @@ def main():
                 if args.precond == "mg" else "Jacobi",
                 "preconditioner_storage": args.precond_storage,
                 "smoother_precision": args.smoother_precision,
+                "smoother_quadrature": args.smoother_quadrature,
                 "n_dofs": G.n,
                 "nnz": G.nnz,
                 "decomposition": ("single GPU" if args.slabs == 1 else "%d slabs cut along %s, emulated on one GPU"
@@ -630,8 +638,11 @@ def main():
             # ... + per diagonal-block pass: records read, the cells' slots written and read, the node data written
             diag_bytes = G.ncells * per_cell + 2 * 48 * G.ncells * 27 + (72 + 72 + 48 + 24) * G.nnodes
         cg_bytes = ebe_bytes if (mf_level or (args.cg_operator == "element" and ebe)) else spmv_bytes(G.nnodes, nnzb, 3)
+        sm_bytes = ebe_bytes
+        if form == 2 and G.get_tuning("smoother_quadrature_active") == 3:
+            sm_bytes = G.ncells * (11 * 27 * 8 + 4) + 8 * G.n * 2
         step_bytes = (spmv_n / args.steps * cg_bytes + (tm["assemble_diag"][1] / args.steps * diag_bytes if mf_level else 0) +
-                      tm["spmv_precond"][1] / args.steps * (ebe_bytes if ebe else spmv_bytes(G.nnodes, nnzb, 3)) +
+                      tm["spmv_precond"][1] / args.steps * (sm_bytes if ebe else spmv_bytes(G.nnodes, nnzb, 3)) +
                       tm["assemble_cells"][1] / args.steps * asm_bytes +
                       tm["assemble_residual"][1] / args.steps * res_bytes +
                       120 * G.n) / share
@@ -658,12 +669,20 @@ def main():
             ebe_ms = tm["ebe_launch"][0] / tm["ebe_launch"][1]
             per_launch = ebe_bytes / 8  # one colour of the eight; the colours differ by +-5 % in cells
             single = form == 2 and G.get_tuning("mf_single_launch") == 1
+            q27 = single and G.get_tuning("smoother_quadrature_active") == 3
             if single:
                 # ONE launch over all cells: records + node ids + slot ids per cell, x once, 81 contributions per cell
                 # written to the cell's slots (the sum over the slots of a node is a second, streaming launch: mf_gather)
                 per_launch = G.ncells * (11 * 64 * 8 + 27 * 4 + 27 * 4 + 81 * 8) + 8 * G.n
+            if q27:
+                # the smoother's 27-point form: 27 x 11 record numbers per cell, node ids by arithmetic, cell-major slots (no slot ids)
+                per_launch = G.ncells * (11 * 27 * 8 + 81 * 8) + 8 * G.n
             out["roofline"] = {
-                "kernel": ("mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
+                "kernel": ("mf_spmv27: the smoother's fine-level product P^T K_e P x of all cells, evaluated from 27 x 11 quadrature-point "
+                           "numbers per cell (F, J^(-2/3), 1/J at the 3 x 3 x 3 Gauss points: the full-order rule of Q2 elements; the "
+                           "CG's operator keeps the assembly's 64 points), sum factorised, TWO cells per wavefront (27 work items per "
+                           "stage and cell); " if q27 else
+                           "mf_spmv: the cells' P^T K_e P x evaluated from the 64 x 11 quadrature-"
                            "point numbers per cell the tangent is linearised at (sum factorisation, no stored K_e; 4.8x fewer bytes "
                            "than the element tangents it replaced, which takes the product off the HBM roofline: VALU, LDS and HBM "
                            "are each half to three quarters busy, profiles/r05/pmc_counters_mf_spmv_n59.json); "
@@ -696,10 +715,14 @@ def main():
                 # instructions of FP64 arithmetic (SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 of the committed counter pass, FMA = 2),
                 # i.e. counted over all 64 lanes of the cell's wavefront whether a stage uses them or not
                 flops = G.ncells * 64.0 * MF_FLOPS_PER_LANE
+                src = "profiles/r05/pmc_counters_mf_spmv_n59.json (2 x FMA + MUL + ADD wave instructions x 64 lanes per cell)"
+                if q27:
+                    flops = ((G.ncells + 1) // 2) * 64.0 * MF27_FLOPS_PER_LANE
+                    src = ("instruction count of the kernel's ISA: 267 FMA + 96 MUL + 12 ADD FP64 wave instructions per wavefront of two cells "
+                           "x 64 lanes (profiles/r06/pmc_counters_mf_spmv27_n59.json)")
                 out["roofline"]["fp64"] = {
                     "flops_per_launch": flops, "TFLOP_per_s": flops / (ebe_ms * 1e-3) / 1e12, "peak_TFLOP_per_s": FP64_VECTOR_PEAK_TF,
-                    "frac": flops / (ebe_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF,
-                    "source": "profiles/r05/pmc_counters_mf_spmv_n59.json (2 x FMA + MUL + ADD wave instructions x 64 lanes per cell)"}
+                    "frac": flops / (ebe_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TF, "source": src}
         out["roofline"]["whole_step"] = {
             "fine_level_products_per_step": n_prod, "algorithmic_GB_per_step": step_bytes / 1e9,
             "GB_per_s": step_bytes / 1e9 / (ms_step * 1e-3), "frac": step_bytes / 1e9 / (ms_step * 1e-3) / HBM_PEAK_GBS,
@@ -731,7 +754,8 @@ def main():
             cgp["traffic"], cgp["traffic_launches"] = t_cg
             cgp["traffic_ratio_to_algorithmic"] = t_cg[0] / cgp["bytes_per_launch"]
             cgp["traffic_source"] = how_live
-        t_dom = live_traffic("mi::mf_spmv" if form == 2 else "mi::ebe_spmv", 0.5e9 if single else 0.0) if dom is not None else None
+        q27_dom = dom is not None and "mf_spmv27" in dom["kernel"]
+        t_dom = live_traffic("mi::mf_spmv27" if q27_dom else "mi::mf_spmv<" if form == 2 else "mi::ebe_spmv", 0.3e9 if single else 0.0) if dom is not None else None
         if t_dom:
             dom["traffic"], dom["traffic_launches"] = t_dom
             dom["traffic_ratio_to_algorithmic"] = t_dom[0] / dom["bytes_per_launch"]
@@ -833,6 +857,22 @@ def main():
             r["note"] = ("tuning \"fine_level\" 1 (bench.py --fine-level matrix-free): no global fine tangent is assembled or "
                          "stored (7.6 GB at 5 M DoFs released); not the headline because north_star names the CSR + SpMV path")
             out["config"]["with_matrix_free_fine_level"] = r
+        if args.smoother_quadrature == 3 and args.smoother_operator == "matrix-free" and n >= 8:
+            # The smoother's fine-level operator with the assembly's 4 x 4 x 4 Gauss points instead of the 3 x 3 x 3 the library
+            # defaults to since round 6 (mf_spmv27: two cells per wave from 27-point records; preconditioner side only, all fp64:
+            # the CG's operator, every residual and the assembly keep the reference's rule).  On both fine levels, over the
+            # headline's step window: what the headline and with_matrix_free_fine_level would be with the rounds-3-to-5 smoother.
+            note = ("tuning \"smoother_quadrature\" 4: the V-cycle's fine-level smoother products, residual and eigenvalue estimate with "
+                    "the 64-point rule of the assembly (rounds 3-5); the default is 3 (27 points): same Newton tables and CG iterations")
+            r3, tm3 = side(quadrature=4)
+            r3["ms_smoother_fine_product"] = tm3["spmv_precond"][0] / max(tm3["spmv_precond"][1], 1)
+            r3["note"] = note
+            out["config"]["with_smoother_quadrature_4"] = r3
+            if args.fine_level == "assembled":
+                r4, tm4 = side(quadrature=4, fine_level="matrix-free")
+                r4["ms_smoother_fine_product"] = tm4["spmv_precond"][0] / max(tm4["spmv_precond"][1], 1)
+                r4["note"] = note
+                out["config"]["with_matrix_free_fine_level_smoother_quadrature_4"] = r4
     if rank == 0 and world == 1 and args.cpu_cells > 0:
         # the GPU on the CPU sample's own configuration, beside it
         if args.cpu_cells != n or args.slabs != 1:

@@ -403,8 +403,11 @@ namespace mi_detail
         // ... unless the cells can be told apart by their layer (round 4: matrix-free, one launch, lattice ids): the cells that
         // touch no ghost plane of x -- all but the lowest layer (rank > 0) and the ghost layer (rank < size - 1) -- run as part 1
         // while the halo is in flight, the others as part 2; every cell still writes its own slots, so the sum is the same
+        // smoother quadrature 3: the smoother's products (never the CG's) from the 27-point records, two cells per wave
+        const bool q27 = smoother && !ebe_for_cg && c->smoother_points == 3 && c->qrec27_valid && kind == 2 && c->mf_slots && c->d_mf_yc &&
+                         !(c->smoother_precision == 32 && c->qrec32_valid); // (the opt-in fp32 smoother products keep the 64-point kernel)
         const bool mf_split = part != 0 && kind == 2 && c->mf_slots && c->d_mf_yc && c->lat.ncol > 0 && c->team->mf_overlap &&
-                              !(ebe_for_cg && !mf_all);
+                              !(ebe_for_cg && !mf_all) && !q27; // (the 27-point kernel takes all cells after the exchange)
         if (part == 1 && !mf_split)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
@@ -413,6 +416,8 @@ namespace mi_detail
         // opt-in "smoother_precision" 32: the SMOOTHER's products in fp32 arithmetic on fp32 records (residuals, start-vector
         // products and mi_spmv keep the fp64 form)
         f.qrec32  = (smoother && c->smoother_precision == 32 && c->qrec32_valid) ? c->d_qrec32 : nullptr;
+        f.qrec27  = c->d_qrec27;
+        f.tab27   = c->d_tab27;
         f.conn    = c->d_conn;
         f.first   = c->d_node_first;
         f.cmask   = c->d_cmask;
@@ -433,6 +438,7 @@ namespace mi_detail
             f.yc        = c->d_mf_yc;
             f.dst       = c->d_mf_dst;
             f.slot_base = c->d_mf_slot_base;
+            f.slot_src  = c->d_mf_src;
           }
         // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
         // profiler reports them), class MI_T_EBE_LAUNCH
@@ -440,7 +446,9 @@ namespace mi_detail
         // (a product that runs in two parts around a halo exchange counts once -- with its second part -- and the
         // launch that holds the bulk of the cells, part 1, is the one that is timed)
         const bool counts = !(mf_split && part == 1);
-        const bool sample = c0->profiling && (counts ? c->ebe_products++ % 6 == 0 : c->ebe_products % 6 == 0);
+        // (the SMOOTHER's products: the class times one kernel -- the CG's own matrix-free products and the start-vector
+        // products of a matrix-free fine level are 64-point launches beside the smoother's 27-point ones)
+        const bool sample = c0->profiling && smoother && (counts ? c->ebe_products++ % 6 == 0 : c->ebe_products % 6 == 0);
         if (one_launch) // all cells at once (no two cells share a slot), then the sum over the slots of every node
           {
             if (mf_split)
@@ -480,6 +488,12 @@ namespace mi_detail
                   }
                 layers(0, zlo, false);
                 layers(zhi, nzl, false);
+              }
+            else if (q27)
+              {
+                const int t = sample ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
+                mi::launch_mf_spmv27(f, int32_t(c->mesh.ncells), c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                     t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
               }
             else
               {
@@ -804,8 +818,8 @@ namespace mi_detail
         p.res_slots  = c->d_mf_yc; // (the product's slot array: no product is in flight during an assembly)
         p.slot_dst   = c->d_mf_dst;
         mi::launch_point_pass_slots(p, c->stream);
-        mi::launch_residual_gather(c->d_mf_yc, c->d_mf_slot_base, c->d_cmask, c->vec(MI_V_SYSTEM_RHS), int64_t(c->mesh.nnodes) * 3,
-                                   c->stream);
+        mi::launch_residual_gather(c->d_mf_yc, c->d_mf_slot_base, c->d_mf_src, c->d_cmask, c->vec(MI_V_SYSTEM_RHS),
+                                   int64_t(c->mesh.nnodes) * 3, c->stream);
       }
     for (int col = 0; col < c->mesh.ncolours; ++col)
       {
@@ -832,6 +846,15 @@ namespace mi_detail
         HIPCHK(c, hipGetLastError());
         return MI_OK;
       }
+    c->qrec27_valid = false;
+    if (c->smoother_points == 3 && c->d_qrec && c->d_qrec27) // the smoother's own records: F, J^(-2/3), 1/J at the 27 points
+      {
+        mi::MfParams f{};
+        f.conn = c->d_conn, f.cverts = c->d_cverts, f.cellbox = c->d_cellbox, f.tab27 = c->d_tab27, f.lat = c->lat;
+        mi::launch_mf_records27(f, c->vec(MI_V_TOTAL_DISPLACEMENT), c->vec(MI_V_SOLUTION_DELTA), c->d_qrec27, int32_t(c->mesh.ncells),
+                                c->stream);
+        c->qrec27_valid = true;
+      }
     // which kernel ran: assemble_q2sf (sum factorised; it alone writes the fp32 records) or the node-pair form
     const bool q2sf = c->dim == 3 && c->degree == 2 && (p.variant == 0 || (p.variant >= 3 && p.variant <= 8));
     c->ke_valid     = (c->d_ke && q2sf && !c->mf_fine) || c->d_qrec;
@@ -850,7 +873,7 @@ namespace mi_detail
         f.mu = c->mat.mu, f.kappa = c->kappa, f.mass = c->alpha[1] * c->mat.rho;
         const int td = tic(c0, MI_T_ASSEMBLE_DIAG);
         mi::launch_mf_diag(f, c->d_diag_slots, int32_t(c->mesh.ncells), c->stream);
-        mi::launch_mf_diag_gather(c->d_diag_slots, c->d_mf_slot_base, c->d_cmask, c->d_diagpos_mf, c->d_diag_blk, c->work(W_DINV),
+        mi::launch_mf_diag_gather(c->d_diag_slots, c->d_mf_slot_base, c->d_mf_src, c->d_cmask, c->d_diagpos_mf, c->d_diag_blk, c->work(W_DINV),
                                   c->d_dinv_blk, c->d_dinv_sym6, c->mesh.nnodes, c->stream);
         toc(c0, td);
         HIPCHK(c, hipGetLastError());
@@ -872,11 +895,77 @@ namespace mi_detail
     return MI_OK;
   }
 
+  // slots of the matrix-free kernels' results (see MfParams::dst / slot_base / slot_src); rebuilt when the layout key changes
+  int build_slot_tables(mi_ctx *c)
+  {
+    for (int32_t **p : {&c->d_mf_dst, &c->d_mf_slot_base, &c->d_mf_src})
+      if (*p)
+        {
+          hipFree(*p);
+          *p = nullptr;
+        }
+
+    // slots for the single-launch product: rank of every (cell, local node) among the cells of the node, in
+    // processing order (colour-sorted cell order: the order in which the colour-by-colour update adds them)
+    const int64_t        nc = c->mesh.ncells, nn = c->mesh.nnodes;
+    std::vector<int32_t> base(size_t(nn) + 1, 0), dst(size_t(nc) * 27), fill(size_t(nn), 0);
+    for (int64_t e = 0; e < nc; ++e)
+      for (int a = 0; a < 27; ++a)
+        ++base[size_t(c->mesh.conn[size_t(e) * 27 + a]) + 1];
+    for (int64_t n = 0; n < nn; ++n)
+      base[size_t(n) + 1] += base[size_t(n)];
+    for (int64_t e = 0; e < nc; ++e)
+      for (int a = 0; a < 27; ++a)
+        {
+          const int32_t n = c->mesh.conn[size_t(e) * 27 + a];
+          dst[size_t(e) * 27 + a] = base[size_t(n)] + fill[size_t(n)]++;
+        }
+    // cell-major layout ("mf_slots_cell_major" 1): a cell stores its 81 results as one contiguous run, the gathers read a
+    // node's contributions through slot_src (their positions, in processing order)
+    std::vector<int32_t> src;
+    const bool cell_major = c->slots_cell_major >= 0 ? c->slots_cell_major != 0 : c->smoother_points == 3;
+    if (cell_major)
+      {
+        src.resize(dst.size());
+        for (size_t k = 0; k < dst.size(); ++k)
+          src[size_t(dst[k])] = int32_t(k);
+        for (size_t k = 0; k < dst.size(); ++k)
+          dst[k] = int32_t(k);
+      }
+    int rc = upload(c, &c->d_mf_dst, dst);
+    if (rc == MI_OK)
+      rc = upload(c, &c->d_mf_slot_base, base);
+    if (rc == MI_OK && cell_major)
+      rc = upload(c, &c->d_mf_src, src);
+    if (rc)
+      return rc;
+    if (!c->d_mf_yc)
+      HIPCHK(c, hipMalloc((void **)&c->d_mf_yc, size_t(nc) * 27 * 3 * sizeof(double)));
+    
+    return MI_OK;
+  }
+
+  // the smoother's own records and tables ("smoother_quadrature" 3), beside the assembly's
+  int alloc_records27(mi_ctx *c)
+  {
+    if (c->d_qrec27 || c->smoother_points != 3)
+      return MI_OK;
+    mi::Tables1D t3;
+    t3.build(2, 3);
+    const int rc = upload(c, &c->d_tab27, t3.packed());
+    if (rc)
+      return rc;
+    HIPCHK(c, hipMalloc((void **)&c->d_qrec27, size_t(c->mesh.ncells) * mi::MF_NREC * 27 * sizeof(double)));
+    return MI_OK;
+  }
+
   // quadrature-point records for the matrix-free product (3D Q2) + the geometry class of the local cells
   int alloc_point_records(mi_ctx *c)
   {
     if (c->d_qrec)
-      return MI_OK;
+      return alloc_records27(c);
+    if (int r27 = alloc_records27(c))
+      return r27;
     HIPCHK(c, hipMalloc((void **)&c->d_qrec, size_t(c->mesh.ncells) * mi::MF_NREC * 64 * sizeof(double)));
     bool box = c->dim == 3;
     for (int64_t e = 0; e < c->mesh.ncells && box; ++e)
@@ -886,29 +975,8 @@ namespace mi_detail
           for (int d = 0; d < 3; ++d)
             box = box && cv[v * 3 + d] == cv[(((v >> d) & 1) ? 7 : 0) * 3 + d];
       }
-    {
-      // slots for the single-launch product: rank of every (cell, local node) among the cells of the node, in
-      // processing order (colour-sorted cell order: the order in which the colour-by-colour update adds them)
-      const int64_t        nc = c->mesh.ncells, nn = c->mesh.nnodes;
-      std::vector<int32_t> base(size_t(nn) + 1, 0), dst(size_t(nc) * 27), fill(size_t(nn), 0);
-      for (int64_t e = 0; e < nc; ++e)
-        for (int a = 0; a < 27; ++a)
-          ++base[size_t(c->mesh.conn[size_t(e) * 27 + a]) + 1];
-      for (int64_t n = 0; n < nn; ++n)
-        base[size_t(n) + 1] += base[size_t(n)];
-      for (int64_t e = 0; e < nc; ++e)
-        for (int a = 0; a < 27; ++a)
-          {
-            const int32_t n = c->mesh.conn[size_t(e) * 27 + a];
-            dst[size_t(e) * 27 + a] = base[size_t(n)] + fill[size_t(n)]++;
-          }
-      int rc = upload(c, &c->d_mf_dst, dst);
-      if (rc == MI_OK)
-        rc = upload(c, &c->d_mf_slot_base, base);
-      if (rc)
-        return rc;
-      HIPCHK(c, hipMalloc((void **)&c->d_mf_yc, size_t(nc) * 27 * 3 * sizeof(double)));
-    }
+    if (int rs = build_slot_tables(c))
+      return rs;
     if (box) // 1/h and the volume per cell, so that the product needs no division for its geometry
       {
         std::vector<double> cb(size_t(c->mesh.ncells) * 4);
@@ -1443,8 +1511,8 @@ namespace mi_detail
                     c->d_flags,     c->d_cverts,    c->d_tab,         c->d_vals,        c->d_vecs,        c->d_work,
                     c->d_saved,     c->d_part,      c->d_sc,          c->d_iface_buf,   c->d_off,         c->d_cmask,
                     c->d_sell_perm, c->d_sell_len,  c->d_sell_col,    c->d_sell_off,    c->d_rowinfo, c->d_rowwx, c->d_sell_wx, c->d_band, c->d_band_work, c->d_band_perm,
-                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_qrec32, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_lat_rows,
-                    c->d_diag_blk, c->d_diag_slots, c->d_diagpos_mf, c->d_face_slots, c->d_fn_ids, c->d_fn_start, c->d_fn_src,
+                    c->d_own_if_nodes, c->d_own_if_slots, c->d_sell_vals32, c->d_dinv_blk, c->d_dinv_sym6, c->d_sell_box, c->d_ke, c->d_node_first, c->d_qrec, c->d_qrec32, c->d_cellbox, c->d_mf_yc, c->d_mf_dst, c->d_mf_slot_base, c->d_mf_src, c->d_lat_rows,
+                    c->d_qrec27, c->d_tab27, c->d_diag_blk, c->d_diag_slots, c->d_diagpos_mf, c->d_face_slots, c->d_fn_ids, c->d_fn_start, c->d_fn_src,
                     c->d_pred[0][0], c->d_pred[0][1], c->d_pred[1][0], c->d_pred[1][1], c->d_pred[2][0], c->d_pred[2][1], c->d_pred[3][0], c->d_pred[3][1],
                     c->d_pred_saved[0][0], c->d_pred_saved[0][1], c->d_pred_saved[1][0], c->d_pred_saved[1][1], c->d_pred_saved[2][0],
                     c->d_pred_saved[2][1], c->d_pred_saved[3][0], c->d_pred_saved[3][1]};
@@ -2705,7 +2773,7 @@ int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
     HIPCHK(m, hipMemcpy(m->work(W_P), x_host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
                         hipMemcpyHostToDevice));
   for (mi_ctx *m : T.members)
-    enqueue_spmv(m, m->work(W_P), m->work(W_Q), nullptr, nullptr, nullptr);
+    enqueue_spmv(m, m->work(W_P), m->work(W_Q), nullptr, nullptr, nullptr, 0, m->spmv_as_smoother != 0);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (T.size == 1)
@@ -2735,6 +2803,43 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
                          (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
                          (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
         return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
+      if (k == "mf_slots_cell_major" && value >= -1 && value <= 1) // A/B: -1 follows the smoother's quadrature
+        {
+          m->slots_cell_major = value;
+          if (m->d_mf_dst)
+            {
+              HIPCHK(m, hipStreamSynchronize(m->stream));
+              const int rc = build_slot_tables(m);
+              if (rc)
+                return rc;
+            }
+          continue;
+        }
+      if (k == "spmv_as_smoother" && (value == 0 || value == 1)) // tests: mi_spmv through the smoother's form of the operator
+        {
+          m->spmv_as_smoother = value;
+          continue;
+        }
+      if (k == "smoother_quadrature" && (value == 3 || value == 4))
+        {
+          // (matters where the smoother multiplies matrix-free from point records: 3D Q2 meshes above 100 k nodes, or after
+          // "element_tangents" 2 / "fine_level" 1; elsewhere the key is accepted and has no effect)
+          const bool change = m->smoother_points != value;
+          m->smoother_points = value;
+          if (m->d_qrec && change) // the records exist already: the smoother's own, and the slot layout that goes with the rule
+            {
+              HIPCHK(m, hipStreamSynchronize(m->stream));
+              int rc = alloc_records27(m);
+              if (rc == MI_OK && m->slots_cell_major < 0)
+                rc = build_slot_tables(m);
+              if (rc)
+                return rc;
+            }
+          m->qrec27_valid = false;
+          m->ke_valid     = false; // takes effect with the next tangent
+          m->mg_stale = m->mg_force = true;
+          continue;
+        }
       if (k == "asm_box_geometry" && (value == 0 || value == 1)) // assemble_q2sf on meshes of boxes: geometry from 1/h | the trilinear map
         {
           m->asm_box_geometry = value;
@@ -2946,6 +3051,10 @@ int mi_get_tuning(mi_ctx *c, const char *key, int *value)
     *value = m->mf_fine;
   else if (k == "mf_diag_lag")
     *value = m->mf_diag_lag;
+  else if (k == "smoother_quadrature")
+    *value = m->smoother_points;
+  else if (k == "smoother_quadrature_active") // 3: the smoother's fine-level products run on the 27-point records of the current tangent
+    *value = (m->smoother_points == 3 && m->qrec27_valid && element_form(m) == 2) ? 3 : 4;
   else if (k == "experiments") // 1: built with -DMI_EXPERIMENTS (environment hooks and A/B kernel instantiations compiled in)
 #ifdef MI_EXPERIMENTS
     *value = 1;
@@ -3035,7 +3144,10 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
     for (mi_ctx *m : c->team->members)
       {
         const bool plain = m->spmv_variant == 4 && !m->mf_fine; // the unassembled forms carry no fused dot product
-        enqueue_spmv(m, m->work(W_P), m->work(W_Q), plain ? nullptr : m->work(W_P), plain ? nullptr : m->part(2), nullptr);
+        if (m->spmv_as_smoother) // (tests / tools: the smoother's form of the operator)
+          enqueue_spmv(m, m->work(W_P), m->work(W_Q), nullptr, nullptr, nullptr, 0, true);
+        else
+          enqueue_spmv(m, m->work(W_P), m->work(W_Q), plain ? nullptr : m->work(W_P), plain ? nullptr : m->part(2), nullptr);
       }
   };
   once(); // warm-up
@@ -3061,7 +3173,7 @@ int mi_bench_spmv(mi_ctx *c, int reps, double *ms_per_launch)
       f.qrec = c->d_qrec, f.conn = c->d_conn, f.first = c->d_node_first, f.cmask = c->d_cmask, f.vals = c->d_vals;
       f.diagpos = c->d_diagpos, f.tab1d = c->d_tab, f.cverts = c->d_cverts, f.mu = c->mat.mu, f.kappa = c->kappa;
       f.cellbox = c->d_cellbox, f.x = c->work(W_P), f.y = c->work(W_Q), f.mass = c->alpha[1] * c->mat.rho, f.lat = c->lat;
-      f.yc = c->d_mf_yc, f.dst = c->d_mf_dst, f.slot_base = c->d_mf_slot_base, f.stamps = d_st;
+      f.yc = c->d_mf_yc, f.dst = c->d_mf_dst, f.slot_base = c->d_mf_slot_base, f.slot_src = c->d_mf_src, f.stamps = d_st;
       mi::launch_mf_spmv(f, 0, int32_t(ncell), c->stream);
       std::vector<unsigned long long> st(size_t(ncell) * 8);
       HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -136,11 +136,22 @@ struct mi_ctx
   uint32_t *d_node_first = nullptr; // per cell: bit a = first touch of local node a (see HostMesh::node_first)
   float    *d_qrec32 = nullptr; // the same records in fp32 (opt-in "smoother_precision" 32)
   int       smoother_precision = 64;
+  // tuning "smoother_quadrature" 3 (round 6; 3D Q2 with point records): the multigrid smoother's fine-level products, the
+  // V-cycle's fine residual and the eigenvalue estimate integrate the tangent with 3 x 3 x 3 Gauss points (mf_spmv27: two
+  // cells per wave) from records of their own; 4 (default): the assembly's 4 x 4 x 4 rule.  The CG's operator stays exact.
+  int       smoother_points = 3; // (library default since round 6: same Newton tables and iteration counts, -11 % per step)
+  double   *d_qrec27 = nullptr;  // [ncells][MF_NREC][27]
+  double   *d_tab27  = nullptr;  // 1D tables of the 3-point rule
+  bool      qrec27_valid = false;
+  int       spmv_as_smoother = 0; // tests: mi_spmv applies the smoother's form of the operator
   bool      qrec32_valid = false; // d_qrec32 belongs to the current tangent
   double   *d_qrec = nullptr; // quadrature-point records of the last tangent assembly (3D Q2): the matrix-free form of the smoother's operator
   double   *d_mf_yc = nullptr;        // matrix-free product in one launch: per-(cell, node) contributions ...
   int32_t  *d_mf_dst = nullptr;       // ... their slots [ncells][27] ...
   int32_t  *d_mf_slot_base = nullptr; // ... and the first slot of every node [nnodes+1]
+  int32_t  *d_mf_src = nullptr;       // cell-major slots: position of every contribution, node by node (MfParams::slot_src)
+  int       slots_cell_major = -1;    // -1: follows the smoother's quadrature (3: cell-major, 4: node-major: what each measured faster
+                                      // with); 0 / 1: forced (tuning "mf_slots_cell_major", A/B)
   int       mf_slots = 1;             // tuning "mf_single_launch": 1 one launch + gather (default), 0 eight colour launches
   mi::CellLattice lat;                // 3D Q2: node ids of a cell by arithmetic (ncol == 0: unavailable / switched off)
   mi::CellLattice lat_built;          // ... as built at creation (tuning "cell_lattice" 0 / 1 switches lat)

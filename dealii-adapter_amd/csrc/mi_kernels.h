@@ -103,6 +103,8 @@ namespace mi
   {
     const double   *qrec;    // [ncells][MF_NREC][64]
     const float    *qrec32;  // the same records rounded to fp32 (opt-in fp32 smoother product), or null
+    const double   *qrec27;  // [ncells][MF_NREC][27] the records at the 27 points of the 3-point rule (smoother quadrature 3), or null
+    const double   *tab27;   // N1[3][3], dN1[3][3], qw[3], qx[3] of that rule
     const int32_t  *conn;    // [ncells][27] colour-sorted
     const uint32_t *first;   // as EbeParams
     const uint8_t  *cmask;   // [nnodes]
@@ -120,6 +122,8 @@ namespace mi
     double         *yc;        // [nslots][3] contributions
     const int32_t  *dst;       // [ncells][27] slot of (cell, local node)
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
+    const int32_t  *slot_src;  // cell-major slots (dst[cell][a] = cell * 27 + a: a cell's 81 results are ONE contiguous run): position
+                               // of the k-th contribution of a node, k in [slot_base[n], slot_base[n+1]); null: node-major (dst = k)
     CellLattice     lat;       // node ids by arithmetic (ncol == 0: read conn)
     unsigned long long *stamps; // diagnostic (null in production): [cells][8] shader-clock stamps at the stage boundaries
     // slabs, lattice ids only: a launch over the cells of the layers [z_a, z_b) of the last lattice direction alone (the
@@ -262,6 +266,10 @@ namespace mi
   // (f32: the fp32 form -- production shape with p.qrec32 only, otherwise the fp64 kernel runs)
   void launch_mf_spmv(const MfParams &p, int64_t cell_begin, int32_t cell_count, hipStream_t s,
                       hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+  // smoother quadrature 3 (see mf_spmv27): the product with two cells per wave from the 27-point records, and the kernel that
+  // writes those records from u + du
+  void launch_mf_spmv27(const MfParams &p, int32_t cell_count, hipStream_t s, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+  void launch_mf_records27(const MfParams &p, const double *u, const double *du, double *rec27, int32_t cell_count, hipStream_t s);
   void launch_mf_gather(const MfParams &p, int64_t ndofs, hipStream_t s);
   // ... with the partials of dotv . y over the owned dofs (fixed grid): the CG's product on the matrix-free fine level
   void launch_mf_gather_dot(const MfParams &p, int64_t ndofs, const double *dotv, double *partials, int grid, int64_t own0,
@@ -272,10 +280,10 @@ namespace mi
   // the matrix-free fine level's point pass over ALL cells in one launch (assemble_q2sf<true> with the residual into slots:
   // AsmParams::res_slots / slot_dst; cell_begin = 0, cell_count = all) and the sum of the slots into system_rhs
   void launch_point_pass_slots(const AsmParams &p, hipStream_t s);
-  void launch_residual_gather(const double *slots3, const int32_t *slot_base, const uint8_t *cmask, double *rhs, int64_t ndofs,
-                              hipStream_t s);
-  void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const uint8_t *cmask, const int32_t *diagpos,
-                             double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s);
+  void launch_residual_gather(const double *slots3, const int32_t *slot_base, const int32_t *slot_src, const uint8_t *cmask, double *rhs,
+                              int64_t ndofs, hipStream_t s);
+  void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const int32_t *slot_src, const uint8_t *cmask,
+                             const int32_t *diagpos, double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s);
   // gather fused with the smoother's Chebyshev step (d != null: x += d in place) or residual (d == null: yres = b - K x)
   void launch_mf_gather_cheb3(const MfParams &p, const double *b, const double *dinv6, const double *xprev, const double *xcur,
                               double *xnext, double c1, double c2, int64_t node0, int64_t nnodes, hipStream_t s);

@@ -3160,9 +3160,9 @@ namespace mi
         return;
       }
     const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-    double        s  = prm.yc[int64_t(b0) * 3 + c];
+    double        s  = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
     for (int32_t k = b0 + 1; k < b1; ++k)
-      s = s + prm.yc[int64_t(k) * 3 + c];
+      s = s + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
     prm.y[g] = s;
   }
 
@@ -3189,9 +3189,9 @@ namespace mi
         else
           {
             const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-            q                = prm.yc[int64_t(b0) * 3 + c];
+            q                = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
             for (int32_t k = b0 + 1; k < b1; ++k)
-              q = q + prm.yc[int64_t(k) * 3 + c];
+              q = q + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
           }
         res = b[g] - q;
       }
@@ -3248,9 +3248,9 @@ namespace mi
         else
           {
             const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-            q                = prm.yc[int64_t(b0) * 3 + c];
+            q                = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
             for (int32_t k = b0 + 1; k < b1; ++k)
-              q = q + prm.yc[int64_t(k) * 3 + c];
+              q = q + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
           }
         res = b[g] - q;
       }
@@ -3290,9 +3290,9 @@ namespace mi
         else
           {
             const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-            s                = prm.yc[int64_t(b0) * 3 + c];
+            s                = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
             for (int32_t k = b0 + 1; k < b1; ++k)
-              s = s + prm.yc[int64_t(k) * 3 + c];
+              s = s + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
           }
         prm.y[g] = s;
         if (g >= own0 && g < own0 + own_n)
@@ -3468,6 +3468,7 @@ namespace mi
   // read at constrained dofs and mi_get_diagonal_blocks returns), its inverse in full and as symmetric half (block-Jacobi
   // smoother), 1 / diagonal (Jacobi).  Nodes without a row here (ghost planes of a slab): zeros, never read.
   __global__ __launch_bounds__(256) void mf_diag_gather(const double *__restrict__ slots6, const int32_t *__restrict__ slot_base,
+                                                        const int32_t *__restrict__ slot_src,
                                                         const uint8_t *__restrict__ cmask, const int32_t *__restrict__ diagpos,
                                                         double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes)
   {
@@ -3482,7 +3483,7 @@ namespace mi
         double        s[6] = {0, 0, 0, 0, 0, 0};
         for (int32_t k = b0; k < b1; ++k)
           {
-            const double2 *__restrict__ p = reinterpret_cast<const double2 *>(slots6 + int64_t(k) * 6);
+            const double2 *__restrict__ p = reinterpret_cast<const double2 *>(slots6 + int64_t(slot_src ? slot_src[k] : k) * 6);
             const double2 p0 = p[0], p1 = p[1], p2 = p[2];
             double        v[6] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y};
 #pragma unroll
@@ -3522,9 +3523,371 @@ namespace mi
       dinv[n * 3 + c] = diagpos[n] >= 0 ? 1.0 / A[c * 4] : 0.0;
   }
 
+  // ------------------------------------------------------------------ smoother quadrature 3 x 3 x 3 (round 6)
+  // The multigrid smoother's fine-level operator A' = the same tangent integrated with the 27-point Gauss rule (3 per
+  // direction: the full-order rule of Q2 elements; the reference -- and the CG's own operator, every residual and the
+  // assembly -- integrate with 4 per direction, qf_cell(p+2), nonlinear_elasticity.cc:74).  A preconditioner-side choice, all
+  // fp64: the V-cycle smooths, forms its fine residual and estimates its eigenvalues with A'; the CG still multiplies with A.
+  // With 27 points every stage of the sum-factorised product has 27 work items, so ONE wave carries TWO cells (lanes 0-26
+  // and 32-58), and per cell the wave issues 156 FP64 instructions instead of 412 and reads 27 x 11 instead of 64 x 11 record
+  // numbers.  Stages per half-wave (R = 324 doubles reused in place: every stage reads its inputs into registers, the wave
+  // synchronises, then the outputs go on top of them; X = the 81 gathered values):
+  //   E12  item (c,k,qx): x-line values of plane (c,k) -> B_DS / B_SD / B_SS [c,k][qy][qx]         27 + 18 multiply-adds
+  //   E3   item = point:  H[c][l] = d x_c / d xi_l, V[c] = x_c                                      36
+  //   point (mf_spmv's: neo_hooke_from_F on the 27-point record, Q = JxW S M^T, mass)               ~150
+  //   I3   item (c,qy,qx): contract qz -> C_DS / C_SD / C_SS [c][k][qy][qx]                         36
+  //   I2   item (c,k,qx):  contract qy -> E_D / E_S [c,k][j][qx]                                    27
+  //   I1   item (c,k,j):   contract qx -> the 81 results into the cell's slots (as mf_spmv)         18
+  // mf_records27 runs E12 + E3 on u + du and stores F, J^(-2/3), 1/J of the 27 points: [cell][11][27].
+#ifndef MF27_OCC
+#define MF27_OCC 4
+#endif
+#ifndef MF27_ABL
+#define MF27_ABL 0 // timing-only ablations (wrong results): 2 no result stores, 4 every cell reads the records of cell 0 / 1, 8 ... gathers their x
+#endif
+  constexpr int Q27 = 27, H27 = 336; // points per cell; doubles of LDS per half-wave (R = 324, padded: the halves 16 banks apart; the
+                                     // gathered values X live in R's last 81 entries, which E12 -- their only reader -- does not write)
+  // S[q][a] = N_a(x_q), D[q][a] = N_a'(x_q) on the 3-point rule: uniform, scalar registers
+#define MF27_TABLES(t_)                                 \
+  double S27[3][3], D27[3][3];                          \
+  _Pragma("unroll") for (int q_ = 0; q_ < 3; ++q_)      \
+    _Pragma("unroll") for (int a_ = 0; a_ < 3; ++a_)    \
+    {                                                   \
+      S27[q_][a_] = (t_)[q_ * 3 + a_];                  \
+      D27[q_][a_] = (t_)[9 + q_ * 3 + a_];              \
+    }
+  // E12 + E3 of one half-wave: X (81 values [c][a], a = (k*3+j)*3+i) -> H, V at point `it` (lanes it < 27)
+  __device__ __forceinline__ void mf27_gradients(const double (&S27)[3][3], const double (&D27)[3][3], const double *__restrict__ tab,
+                                                 double *__restrict__ R, const double *__restrict__ X, const int it, const bool act, double H[3][3],
+                                                 double V[3])
+  {
+    const int ck = it / 3, qx = it - 3 * ck; // E12 item
+    // this lane's rows of the tables (row qx for the x-contraction, row qz for the z-contraction): per-lane loads -- a select
+    // over the uniform tables turns into a dynamically indexed private array, i.e. scratch
+    const int qzl = it / 9;
+    double    sx[3], dx[3], sz[3], dz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      {
+        sx[i] = tab[(act ? qx : 0) * 3 + i];
+        dx[i] = tab[9 + (act ? qx : 0) * 3 + i];
+        sz[i] = tab[(act ? qzl : 0) * 3 + i];
+        dz[i] = tab[9 + (act ? qzl : 0) * 3 + i];
+      }
+    if (act)
+      {
+        double as[3], ad[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          {
+            const double x0 = X[ck * 9 + j * 3], x1 = X[ck * 9 + j * 3 + 1], x2 = X[ck * 9 + j * 3 + 2];
+            as[j] = sx[0] * x0 + sx[1] * x1 + sx[2] * x2;
+            ad[j] = dx[0] * x0 + dx[1] * x1 + dx[2] * x2;
+          }
+#pragma unroll
+        for (int qy = 0; qy < 3; ++qy)
+          {
+            const int o  = ck * 9 + qy * 3 + qx;
+            R[o]         = S27[qy][0] * ad[0] + S27[qy][1] * ad[1] + S27[qy][2] * ad[2]; // d/dx
+            R[81 + o]    = D27[qy][0] * as[0] + D27[qy][1] * as[1] + D27[qy][2] * as[2]; // d/dy
+            R[162 + o]   = S27[qy][0] * as[0] + S27[qy][1] * as[1] + S27[qy][2] * as[2]; // value / d/dz
+          }
+      }
+    __syncthreads();
+    const int qz = it / 9, q9 = it - 9 * qz; // E3: item = point
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      {
+        H[c][0] = H[c][1] = H[c][2] = V[c] = 0.0;
+        if (act)
+#pragma unroll
+          for (int k = 0; k < 3; ++k)
+            {
+              const int    o   = (c * 3 + k) * 9 + q9;
+              const double bds = R[o], bsd = R[81 + o], bss = R[162 + o];
+              H[c][0] = fma(sz[k], bds, H[c][0]);
+              H[c][1] = fma(sz[k], bsd, H[c][1]);
+              H[c][2] = fma(dz[k], bss, H[c][2]);
+              V[c]    = fma(sz[k], bss, V[c]);
+            }
+      }
+    __syncthreads(); // B is consumed
+  }
+  // geometry of the cell at point (qx, qy, qz) of the 27-point rule: Ji = Jinv (row-major), detJ
+  template <bool BOX>
+  __device__ __forceinline__ void mf27_geometry(const MfParams &prm, const int64_t cell, const int it, double Ji[9], double &detJ)
+  {
+    if constexpr (BOX)
+      {
+        const double *__restrict__ cb = prm.cellbox + cell * 4;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+          Ji[k] = 0.0;
+        Ji[0] = cb[0], Ji[4] = cb[1], Ji[8] = cb[2];
+        detJ  = cb[3];
+      }
+    else
+      {
+        const double *__restrict__ cv = prm.cverts + cell * 24;
+        const int    qz = it / 9, qy = (it - 9 * qz) / 3, qx = it - 9 * qz - 3 * qy;
+        const double xiq[3] = {prm.tab27[21 + qx], prm.tab27[21 + qy], prm.tab27[21 + qz]};
+        double       verts[24], Jm[9];
+#pragma unroll
+        for (int k = 0; k < 24; ++k)
+          verts[k] = cv[k];
+        q1_jacobian<3>(verts, xiq, Jm);
+        detJ = det3x3(Jm);
+        inv3x3(Jm, detJ, Ji);
+      }
+  }
+
+  template <bool BOX, bool LAT>
+  __global__ __launch_bounds__(64, 4) void mf_records27(MfParams prm, const double *__restrict__ u, const double *__restrict__ du,
+                                                        double *__restrict__ rec27)
+  {
+    __shared__ double s_lds[2 * H27];
+    const int     lane = threadIdx.x, cw = lane >> 5, it = lane & 31;
+    const int64_t pair = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
+    if (pair * 2 >= prm.count)
+      return;
+    const int64_t cell = pair * 2 + cw;
+    const bool    act  = it < Q27 && cell < prm.count;
+    double *const R = s_lds + cw * H27, *const X = R + 243;
+    MF27_TABLES(prm.tab27)
+    if (act)
+      {
+        int32_t node;
+        if constexpr (LAT)
+          {
+            const int32_t node0 = lattice_node0(prm.lat, cell);
+            const int     k9 = it / 9, r9 = it - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
+            node               = node0 + i3 + j3 * prm.lat.nn0 + k9 * prm.lat.nn01;
+          }
+        else
+          node = prm.conn[cell * Q27 + it];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          X[c * Q27 + it] = u[int64_t(node) * 3 + c] + du[int64_t(node) * 3 + c]; // get_total_solution, :580-588
+      }
+    __syncthreads();
+    double H[3][3], V[3];
+    mf27_gradients(S27, D27, prm.tab27, R, X, it, act, H, V);
+    if (!act)
+      return;
+    double Ji[9], detJ, gu[9], F[9];
+    mf27_geometry<BOX>(prm, cell, it, Ji, detJ);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        gu[i * 3 + j] = H[i][0] * Ji[0 * 3 + j] + H[i][1] * Ji[1 * 3 + j] + H[i][2] * Ji[2 * 3 + j];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      F[k] = gu[k];
+    F[0] += 1.0, F[4] += 1.0, F[8] += 1.0;
+    const double J = det3x3(F), rJ = 1.0 / J, Jm = 1.0 / (cbrt(J) * cbrt(J));
+    double *__restrict__ g = rec27 + cell * int64_t(MF_NREC * Q27) + it;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      g[k * Q27] = F[k];
+    g[9 * Q27]  = Jm;
+    g[10 * Q27] = rJ;
+  }
+
+  template <bool BOX, bool LAT>
+  __global__ __launch_bounds__(64, MF27_OCC) void mf_spmv27(MfParams prm)
+  {
+    __shared__ double s_lds[2 * H27];
+    const int     lane = threadIdx.x, cw = lane >> 5, it = lane & 31;
+    const int64_t pair = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
+    if (pair * 2 >= prm.count)
+      return;
+    const int64_t cell = pair * 2 + cw;
+    const bool    act  = it < Q27 && cell < prm.count;
+    double *const R = s_lds + cw * H27, *const X = R + 243;
+    // gather x (constrained entries masked) and this lane's record
+    double rec[MF_NREC];
+#pragma unroll
+    for (int f = 0; f < MF_NREC; ++f)
+      rec[f] = 0.0;
+    rec[0] = rec[4] = rec[8] = rec[9] = rec[10] = 1.0; // (idle lanes: the identity, no NaN in flight)
+    int32_t ydst[3] = {0, 0, 0};
+    if (act)
+      {
+        int32_t node;
+        if constexpr (LAT)
+          {
+            const int32_t node0 = lattice_node0(prm.lat, (MF27_ABL & 8) ? int64_t(cw) : cell);
+            const int     k9 = it / 9, r9 = it - 9 * k9, j3 = r9 / 3, i3 = r9 - 3 * j3;
+            node               = node0 + i3 + j3 * prm.lat.nn0 + k9 * prm.lat.nn01;
+          }
+        else
+          node = prm.conn[cell * Q27 + it];
+        const int cm = prm.cmask[node];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          X[c * Q27 + it] = ((cm >> c) & 1) ? 0.0 : prm.x[int64_t(node) * 3 + c];
+        const double *__restrict__ rp = prm.qrec27 + ((MF27_ABL & 4) ? int64_t(cw) : cell) * int64_t(MF_NREC * Q27) + it;
+#pragma unroll
+        for (int f = 0; f < MF_NREC; ++f)
+          rec[f] = __builtin_nontemporal_load(&rp[f * Q27]);
+        // I1's item of this lane: line (c,k,j) = it, its three nodes i
+        const int lkj = it - 9 * (it / 9);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          ydst[i] = prm.dst[cell * Q27 + lkj * 3 + i];
+      }
+    MF27_TABLES(prm.tab27)
+    __syncthreads();
+    double H[3][3], V[3];
+    mf27_gradients(S27, D27, prm.tab27, R, X, it, act, H, V);
+    // ---- point stage: Q = JxW S M^T (as mf_spmv), 12 numbers per point on top of B
+    {
+      const int    qz = it / 9, qy = (it - 9 * qz) / 3, qx = it - 9 * qz - 3 * qy;
+      const double wq = act ? prm.tab27[18 + qx] * prm.tab27[18 + qy] * prm.tab27[18 + qz] : 0.0;
+      double       Finv[9], tau[6], tiso[6], cII, cS, Ji[9], detJ = 1.0, M[9];
+      neo_hooke_from_F<3>(rec, det3x3(rec), rec[9], rec[10], prm.mu, prm.kappa, Finv, tau, tiso, cII, cS);
+      if (act)
+        mf27_geometry<BOX>(prm, cell, it, Ji, detJ);
+      else
+        {
+#pragma unroll
+          for (int k = 0; k < 9; ++k)
+            Ji[k] = 0.0;
+        }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          M[i * 3 + j] = BOX ? Ji[i * 4] * Finv[i * 3 + j] :
+                               Ji[i * 3 + 0] * Finv[0 * 3 + j] + Ji[i * 3 + 1] * Finv[1 * 3 + j] + Ji[i * 3 + 2] * Finv[2 * 3 + j];
+      const double w = detJ * wq, wcII = w * cII, cs2 = 0.5 * cS;
+      double       h[3][3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          h[j][k] = H[j][0] * M[k] + H[j][1] * M[3 + k] + H[j][2] * M[6 + k];
+      const double pv  = (tau[0] + tau[1] + tau[2]) * (1.0 / 3.0);
+      const double ti0 = tau[0] - pv, ti1 = tau[1] - pv, ti2 = tau[2] - pv;
+      const double trh = h[0][0] + h[1][1] + h[2][2];
+      const double th  = ti0 * h[0][0] + ti1 * h[1][1] + ti2 * h[2][2] + tau[3] * (h[0][1] + h[1][0]) + tau[4] * (h[0][2] + h[2][0]) +
+                        tau[5] * (h[1][2] + h[2][1]);
+      const double aI = wcII * trh - (2.0 / 3.0) * w * th;
+      const double m3 = -(2.0 / 3.0) * trh;
+      const double Tt[3][3] = {{tau[0], tau[3], tau[4]}, {tau[3], tau[1], tau[5]}, {tau[4], tau[5], tau[2]}};
+      const double Ti[3][3] = {{ti0, tau[3], tau[4]}, {tau[3], ti1, tau[5]}, {tau[4], tau[5], ti2}};
+      const double wm       = prm.mass * w;
+      if (act)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          {
+            double Sm[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+              {
+                const double v = m3 * Ti[i][j] + cs2 * (h[i][j] + h[j][i]) + h[i][0] * Tt[0][j] + h[i][1] * Tt[1][j] + h[i][2] * Tt[2][j];
+                Sm[j]          = w * v + (i == j ? aI : 0.0);
+              }
+#pragma unroll
+            for (int l = 0; l < 3; ++l)
+              R[(i * 4 + l) * Q27 + it] = Sm[0] * M[l * 3] + Sm[1] * M[l * 3 + 1] + Sm[2] * M[l * 3 + 2];
+            R[(i * 4 + 3) * Q27 + it] = wm * V[i];
+          }
+    }
+    __syncthreads();
+    // ---- I3: contract qz.  item (c, q9 = qy*3+qx)
+    {
+      const int c = it / 9, q9 = it - 9 * c;
+      double    v[4][3];
+      if (act)
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int z = 0; z < 3; ++z)
+            v[d][z] = R[(c * 4 + d) * Q27 + z * 9 + q9];
+      __syncthreads(); // Q is consumed: C goes on top of it
+      if (act)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          {
+            double cds = 0.0, csd = 0.0, css = 0.0;
+#pragma unroll
+            for (int z = 0; z < 3; ++z)
+              {
+                cds = fma(S27[z][k], v[0][z], cds);
+                csd = fma(S27[z][k], v[1][z], csd);
+                css = fma(D27[z][k], v[2][z], css);
+                css = fma(S27[z][k], v[3][z], css);
+              }
+            R[(c * 3 + 0) * Q27 + k * 9 + q9] = cds;
+            R[(c * 3 + 1) * Q27 + k * 9 + q9] = csd;
+            R[(c * 3 + 2) * Q27 + k * 9 + q9] = css;
+          }
+    }
+    __syncthreads();
+    // ---- I2: contract qy.  item (c, k, qx)
+    {
+      const int ck = it / 3, qx = it - 3 * ck, c = ck / 3, k = ck - 3 * c;
+      double    cds[3], csd[3], css[3];
+      if (act)
+#pragma unroll
+        for (int qy = 0; qy < 3; ++qy)
+          {
+            const int o = k * 9 + qy * 3 + qx;
+            cds[qy]     = R[(c * 3 + 0) * Q27 + o];
+            csd[qy]     = R[(c * 3 + 1) * Q27 + o];
+            css[qy]     = R[(c * 3 + 2) * Q27 + o];
+          }
+      __syncthreads(); // C is consumed: E goes on top of it
+      if (act)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          {
+            double ed = 0.0, es = 0.0;
+#pragma unroll
+            for (int qy = 0; qy < 3; ++qy)
+              {
+                ed = fma(S27[qy][j], cds[qy], ed);
+                es = fma(D27[qy][j], csd[qy], es);
+                es = fma(S27[qy][j], css[qy], es);
+              }
+            R[ck * 9 + j * 3 + qx]      = ed;
+            R[81 + ck * 9 + j * 3 + qx] = es;
+          }
+    }
+    __syncthreads();
+    // ---- I1: contract qx, results into the cell's slots.  item = line (c,k,j) = it
+    if (act)
+      {
+        const int lc = it / 9;
+        double    ed[3], es[3];
+#pragma unroll
+        for (int qx = 0; qx < 3; ++qx)
+          {
+            ed[qx] = R[it * 3 + qx];
+            es[qx] = R[81 + it * 3 + qx];
+          }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+          {
+            double yv = 0.0;
+#pragma unroll
+            for (int qx = 0; qx < 3; ++qx)
+              {
+                yv = fma(D27[qx][i], ed[qx], yv);
+                yv = fma(S27[qx][i], es[qx], yv);
+              }
+            if (!(MF27_ABL & 2) || yv == -1.2345678e30)
+              prm.yc[int64_t(ydst[i]) * 3 + lc] = yv;
+          }
+      }
+  }
+
   // system_rhs from the cells' residual slots (point pass in one launch): rhs = 0 - r_1 - r_2 - ... in slot order, the
   // subtractions of the colour-by-colour update in their order; constrained rows get no rhs (:769-773).  One thread per dof.
   __global__ __launch_bounds__(256) void residual_gather(const double *__restrict__ slots3, const int32_t *__restrict__ slot_base,
+                                                         const int32_t *__restrict__ slot_src,
                                                          const uint8_t *__restrict__ cmask, double *rhs, int64_t ndofs)
   {
     const int64_t g = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -3537,7 +3900,7 @@ namespace mi
       {
         const int32_t b0 = slot_base[n], b1 = slot_base[n + 1];
         for (int32_t k = b0; k < b1; ++k)
-          s = s - slots3[int64_t(k) * 3 + c];
+          s = s - slots3[int64_t(slot_src ? slot_src[k] : k) * 3 + c];
       }
     rhs[g] = s;
   }
@@ -6370,10 +6733,35 @@ namespace mi
     q.xcd_chunk = (p.cell_count + 7) / 8;
     hipLaunchKernelGGL((assemble_q2sf<true, 1024>), dim3(q.xcd_chunk * 8), dim3(64), 0, s, q);
   }
-  void launch_residual_gather(const double *slots3, const int32_t *slot_base, const uint8_t *cmask, double *rhs, int64_t ndofs,
-                              hipStream_t s)
+  void launch_residual_gather(const double *slots3, const int32_t *slot_base, const int32_t *slot_src, const uint8_t *cmask, double *rhs,
+                              int64_t ndofs, hipStream_t s)
   {
-    hipLaunchKernelGGL(residual_gather, dim3(int((ndofs + 255) / 256)), dim3(256), 0, s, slots3, slot_base, cmask, rhs, ndofs);
+    hipLaunchKernelGGL(residual_gather, dim3(int((ndofs + 255) / 256)), dim3(256), 0, s, slots3, slot_base, slot_src, cmask, rhs, ndofs);
+  }
+  void launch_mf_spmv27(const MfParams &p, int32_t cell_count, hipStream_t s, hipEvent_t ev_start, hipEvent_t ev_stop)
+  {
+    if (cell_count <= 0)
+      return;
+    MfParams q  = p;
+    q.count     = cell_count;
+    q.xcd_chunk = ((cell_count + 1) / 2 + 7) / 8; // PAIRS of cells per XCD
+    auto *kern  = q.lat.ncol > 0 ? (q.cellbox ? mf_spmv27<true, true> : mf_spmv27<false, true>) :
+                                   (q.cellbox ? mf_spmv27<true, false> : mf_spmv27<false, false>);
+    if (ev_start || ev_stop)
+      hipExtLaunchKernelGGL(kern, dim3(q.xcd_chunk * 8), dim3(64), 0, s, ev_start, ev_stop, 0, q);
+    else
+      hipLaunchKernelGGL(kern, dim3(q.xcd_chunk * 8), dim3(64), 0, s, q);
+  }
+  void launch_mf_records27(const MfParams &p, const double *u, const double *du, double *rec27, int32_t cell_count, hipStream_t s)
+  {
+    if (cell_count <= 0)
+      return;
+    MfParams q  = p;
+    q.count     = cell_count;
+    q.xcd_chunk = ((cell_count + 1) / 2 + 7) / 8;
+    auto *kern  = q.lat.ncol > 0 ? (q.cellbox ? mf_records27<true, true> : mf_records27<false, true>) :
+                                   (q.cellbox ? mf_records27<true, false> : mf_records27<false, false>);
+    hipLaunchKernelGGL(kern, dim3(q.xcd_chunk * 8), dim3(64), 0, s, q, u, du, rec27);
   }
   void launch_mf_diag(const MfParams &p, double *slots6, int32_t cell_count, hipStream_t s)
   {
@@ -6387,10 +6775,10 @@ namespace mi
     else
       hipLaunchKernelGGL(mf_diag<false>, dim3(q.xcd_chunk * 8), dim3(64), 0, s, q, slots6);
   }
-  void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const uint8_t *cmask, const int32_t *diagpos,
-                             double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s)
+  void launch_mf_diag_gather(const double *slots6, const int32_t *slot_base, const int32_t *slot_src, const uint8_t *cmask,
+                             const int32_t *diagpos, double *blk, double *dinv, double *dinv_blk, double *sym6, int64_t nnodes, hipStream_t s)
   {
-    hipLaunchKernelGGL(mf_diag_gather, dim3(int((nnodes + 255) / 256)), dim3(256), 0, s, slots6, slot_base, cmask, diagpos, blk,
+    hipLaunchKernelGGL(mf_diag_gather, dim3(int((nnodes + 255) / 256)), dim3(256), 0, s, slots6, slot_base, slot_src, cmask, diagpos, blk,
                        dinv, dinv_blk, sym6, nnodes);
   }
 

@@ -75,7 +75,7 @@ def test_oracle_reproduces_config2_fixture():
 
 
 def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, slabs=1, cut_axis=0, dist_nodes=None,
-               smoother_precision=64, fine_level=0):
+               smoother_precision=64, fine_level=0, quadrature=None):
     g = _g()
     n = int(g[name + "_cells"])
     # (make_golden_big.distortion: vertices moved by 8 % of the cell size, seeded)
@@ -87,6 +87,8 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, s
     if slabs > 1:  # levels cut into slabs: fine + Q1 on the same cells (+ the first coarsened level when forced / big enough)
         assert G.get_tuning("mg_distributed_levels") == (2 if degree > 1 else 1) + (1 if dist_nodes == 0 else 0)
     G.set_tuning("cg_warm_start", start)  # 0: the library's default; 2: what the executable and bench.py set
+    if quadrature is not None:  # (default 3 since round 6: the smoother's fine-level operator with 27 Gauss points)
+        G.set_tuning("smoother_quadrature", quadrature)
     if smoother_precision != 64:
         G.set_tuning("smoother_precision", smoother_precision)
     if fine_level:  # round 6: no assembled fine tangent -- records + residual + diagonal blocks, every product on mf_spmv
@@ -108,6 +110,8 @@ def _nonlinear(name, tol_u, tol_va, start=0, distorted=False, dim=3, degree=2, s
     # 3D Q2: the matrix-free smoother was what ran; the other elements smooth with the assembled matrix
     if slabs == 1 or fine_level:  # (a slab of a quarter of this block is below the size at which the matrix-free form is chosen)
         assert G.get_tuning("smoother_operator_active") == (2 if (dim, degree) == (3, 2) else 0)
+        if (dim, degree) == (3, 2) and smoother_precision == 64:  # ... from the 27-point records unless asked otherwise
+            assert G.get_tuning("smoother_quadrature_active") == (quadrature or 3)
     if fine_level:  # nothing was assembled: no matrix to export
         with pytest.raises(M.MiError):
             G.csr()
@@ -167,6 +171,16 @@ def test_gpu_matrix_free_fine_level_against_the_oracle(name, slabs, cut_axis, st
     formed at the first tangent of a time step and kept over its Newton iterations: the policy bench.py's
     with_matrix_free_fine_level and the executable (MI_FINE_LEVEL=1) run with."""
     _nonlinear(name, 1e-8, 1e-6, start, distorted=distorted, slabs=slabs, cut_axis=cut_axis, fine_level=mode)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,slabs,fine_level,distorted", [("blk24", 1, 0, False), ("blk24d", 1, 0, True), ("cfg3", 1, 0, False),
+                                                             ("cfg3", 4, 2, False), ("cfg4s", 1, 2, False)])
+def test_gpu_smoother_with_the_assembly_quadrature_against_the_oracle(name, slabs, fine_level, distorted):
+    """the multigrid smoother's fine-level operator with the assembly's 4 x 4 x 4 Gauss points (tuning "smoother_quadrature" 4: the
+    smoother of rounds 3-5, mf_spmv) -- the library's default since round 6 is the 27-point rule (mf_spmv27), which every
+    other test of this file runs under; both against the same oracle steps at the same tolerances"""
+    _nonlinear(name, 1e-8, 1e-6, 2, distorted=distorted, slabs=slabs, fine_level=fine_level, quadrature=4)
 
 
 @pytest.mark.gpu

@@ -311,6 +311,67 @@ def test_matrix_free_fine_level_against_the_oracle(perturb_amp, reps, slabs):
     assert _relmax(G.diagonal_blocks(), D_o) < TOL_ASM
 
 
+@pytest.mark.parametrize("perturb_amp,slabs", [(0.0, 1), (0.05, 1), (0.0, 3)])
+def test_smoother_quadrature_3_operator_and_solves(perturb_amp, slabs):
+    """round 6, tuning "smoother_quadrature" 3 (the library's default): the multigrid smoother's fine-level operator A' is the
+    same tangent integrated with 3 x 3 x 3 Gauss points (mf_spmv27, two cells per wave, from records of its own), the CG's
+    operator A keeps the assembly's 4 x 4 x 4 [REF nonlinear_elasticity.cc:74].  (1) On undeformed boxes the integrand is a
+    polynomial the 3-point rule integrates exactly: A' x = A x to rounding -- the kernel, its records and its tables against the
+    64-point product.  (2) On a deformed state (and on distorted cells) the two differ by the quadrature error of a smooth
+    integrand only.  (3) A preconditioner-side choice: the multigrid-PCG converges to the same update with either rule, in
+    the same number of iterations (+-1), on one slab and on three."""
+    reps = (6, 5, 7)
+    roles = [O.FACE_CLAMPED, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_INTERFACE, O.FACE_ZCLAMP, O.FACE_INTERFACE]
+    P, G = _pair(3, 2, reps, perturb_amp=perturb_amp, seed=31, roles=roles, slabs=slabs)
+    G.set_tuning("precond", 1)
+    G.set_tuning("element_tangents", 2)
+    assert G.get_tuning("smoother_quadrature") == 3
+    rng = np.random.default_rng(32)
+    x = rng.standard_normal(G.n)
+    # (1) / (2): the operators
+    G.set_interface_traction((0.0, -2e3, 0.0))
+    G.update_acceleration()
+    G.assemble()
+    assert G.get_tuning("smoother_quadrature_active") == 3
+    y4 = G.spmv(x)
+    G.set_tuning("spmv_as_smoother", 1)
+    y3 = G.spmv(x)
+    assert np.array_equal(G.spmv(x), y3)  # fixed summation order
+    G.set_tuning("spmv_as_smoother", 0)
+    if perturb_amp == 0.0:
+        assert _relmax(y3, y4) < 1e-13
+    else:
+        assert 1e-9 < _relmax(y3, y4) < 2e-2
+    # a smooth deformation: the quadrature error of a smooth integrand
+    X = G.coords
+    u = np.zeros((G.nnodes, 3))
+    u[:, 1] = 0.02 * X[:, 0] ** 2
+    u[:, 2] = 0.01 * np.sin(3 * X[:, 0]) * X[:, 1]
+    u = u.reshape(-1) * ~G.constrained
+    G.set(M.V_U, u)
+    G.update_acceleration()
+    G.assemble()
+    G.set_tuning("spmv_as_smoother", 1)
+    d = _relmax(G.spmv(x), G.spmv(x) * 0 + G.spmv(x))  # (same call twice: repeatable)
+    assert d == 0.0
+    y3 = G.spmv(x)
+    G.set_tuning("spmv_as_smoother", 0)
+    y4 = G.spmv(x)
+    assert 1e-12 < _relmax(y3, y4) < 5e-3
+    # (3): the solves
+    sols = {}
+    for q in (4, 3):
+        G.set_tuning("smoother_quadrature", q)
+        G.newton_begin_step()
+        G.update_acceleration()
+        G.assemble()
+        assert G.get_tuning("smoother_quadrature_active") == q
+        rc, its, res = G.cg_solve(1e-11, 4 * G.n)
+        assert rc == 0 and 0 < its < 60
+        sols[q] = (G.get(M.V_NEWTON), its)
+    assert _relmax(sols[3][0], sols[4][0]) < 1e-8 and abs(sols[3][1] - sols[4][1]) <= 1
+
+
 def test_fp32_smoother_records_follow_the_kernel_that_wrote_them():
     """only the sum-factorised kernel writes the fp32 point records; with the node-pair kernel ("asm_variant" 9)
     the opt-in fp32 smoother product must fall back to the fp64 records instead of multiplying with stale / uninitialised

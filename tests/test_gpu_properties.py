@@ -116,10 +116,17 @@ def test_fullsize_decomposition_invariance(config3):
     assert abs(rn4 - np.linalg.norm(r1[~G.constrained])) / rn4 < 1e-12
     x = np.random.default_rng(5).standard_normal(G.n)
     assert np.abs(G4.spmv(x) - G.spmv(x)).max() / np.abs(G.spmv(x)).max() < 1e-13
-    rc, its4, _ = G4.cg_solve(rel_tol=1e-8)
+    # (the slabs are below the size at which the smoother multiplies matrix-free: they smooth with the assembled operator, the
+    # undecomposed run with the 27-point form of it -- on this grid-scale-noisy state the two differ by a percent, so the Krylov
+    # paths differ: both solutions are held against the TRUE residual bound of the stopping rule, and against each other at
+    # the accuracy that bound implies)
+    rc, its4, _ = G4.cg_solve(rel_tol=1e-10)
     G.set(M.V_NEWTON, np.zeros(G.n))
-    rc1, its1, _ = G.cg_solve(rel_tol=1e-8)
-    assert rc == 0 and rc1 == 0 and abs(its4 - its1) <= 1
+    rc1, its1, _ = G.cg_solve(rel_tol=1e-10)
+    assert rc == 0 and rc1 == 0 and abs(its4 - its1) <= 2
+    b = G.get(M.V_RHS)
+    for H in (G, G4):
+        assert np.linalg.norm(b - H.spmv(H.get(M.V_NEWTON))) <= 1.5e-10 * np.linalg.norm(b)
     assert np.abs(G4.get(M.V_NEWTON) - G.get(M.V_NEWTON)).max() / np.abs(G.get(M.V_NEWTON)).max() < 1e-6
 
 
