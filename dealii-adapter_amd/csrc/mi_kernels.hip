@@ -3144,6 +3144,35 @@ namespace mi
 #undef MF_STAMP
   }
 
+  // Sum of the contributions of a node's cells to component c, in processing order.  Node-major slots: a contiguous run.
+  // Cell-major slots (MfParams::slot_src): the positions come from an index -- all (up to eight: a vertex node of a 3D mesh)
+  // index loads are issued together, then all value loads, then the additions in order: two dependent round trips per node
+  // instead of two per contribution; the same additions in the same order.
+  __device__ __forceinline__ double mf_slot_sum(const MfParams &prm, const int32_t b0, const int32_t b1, const int c)
+  {
+    if (prm.slot_src && b1 - b0 <= 8)
+      {
+        const int cnt = b1 - b0;
+        int32_t   idx[8];
+        double    v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          idx[j] = prm.slot_src[j < cnt ? b0 + j : b0];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          v[j] = prm.yc[int64_t(idx[j]) * 3 + c];
+        double s = v[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j)
+          s = j < cnt ? s + v[j] : s;
+        return s;
+      }
+    double s = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
+    for (int32_t k = b0 + 1; k < b1; ++k)
+      s = s + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
+    return s;
+  }
+
   // y = sum of the cells' contributions, node by node in slot order (= processing order of the cells: the order of the
   // colour-by-colour update); constrained rows: diag(K) x from the assembled tangent.  One thread per DOF.
   __global__ __launch_bounds__(256) void mf_gather(MfParams prm, int64_t ndofs)
@@ -3160,10 +3189,7 @@ namespace mi
         return;
       }
     const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-    double        s  = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
-    for (int32_t k = b0 + 1; k < b1; ++k)
-      s = s + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
-    prm.y[g] = s;
+    prm.y[g] = mf_slot_sum(prm, b0, b1, c);
   }
 
   // the same sum fused with its consumer in the multigrid smoother: q = (K x) from the slots, then the Chebyshev step
@@ -3189,9 +3215,7 @@ namespace mi
         else
           {
             const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-            q                = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
-            for (int32_t k = b0 + 1; k < b1; ++k)
-              q = q + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
+            q                = mf_slot_sum(prm, b0, b1, c);
           }
         res = b[g] - q;
       }
@@ -3248,9 +3272,7 @@ namespace mi
         else
           {
             const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-            q                = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
-            for (int32_t k = b0 + 1; k < b1; ++k)
-              q = q + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
+            q                = mf_slot_sum(prm, b0, b1, c);
           }
         res = b[g] - q;
       }
@@ -3290,9 +3312,7 @@ namespace mi
         else
           {
             const int32_t b0 = prm.slot_base[n], b1 = prm.slot_base[n + 1];
-            s                = prm.yc[int64_t(prm.slot_src ? prm.slot_src[b0] : b0) * 3 + c];
-            for (int32_t k = b0 + 1; k < b1; ++k)
-              s = s + prm.yc[int64_t(prm.slot_src ? prm.slot_src[k] : k) * 3 + c];
+            s                = mf_slot_sum(prm, b0, b1, c);
           }
         prm.y[g] = s;
         if (g >= own0 && g < own0 + own_n)
@@ -3731,11 +3751,11 @@ namespace mi
 #pragma unroll
         for (int f = 0; f < MF_NREC; ++f)
           rec[f] = __builtin_nontemporal_load(&rp[f * Q27]);
-        // I1's item of this lane: line (c,k,j) = it, its three nodes i
+        // I1's item of this lane: line (c,k,j) = it, its three nodes i (cell-major slots: no table to read)
         const int lkj = it - 9 * (it / 9);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          ydst[i] = prm.dst[cell * Q27 + lkj * 3 + i];
+          ydst[i] = prm.slot_src ? int32_t(cell) * Q27 + lkj * 3 + i : prm.dst[cell * Q27 + lkj * 3 + i];
       }
     MF27_TABLES(prm.tab27)
     __syncthreads();

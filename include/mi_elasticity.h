@@ -324,6 +324,12 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  launch after the exchange (same bits)
  *  halo_skip            1 | 0                      no exchange before a product whose operand's ghost planes are        -
  *                                                  current (first post-smoothing step) | always exchange (same bits)
+ *  smoother_quadrature  3 | 4                      Gauss points per direction of the multigrid smoother's fine-level       -
+ *                                                  operator (3D Q2, where it multiplies matrix-free): the full-order
+ *                                                  3 x 3 x 3 rule (mf_spmv27, two cells per wave, records of its own; the
+ *                                                  V-cycle's residual and eigenvalue estimate use it too) | the assembly's
+ *                                                  4 x 4 x 4 (nonlinear_elasticity.cc:74).  Preconditioner side only, fp64:
+ *                                                  the CG's operator, residuals and the assembly always integrate with 4
  *  smoother_precision   64 | 32                    the smoother's matrix-free fine-level products in fp64 | in fp32      -
  *                                                  arithmetic on fp32 point records (opt-in; everything else stays fp64;
  *                                                  takes effect with the next tangent assembly)
@@ -354,6 +360,10 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  from the point records (profiles/r06/asm_split_ab_n59.txt: slower)
  *  mg_fuse              1 | 0 | 2                  smoother update fused into the product on small levels | never |     MI_MG_FUSE
  *                                                  always
+ *  mf_slots_cell_major  -1 | 0 | 1                 result slots of the matrix-free kernels: follows smoother_quadrature     -
+ *                                                  (3: cell-major, a cell's 81 results one contiguous run, the gathers read
+ *                                                  through an index; 4: node-major) | forced (A/B)
+ *  spmv_as_smoother     0 | 1                      tests: mi_spmv / mi_bench_spmv apply the smoother's form of the operator -
  *  mg_scale_lmax_percent 10..400                   tests: spoil the eigenvalue estimates once                           -
  *
  * Further switches of the experiments build only (read at creation; diagnostics): MI_MG_NU, MI_MG_NU_COARSE, MI_MG_RATIO, MI_MG_KIND,
