@@ -831,7 +831,8 @@ def main():
             # opt-in A/B beside the headline: the smoother's matrix-free products in fp32 (preconditioner-only change)
             out["config"]["with_smoother_precision_f32"], _ = side(smoother_precision="f32")
             out["config"]["with_smoother_precision_f32"]["note"] = (
-                "opt-in, not the headline: fp32 arithmetic and records in the smoother's fine-level products only")
+                "opt-in, not the headline: fp32 arithmetic and records in the smoother's fine-level products only -- on the 64-point "
+                "kernel (mf_spmv<..., float>), i.e. to be compared with with_smoother_quadrature_4, not with the 27-point headline")
         if args.cg_operator == "assembled" and args.fine_level == "assembled" and n >= 24:
             # opt-in A/B beside the headline: the CG's own product on the element tangents too (no sliced-ELL copy);
             # not the default because north_star names the product on the assembled matrix

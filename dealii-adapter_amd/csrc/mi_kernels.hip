@@ -3666,12 +3666,14 @@ namespace mi
                                                         double *__restrict__ rec27)
   {
     __shared__ double s_lds[2 * H27];
-    const int     lane = threadIdx.x, cw = lane >> 5, it = lane & 31;
+    // (idle lanes -- five per half, and the second half of the last wave of an odd cell count -- MIRROR work item 26 / the last
+    // cell: they compute and store the same numbers to the same places as the lane they mirror, so no stage needs a branch)
+    const int     lane = threadIdx.x, cw = lane >> 5, it = (lane & 31) < Q27 ? (lane & 31) : Q27 - 1;
     const int64_t pair = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
     if (pair * 2 >= prm.count)
       return;
-    const int64_t cell = pair * 2 + cw;
-    const bool    act  = it < Q27 && cell < prm.count;
+    const int64_t cell = pair * 2 + cw < prm.count ? pair * 2 + cw : int64_t(prm.count) - 1;
+    constexpr bool act = true;
     double *const R = s_lds + cw * H27, *const X = R + 243;
     MF27_TABLES(prm.tab27)
     if (act)
@@ -3718,12 +3720,14 @@ namespace mi
   __global__ __launch_bounds__(64, MF27_OCC) void mf_spmv27(MfParams prm)
   {
     __shared__ double s_lds[2 * H27];
-    const int     lane = threadIdx.x, cw = lane >> 5, it = lane & 31;
+    // (idle lanes -- five per half, and the second half of the last wave of an odd cell count -- MIRROR work item 26 / the last
+    // cell: they compute and store the same numbers to the same places as the lane they mirror, so no stage needs a branch)
+    const int     lane = threadIdx.x, cw = lane >> 5, it = (lane & 31) < Q27 ? (lane & 31) : Q27 - 1;
     const int64_t pair = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
     if (pair * 2 >= prm.count)
       return;
-    const int64_t cell = pair * 2 + cw;
-    const bool    act  = it < Q27 && cell < prm.count;
+    const int64_t cell = pair * 2 + cw < prm.count ? pair * 2 + cw : int64_t(prm.count) - 1;
+    constexpr bool act = true;
     double *const R = s_lds + cw * H27, *const X = R + 243;
     // gather x (constrained entries masked) and this lane's record
     double rec[MF_NREC];

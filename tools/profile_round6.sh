@@ -38,6 +38,12 @@ done
 timeout 900 python bench.py --steps 4 --warmup 2 --cpu-cells 0 --slabs 8 --scaling weak 2>/dev/null | tail -1 > "$OUT/emulated_slabs/weak_slabs8.json"
 timeout 900 python bench.py --steps 4 --warmup 2 --cpu-cells 0 --slabs 8 --scaling weak --fine-level matrix-free 2>/dev/null | tail -1 > "$OUT/emulated_slabs/weak_slabs8_matrix_free_fine_level.json"
 timeout 600 python tools/r6_mf_fine_check.py 59 > "$OUT/matrix_free_fine_level_check_n59.txt" 2>&1
+timeout 600 python tools/r6_quad3_check.py 59 > "$OUT/smoother_quadrature_check_n59.txt" 2>&1
+timeout 600 python tools/r6_quad3_check.py 24 d > "$OUT/smoother_quadrature_check_n24_distorted.txt" 2>&1
+PMC_SCRIPT="tools/r6_quad3_check.py 59" timeout 900 bash tools/pmc_mf.sh "mf_spmv27" > /dev/null 2>&1; cp gpurun_out/pmc_mf.json "$OUT/pmc_counters_mf_spmv27_n59.json"
+PMC_SCRIPT="tools/r6_mf_fine_check.py 59" timeout 900 bash tools/pmc_mf.sh "mf_diag<" > /dev/null 2>&1; cp gpurun_out/pmc_mf.json "$OUT/pmc_counters_mf_diag_n59.json"
+timeout 900 python tools/long_run_policies.py 59 60 > "$OUT/long_run_60_steps_headline.txt" 2>&1
+FINE=1 timeout 900 python tools/long_run_policies.py 59 60 > "$OUT/long_run_60_steps_matrix_free_fine_level.txt" 2>&1
 timeout 900 python tools/rank_share.py > "$OUT/rank_share_n59.txt" 2>&1
 if [ -f dealii-adapter_amd/libmi_elasticity_exp.so ]; then
   MI_LIB=$PWD/dealii-adapter_amd/libmi_elasticity_exp.so MI_ASM_STAMPS=1 timeout 600 python tools/r6_asm_split.py 59 > "$OUT/asm_split_stamps_n59.txt" 2>&1
