@@ -3560,7 +3560,7 @@ namespace mi
   //   I1   item (c,k,j):   contract qx -> the 81 results into the cell's slots (as mf_spmv)         18
   // mf_records27 runs E12 + E3 on u + du and stores F, J^(-2/3), 1/J of the 27 points: [cell][11][27].
 #ifndef MF27_OCC
-#define MF27_OCC 4
+#define MF27_OCC 5 // waves per SIMD of mf_spmv27 on box meshes: 96 VGPRs with one spilled double (0.196 -> 0.190 ms); 6 spills 76 bytes
 #endif
 #ifndef MF27_ABL
 #define MF27_ABL 0 // timing-only ablations (wrong results): 2 no result stores, 4 every cell reads the records of cell 0 / 1, 8 ... gathers their x
@@ -3607,14 +3607,14 @@ namespace mi
 #pragma unroll
         for (int qy = 0; qy < 3; ++qy)
           {
-            const int o  = ck * 9 + qy * 3 + qx;
+            const int o  = qy * 27 + it; // B[kind][qy][(c,k)][qx]: the lanes of a store are consecutive (conflict free)
             R[o]         = S27[qy][0] * ad[0] + S27[qy][1] * ad[1] + S27[qy][2] * ad[2]; // d/dx
             R[81 + o]    = D27[qy][0] * as[0] + D27[qy][1] * as[1] + D27[qy][2] * as[2]; // d/dy
             R[162 + o]   = S27[qy][0] * as[0] + S27[qy][1] * as[1] + S27[qy][2] * as[2]; // value / d/dz
           }
       }
     __syncthreads();
-    const int qz = it / 9, q9 = it - 9 * qz; // E3: item = point
+    const int qz = it / 9, q9 = it - 9 * qz, qy3 = q9 / 3, qx3 = q9 - 3 * qy3; // E3: item = point
 #pragma unroll
     for (int c = 0; c < 3; ++c)
       {
@@ -3623,7 +3623,7 @@ namespace mi
 #pragma unroll
           for (int k = 0; k < 3; ++k)
             {
-              const int    o   = (c * 3 + k) * 9 + q9;
+              const int    o   = qy3 * 27 + (c * 3 + k) * 3 + qx3;
               const double bds = R[o], bsd = R[81 + o], bss = R[162 + o];
               H[c][0] = fma(sz[k], bds, H[c][0]);
               H[c][1] = fma(sz[k], bsd, H[c][1]);
@@ -3717,7 +3717,7 @@ namespace mi
   }
 
   template <bool BOX, bool LAT>
-  __global__ __launch_bounds__(64, MF27_OCC) void mf_spmv27(MfParams prm)
+  __global__ __launch_bounds__(64, BOX ? MF27_OCC : 4) void mf_spmv27(MfParams prm)
   {
     __shared__ double s_lds[2 * H27];
     // (idle lanes -- five per half, and the second half of the last wave of an odd cell count -- MIRROR work item 26 / the last
@@ -3844,9 +3844,9 @@ namespace mi
                 css = fma(D27[z][k], v[2][z], css);
                 css = fma(S27[z][k], v[3][z], css);
               }
-            R[(c * 3 + 0) * Q27 + k * 9 + q9] = cds;
-            R[(c * 3 + 1) * Q27 + k * 9 + q9] = csd;
-            R[(c * 3 + 2) * Q27 + k * 9 + q9] = css;
+            R[(0 * 3 + k) * Q27 + it] = cds; // C[kind][k][c][qy][qx]: consecutive lanes
+            R[(1 * 3 + k) * Q27 + it] = csd;
+            R[(2 * 3 + k) * Q27 + it] = css;
           }
     }
     __syncthreads();
@@ -3858,10 +3858,10 @@ namespace mi
 #pragma unroll
         for (int qy = 0; qy < 3; ++qy)
           {
-            const int o = k * 9 + qy * 3 + qx;
-            cds[qy]     = R[(c * 3 + 0) * Q27 + o];
-            csd[qy]     = R[(c * 3 + 1) * Q27 + o];
-            css[qy]     = R[(c * 3 + 2) * Q27 + o];
+            const int o = k * Q27 + c * 9 + qy * 3 + qx;
+            cds[qy]     = R[0 * 81 + o];
+            csd[qy]     = R[1 * 81 + o];
+            css[qy]     = R[2 * 81 + o];
           }
       __syncthreads(); // C is consumed: E goes on top of it
       if (act)
@@ -3876,21 +3876,21 @@ namespace mi
                 es = fma(D27[qy][j], csd[qy], es);
                 es = fma(S27[qy][j], css[qy], es);
               }
-            R[ck * 9 + j * 3 + qx]      = ed;
-            R[81 + ck * 9 + j * 3 + qx] = es;
+            R[j * Q27 + it]      = ed; // E[kind][j][(c,k)][qx]: consecutive lanes
+            R[81 + j * Q27 + it] = es;
           }
     }
     __syncthreads();
     // ---- I1: contract qx, results into the cell's slots.  item = line (c,k,j) = it
     if (act)
       {
-        const int lc = it / 9;
+        const int lc = it / 9, ckl = it / 3, jl = it - 3 * ckl; // the line (c,k,j)
         double    ed[3], es[3];
 #pragma unroll
         for (int qx = 0; qx < 3; ++qx)
           {
-            ed[qx] = R[it * 3 + qx];
-            es[qx] = R[81 + it * 3 + qx];
+            ed[qx] = R[jl * Q27 + ckl * 3 + qx];
+            es[qx] = R[81 + jl * Q27 + ckl * 3 + qx];
           }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
