@@ -647,7 +647,9 @@ def main():
                       tm["assemble_residual"][1] / args.steps * res_bytes +
                       120 * G.n) / share
         out["config"]["smoother_operator"] = (
-            "matrix-free from the quadrature-point records of the assembly (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 2
+            "matrix-free from the quadrature-point records of its own 27-point rule, rewritten per tangent (%.2f GB per product)"
+            % (sm_bytes / 1e9) if form == 2 and sm_bytes != ebe_bytes
+            else "matrix-free from the quadrature-point records of the assembly (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 2
             else "unassembled symmetric element tangents (%.2f GB per product)" % (ebe_bytes / 1e9) if form == 1
             else "assembled sliced-ELL matrix")
         out["config"]["ms_smoother_fine_product"] = tm["spmv_precond"][0] / max(tm["spmv_precond"][1], 1)
