@@ -403,11 +403,12 @@ namespace mi_detail
         // ... unless the cells can be told apart by their layer (round 4: matrix-free, one launch, lattice ids): the cells that
         // touch no ghost plane of x -- all but the lowest layer (rank > 0) and the ghost layer (rank < size - 1) -- run as part 1
         // while the halo is in flight, the others as part 2; every cell still writes its own slots, so the sum is the same
-        // smoother quadrature 3: the smoother's products (never the CG's) from the 27-point records, two cells per wave
+        // smoother quadrature 3: the smoother's products (never the CG's) from the 27-point records, two cells per wave, in the
+        // same launches over layers
         const bool q27 = smoother && !ebe_for_cg && c->smoother_points == 3 && c->qrec27_valid && kind == 2 && c->mf_slots && c->d_mf_yc &&
                          !(c->smoother_precision == 32 && c->qrec32_valid); // (the opt-in fp32 smoother products keep the 64-point kernel)
         const bool mf_split = part != 0 && kind == 2 && c->mf_slots && c->d_mf_yc && c->lat.ncol > 0 && c->team->mf_overlap &&
-                              !(ebe_for_cg && !mf_all) && !q27; // (the 27-point kernel takes all cells after the exchange)
+                              !(ebe_for_cg && !mf_all);
         if (part == 1 && !mf_split)
           return;
         mi::EbeParams e{c->d_ke, c->d_conn, c->d_node_first, x, y};
@@ -475,8 +476,12 @@ namespace mi_detail
                   if (n > 0)
                     {
                       const int t = timed ? tic(c0, MI_T_EBE_LAUNCH, true) : -1;
-                      mi::launch_mf_spmv(g, 0, n, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
-                                         t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+                      if (q27)
+                        mi::launch_mf_spmv27(g, n, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                             t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
+                      else
+                        mi::launch_mf_spmv(g, 0, n, c->stream, t >= 0 ? c0->stamps[size_t(t)].a : nullptr,
+                                           t >= 0 ? c0->stamps[size_t(t)].b : nullptr);
                     }
                 };
                 const int nzl = c->mesh.reps[2];

@@ -3726,7 +3726,21 @@ namespace mi
     const int64_t pair = int64_t(blockIdx.x & 7) * prm.xcd_chunk + (blockIdx.x >> 3);
     if (pair * 2 >= prm.count)
       return;
-    const int64_t cell = pair * 2 + cw < prm.count ? pair * 2 + cw : int64_t(prm.count) - 1;
+    int64_t cell = pair * 2 + cw < prm.count ? pair * 2 + cw : int64_t(prm.count) - 1;
+    if constexpr (LAT)
+      if (prm.sel_n > 0) // a launch over some layers of a slab (as mf_spmv): `cell` counts the selected cells, colour by colour
+        {
+          const int32_t l = int32_t(cell);
+          int32_t       b = prm.sel_begin[0], p0 = prm.sel_pos0[0];
+#pragma unroll
+          for (int c = 1; c < 8; ++c)
+            if (l >= prm.sel_begin[c])
+              {
+                b  = prm.sel_begin[c];
+                p0 = prm.sel_pos0[c];
+              }
+          cell = int64_t(p0) + (l - b);
+        }
     constexpr bool act = true;
     double *const R = s_lds + cw * H27, *const X = R + 243;
     // gather x (constrained entries masked) and this lane's record

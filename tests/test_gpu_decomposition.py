@@ -210,11 +210,15 @@ def test_matrix_free_product_overlaps_its_halo_exchange_bitwise(reps, slabs, cut
         x = rng.standard_normal(G.n)
         G.set_tuning("spmv_variant", 4)  # the product itself through the same path
         y = G.spmv(x)
-        runs.append((rows, u, v, a, y))
+        G.set_tuning("spmv_as_smoother", 1)  # ... and the smoother's 27-point form of it (round 6; the V-cycles of the ramp ran it split)
+        assert G.get_tuning("smoother_quadrature_active") == 3
+        y27 = G.spmv(x)
+        runs.append((rows, u, v, a, y, y27))
         G.close()
     assert runs[0][0] == runs[1][0]
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 5):
         assert np.array_equal(runs[0][k], runs[1][k])
+    assert not np.array_equal(runs[0][4], runs[0][5])  # (two quadrature rules: equal only on an undeformed mesh)
 
 
 @pytest.mark.parametrize("reps,slabs", [((10, 10, 24), 1), ((10, 10, 24), 3), ((24, 24, 48), 2)])
