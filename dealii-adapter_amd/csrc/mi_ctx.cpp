@@ -440,6 +440,7 @@ namespace mi_detail
             f.dst       = c->d_mf_dst;
             f.slot_base = c->d_mf_slot_base;
             f.slot_src  = c->d_mf_src;
+            f.slot_inline = c->slots_layout == 1;
           }
         // profiling: every 6th product has its launches timed from the dispatch itself (kernel start / end as a
         // profiler reports them), class MI_T_EBE_LAUNCH
@@ -927,16 +928,40 @@ namespace mi_detail
         }
     // cell-major layout ("mf_slots_cell_major" 1): a cell stores its 81 results as one contiguous run, the gathers read a
     // node's contributions through slot_src (their positions, in processing order)
+    // line-major layout ("mf_slots_cell_major" 2, lattice meshes): within an x-row of a colour's cells (mx cells, consecutive
+    // positions) the slots are ordered [(k,j)][cell][i] instead of [cell][(k,j)][i] -- the contributions to ONE line of nodes
+    // from one row of cells are one contiguous run, in the order of the nodes (the last node of a cell next to the first of
+    // its neighbour): a line of nodes gathers from 2 x (1 | 2 | 4) such runs, every fetched line of memory is used by that
+    // line of nodes alone (cell-major: a 128-byte line holds pieces of two node lines, fetched through two XCDs' L2);
+    // the product stores 72-byte pieces, the pieces of consecutive cells next to each other
     std::vector<int32_t> src;
-    const bool cell_major = c->slots_cell_major >= 0 ? c->slots_cell_major != 0 : c->smoother_points == 3;
-    if (cell_major)
+    int layout = c->slots_cell_major >= 0 ? c->slots_cell_major : (c->smoother_points == 3 ? 1 : 0);
+    if (layout == 2 && !(c->lat.ncol > 0 && !c->lat_rows_host.empty()))
+      layout = 1;
+    c->slots_layout = layout;
+    if (layout)
       {
         src.resize(dst.size());
+        std::vector<int32_t> place(dst.size()); // slot of (cell, a)
         for (size_t k = 0; k < dst.size(); ++k)
-          src[size_t(dst[k])] = int32_t(k);
+          place[k] = int32_t(k);
+        if (layout == 2)
+          for (int col = 0; col < c->lat.ncol; ++col)
+            {
+              const mi::CellLatticeRow &R  = c->lat_rows_host[size_t(col)];
+              const int64_t             b0 = c->lat.begin[col], b1 = c->lat.begin[col + 1];
+              for (int64_t e = b0; e < b1; ++e)
+                {
+                  const int64_t r = e - b0, row = r / R.mx, rx = r - row * R.mx;
+                  for (int a = 0; a < 27; ++a)
+                    place[size_t(e) * 27 + a] = int32_t((b0 + row * R.mx) * 27 + int64_t(a / 3) * 3 * R.mx + rx * 3 + a % 3);
+                }
+            }
         for (size_t k = 0; k < dst.size(); ++k)
-          dst[k] = int32_t(k);
+          src[size_t(dst[k])] = place[k];
+        dst = place;
       }
+    const bool cell_major = layout != 0;
     int rc = upload(c, &c->d_mf_dst, dst);
     if (rc == MI_OK)
       rc = upload(c, &c->d_mf_slot_base, base);
@@ -2808,7 +2833,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
                          (k == "precond_storage" && value != 64) || (k == "solver_type" && value != 0) ||
                          (k == "spmv_variant" && value != 3 && value != 4) || (k == "element_tangents" && value != 2)))
         return fail(c, MI_EINVAL, "tuning '%s' %d needs the assembled fine level (\"fine_level\" 0)", k.c_str(), value);
-      if (k == "mf_slots_cell_major" && value >= -1 && value <= 1) // A/B: -1 follows the smoother's quadrature
+      if (k == "mf_slots_cell_major" && value >= -1 && value <= 2) // A/B: -1 follows the smoother's quadrature
         {
           m->slots_cell_major = value;
           if (m->d_mf_dst)

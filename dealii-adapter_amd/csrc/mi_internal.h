@@ -150,6 +150,7 @@ struct mi_ctx
   int32_t  *d_mf_dst = nullptr;       // ... their slots [ncells][27] ...
   int32_t  *d_mf_slot_base = nullptr; // ... and the first slot of every node [nnodes+1]
   int32_t  *d_mf_src = nullptr;       // cell-major slots: position of every contribution, node by node (MfParams::slot_src)
+  int       slots_layout = 0;         // what build_slot_tables made: 0 node-major, 1 cell-major, 2 line-major
   int       slots_cell_major = -1;    // -1: follows the smoother's quadrature (3: cell-major, 4: node-major: what each measured faster
                                       // with); 0 / 1: forced (tuning "mf_slots_cell_major", A/B)
   int       mf_slots = 1;             // tuning "mf_single_launch": 1 one launch + gather (default), 0 eight colour launches

@@ -124,6 +124,7 @@ namespace mi
     const int32_t  *slot_base; // [nnodes+1] first slot of every node (slots of a node in processing order of its cells)
     const int32_t  *slot_src;  // cell-major slots (dst[cell][a] = cell * 27 + a: a cell's 81 results are ONE contiguous run): position
                                // of the k-th contribution of a node, k in [slot_base[n], slot_base[n+1]); null: node-major (dst = k)
+    int32_t         slot_inline; // 1: dst[cell][a] = cell * 27 + a, no need to read it (0: another order of the slots behind slot_src)
     CellLattice     lat;       // node ids by arithmetic (ncol == 0: read conn)
     unsigned long long *stamps; // diagnostic (null in production): [cells][8] shader-clock stamps at the stage boundaries
     // slabs, lattice ids only: a launch over the cells of the layers [z_a, z_b) of the last lattice direction alone (the

@@ -3773,7 +3773,7 @@ namespace mi
         const int lkj = it - 9 * (it / 9);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-          ydst[i] = prm.slot_src ? int32_t(cell) * Q27 + lkj * 3 + i : prm.dst[cell * Q27 + lkj * 3 + i];
+          ydst[i] = prm.slot_inline ? int32_t(cell) * Q27 + lkj * 3 + i : prm.dst[cell * Q27 + lkj * 3 + i];
       }
     MF27_TABLES(prm.tab27)
     __syncthreads();

@@ -360,9 +360,10 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  from the point records (profiles/r06/asm_split_ab_n59.txt: slower)
  *  mg_fuse              1 | 0 | 2                  smoother update fused into the product on small levels | never |     MI_MG_FUSE
  *                                                  always
- *  mf_slots_cell_major  -1 | 0 | 1                 result slots of the matrix-free kernels: follows smoother_quadrature     -
+ *  mf_slots_cell_major  -1 | 0 | 1 | 2             result slots of the matrix-free kernels: follows smoother_quadrature     -
  *                                                  (3: cell-major, a cell's 81 results one contiguous run, the gathers read
- *                                                  through an index; 4: node-major) | forced (A/B)
+ *                                                  through an index; 4: node-major) | forced (A/B; 2: line-major within an
+ *                                                  x-row of cells, lattice meshes -- measured slower)
  *  spmv_as_smoother     0 | 1                      tests: mi_spmv / mi_bench_spmv apply the smoother's form of the operator -
  *  mg_scale_lmax_percent 10..400                   tests: spoil the eigenvalue estimates once                           -
  *
