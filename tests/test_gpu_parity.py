@@ -358,6 +358,15 @@ def test_smoother_quadrature_3_operator_and_solves(perturb_amp, slabs):
     G.set_tuning("spmv_as_smoother", 0)
     y4 = G.spmv(x)
     assert 1e-12 < _relmax(y3, y4) < 5e-3
+    # the layout of the kernels' result slots (node-major | cell-major, the default under the 27-point rule | line-major) is a
+    # permutation behind the gathers' index: the additions and their order are the same -- the same bits from either product
+    for lay in (0, 2, 1):
+        G.set_tuning("mf_slots_cell_major", lay)
+        assert np.array_equal(G.spmv(x), y4)
+        G.set_tuning("spmv_as_smoother", 1)
+        assert np.array_equal(G.spmv(x), y3)
+        G.set_tuning("spmv_as_smoother", 0)
+    G.set_tuning("mf_slots_cell_major", -1)
     # (3): the solves
     sols = {}
     for q in (4, 3):
