@@ -125,3 +125,34 @@ def test_launch_ranks_has_a_wall_clock_limit():
                           "--warmup", "0", "--cpu-cells", "0"], cwd=ROOT, capture_output=True, text=True, timeout=120, env=env)
     assert out.returncode == 124, (out.returncode, out.stderr[-500:])
     assert "did not finish within" in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+
+
+def test_committed_profile_agrees_with_its_bench_line():
+    """profiles/r06: the rocprofv3 --kernel-trace --stats summary and the bench line of the SAME process (bench.py under the
+    profiler) name the same average duration for the roofline's kernel and for the CG product -- the profiler times every
+    launch, the bench every 6th product from the dispatch's own events; and the driver-style line of that box is the one
+    the documents quote.  CPU test: it reads committed files only."""
+    import csv
+
+    P = os.path.join(ROOT, "profiles", "r06")
+    for tag, cg_kernel in (("headline", "mi::sell_spmv<3, true, true"), ("matrix_free_fine_level", "mi::mf_spmv<true, true, true")):
+        stats = {}
+        with open(os.path.join(P, "kernel_stats_bench_%s_n59.csv" % tag), newline="") as f:
+            for row in csv.DictReader(f):
+                stats[row["Name"]] = (int(row["Calls"]), float(row["AverageNs"]) * 1e-6)
+        line = json.load(open(os.path.join(P, "bench_under_rocprof_%s_n59.json" % tag)))
+        r = line["roofline"]
+        calls, avg_ms = next(v for k, v in stats.items() if "mi::mf_spmv27<true, true>" in k)
+        assert r["kernel"].startswith("mf_spmv27") and calls > 100
+        assert abs(r["avg_launch_ms"] - avg_ms) / avg_ms < 0.05, (tag, r["avg_launch_ms"], avg_ms)
+        calls, avg_ms = next(v for k, v in stats.items() if cg_kernel in k)
+        cg_ms = r["cg_product"]["avg_launch_ms"]
+        if tag == "matrix_free_fine_level":  # (the bench times the product with its gather; the trace lists the two kernels)
+            avg_ms += next(v for k, v in stats.items() if "mf_gather_dot" in k)[1]
+        assert abs(cg_ms - avg_ms) / avg_ms < 0.05, (tag, cg_ms, avg_ms)
+    plain = json.load(open(os.path.join(P, "bench_plain_same_box_n59.json")))
+    assert plain["metric"] == line["metric"] and plain["steps"] == 20 and plain["warmup"] == 5 and plain["n_gpus"] == 1
+    assert plain["roofline"]["traffic"] and 1.0 < plain["roofline"]["traffic_ratio_to_algorithmic"] < 1.5
+    assert plain["cpu_baseline"]["value"] > 0 and plain["config"]["with_matrix_free_fine_level"]["ms_per_step"] <= 90.0
+    readme = open(os.path.join(P, "README.md")).read()
+    assert "%.2f ms per step" % plain["ms_per_step"] in readme
