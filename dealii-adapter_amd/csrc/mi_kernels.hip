@@ -3707,7 +3707,15 @@ namespace mi
     for (int k = 0; k < 9; ++k)
       F[k] = gu[k];
     F[0] += 1.0, F[4] += 1.0, F[8] += 1.0;
-    const double J = det3x3(F), rJ = 1.0 / J, Jm = 1.0 / (cbrt(J) * cbrt(J));
+    double J = det3x3(F);
+    // (the assembly reports det F <= 0 at ITS 64 points, nonlinear_elasticity.cc:935; a point of this rule that folds where
+    // none of those does takes the undeformed state: the smoother's operator stays finite and positive definite)
+    const bool folded = !(J > 0.0);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      F[k] = folded ? (k % 4 == 0 ? 1.0 : 0.0) : F[k];
+    J = folded ? 1.0 : J;
+    const double rJ = 1.0 / J, Jm = 1.0 / (cbrt(J) * cbrt(J));
     double *__restrict__ g = rec27 + cell * int64_t(MF_NREC * Q27) + it;
 #pragma unroll
     for (int k = 0; k < 9; ++k)

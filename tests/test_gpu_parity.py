@@ -381,6 +381,44 @@ def test_smoother_quadrature_3_operator_and_solves(perturb_amp, slabs):
     assert _relmax(sols[3][0], sols[4][0]) < 1e-8 and abs(sols[3][1] - sols[4][1]) <= 1
 
 
+def test_smoother_quadrature_3_on_a_state_folded_between_the_assembly_points():
+    """the 27-point rule looks at other points than the assembly: u_x = -1.05 x M(eta), M = 4 eta (1 - eta) in every cell's
+    own eta along y, has det F = 1 - 1.05 M: 0.07 at the assembly's nearest Gauss points (eta = 0.33, 0.67), -0.05 at the
+    3-point rule's eta = 0.5.  The assembly accepts the state (no det F <= 0 where the reference asserts,
+    nonlinear_elasticity.cc:935); the smoother's records take the undeformed state at their folded points, so its operator
+    stays finite (no cube root or reciprocal of a negative volume ratio enters the preconditioner) and the linear solve ends
+    the way it does with the 64-point smoother (on THIS state the tangent itself is indefinite: no convergence either way)."""
+    reps = (3, 3, 3)
+    out = {}
+    for q in (3, 4):
+        G = M.Context(dim=3, degree=2, reps=reps)
+        G.set_tuning("precond", 1)
+        G.set_tuning("element_tangents", 2)
+        G.set_tuning("smoother_quadrature", q)
+        X = G.coords
+        eta = (X[:, 1] * reps[1]) % 1.0
+        u = np.zeros((G.nnodes, 3))
+        u[:, 0] = -1.05 * X[:, 0] * 4.0 * eta * (1.0 - eta)
+        G.set(M.V_U, u.reshape(-1) * ~G.constrained)
+        G.set_interface_traction((0.0, -2e3, 0.0))
+        G.newton_begin_step()
+        G.update_acceleration()
+        assert np.isfinite(G.assemble())
+        assert G.get_tuning("smoother_quadrature_active") == q
+        rng = np.random.default_rng(77)
+        G.set_tuning("spmv_as_smoother", 1)
+        for _ in range(4):
+            x = rng.standard_normal(G.n) * ~G.constrained
+            y = G.spmv(x)
+            assert np.all(np.isfinite(y)) and x @ y > 0.0
+        G.set_tuning("spmv_as_smoother", 0)
+        rc, its, res = G.cg_solve(1e-10, 4 * G.n)
+        assert np.isfinite(res) and np.all(np.isfinite(G.get(M.V_NEWTON)))
+        out[q] = rc
+        G.close()
+    assert out[3] == out[4]
+
+
 def test_fp32_smoother_records_follow_the_kernel_that_wrote_them():
     """only the sum-factorised kernel writes the fp32 point records; with the node-pair kernel ("asm_variant" 9)
     the opt-in fp32 smoother product must fall back to the fp64 records instead of multiplying with stale / uninitialised
