@@ -2799,16 +2799,27 @@ int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::vector<double> rot;
   x_host = to_internal_order(T, x_host, rot);
+  // tests, "spmv_as_smoother" 2: y = M^-1 x, one V-cycle of the multigrid hierarchy as the last linear solve left it
+  const bool vcycle = c->spmv_as_smoother == 2;
+  if (vcycle && (!c->mg || T.members[0]->precond != 1))
+    return fail(c, MI_EINVAL, "\"spmv_as_smoother\" 2 needs the multigrid preconditioner of a linear solve that has run");
+  const int w_in = vcycle ? W_R : W_P, w_out = vcycle ? W_Z : W_Q;
   for (mi_ctx *m : T.members)
-    HIPCHK(m, hipMemcpy(m->work(W_P), x_host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
+    HIPCHK(m, hipMemcpy(m->work(w_in), x_host + m->slab.node_offset * m->dim, size_t(m->n) * sizeof(double),
                         hipMemcpyHostToDevice));
-  for (mi_ctx *m : T.members)
-    enqueue_spmv(m, m->work(W_P), m->work(W_Q), nullptr, nullptr, nullptr, 0, m->spmv_as_smoother != 0);
+  if (vcycle)
+    {
+      if (int e = mg_apply(T))
+        return e;
+    }
+  else
+    for (mi_ctx *m : T.members)
+      enqueue_spmv(m, m->work(W_P), m->work(W_Q), nullptr, nullptr, nullptr, 0, m->spmv_as_smoother != 0);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (T.size == 1)
     {
-      HIPCHK(c, hipMemcpy(y_host, c->work(W_Q), size_t(c->n) * sizeof(double), hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy(y_host, c->work(w_out), size_t(c->n) * sizeof(double), hipMemcpyDeviceToHost));
       return MI_OK;
     }
   int rc = ensure_gbuf(T);
@@ -2816,7 +2827,7 @@ int mi_spmv(mi_ctx *c, const double *x_host, double *y_host)
     return rc;
   HIPCHK(c, hipMemsetAsync(T.d_gbuf, 0, size_t(T.n_global) * sizeof(double), T.stream));
   for (mi_ctx *m : T.members)
-    HIPCHK(m, hipMemcpyAsync(T.d_gbuf + (m->slab.node_offset + m->slab.own_begin) * m->dim, m->work(W_Q) + m->own0,
+    HIPCHK(m, hipMemcpyAsync(T.d_gbuf + (m->slab.node_offset + m->slab.own_begin) * m->dim, m->work(w_out) + m->own0,
                              size_t(m->own_n) * sizeof(double), hipMemcpyDeviceToDevice, T.stream));
   if ((rc = team_allreduce_buffer(T, T.d_gbuf, size_t(T.n_global))))
     return rc;
@@ -2845,7 +2856,7 @@ int mi_set_tuning(mi_ctx *c, const char *key, int value)
             }
           continue;
         }
-      if (k == "spmv_as_smoother" && (value == 0 || value == 1)) // tests: mi_spmv through the smoother's form of the operator
+      if (k == "spmv_as_smoother" && value >= 0 && value <= 2) // tests: mi_spmv through the smoother's form of the operator (2: the V-cycle)
         {
           m->spmv_as_smoother = value;
           continue;

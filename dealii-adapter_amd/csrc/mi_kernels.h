@@ -305,6 +305,7 @@ namespace mi
   void launch_sell_build_cols(const SellParams &p, const int32_t *rowptr, const int32_t *bsr_col, int32_t *sell_col,
                               hipStream_t s);
   void launch_dot_partials(const double *a, const double *b, int64_t n, double *part, int grid, hipStream_t s);
+  void launch_finish_sum(const double *part, int n, double *out, hipStream_t s); // out[0] = sum of part[0..n)
   void launch_cheb4_start(double *x, double *d, double *r, const double *b, const double *q, const double *dinv,
                           double s0, int64_t n, hipStream_t s);
   void launch_cheb4_step(double *x, double *d, double *r, const double *q, const double *dinv, double beta, double ca,

@@ -7045,6 +7045,10 @@ namespace mi
       hipLaunchKernelGGL((masked_norm_partials<2>), dim3(grid), dim3(256), 0, s, v, cmask, n, part);
     hipLaunchKernelGGL(finish_sum, dim3(1), dim3(256), 0, s, part, grid, out);
   }
+  void launch_finish_sum(const double *part, int n, double *out, hipStream_t s)
+  {
+    hipLaunchKernelGGL(finish_sum, dim3(1), dim3(256), 0, s, part, n, out);
+  }
   void launch_reduce_to_totals(const double *pa, int na, double *oa, const double *pb, int nb, double *ob,
                                const int32_t *done, hipStream_t s)
   {

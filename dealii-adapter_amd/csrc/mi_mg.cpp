@@ -39,6 +39,8 @@ namespace mi_detail
     bool    x_swapped = false; // the fused smoother step writes x' = x + d into the other of the two x buffers
     bool    ev_ready = false;
     double  lmax = 0.0;     // estimate of the largest eigenvalue of D^-1 A
+    double  lam_power = 0.0, lam_boost = 1.0; // the power iteration's last value; what the Krylov estimate of the first
+                                              // estimate added to it (estimate_lmax)
     double *dense_inv = nullptr; // coarsest level, n <= 96: the inverse of the level matrix (exact coarse solve in one launch)
     MgTransfer to_coarse;   // to level l+1
     // level 0 works on the CG's own vectors: its right-hand side IS the residual W_R (only owned entries are ever read)
@@ -85,6 +87,7 @@ namespace mi_detail
     int    coarsen_factor = 2;   // cells per direction shrink by this factor from level to level
     double coarse_ratio  = 60.0;
     int    power_its     = 15;   // first estimate
+    int    krylov_its    = 40;   // ... and the steps of its Krylov companion (krylov_lmax)
     int    power_its_update = 2; // refresh, continuing from the previous eigenvector (4 change nothing, 2.5 ms per step)
     double lmax_safety   = 1.15;
   };
@@ -325,6 +328,135 @@ namespace mi_detail
       return rc;
     }
 
+    // largest eigenvalue of the symmetric tridiagonal matrix (diag, off): bisection on the Sturm count below the Gershgorin bound
+    double tridiag_max_eig(const std::vector<double> &dg, const std::vector<double> &of)
+    {
+      const size_t m = dg.size();
+      if (m == 0)
+        return 0.0;
+      double lo = dg[0], hi = dg[0];
+      for (size_t i = 0; i < m; ++i)
+        {
+          const double rad = (i ? std::fabs(of[i - 1]) : 0.0) + (i + 1 < m ? std::fabs(of[i]) : 0.0);
+          lo               = std::min(lo, dg[i] - rad);
+          hi               = std::max(hi, dg[i] + rad);
+        }
+      for (int it = 0; it < 200 && hi - lo > 1e-13 * std::max(1.0, std::fabs(hi)); ++it)
+        {
+          const double x = 0.5 * (lo + hi);
+          size_t       below = 0; // eigenvalues < x = negative pivots of T - x I
+          double       d = 1.0;
+          for (size_t i = 0; i < m; ++i)
+            {
+              d = dg[i] - x - (i ? of[i - 1] * of[i - 1] / d : 0.0);
+              if (d == 0.0)
+                d = 1e-300;
+              below += d < 0.0;
+            }
+          (below == m ? hi : lo) = x;
+        }
+      return 0.5 * (lo + hi);
+    }
+
+    // Krylov estimate of lambda_max(D^-1 A) on level l: `steps` iterations of the conjugate-gradient recurrence for A with
+    // D^-1 as its preconditioner from the start vector in ev(); their coefficients are the Lanczos tridiagonal matrix of
+    // D^-1/2 A D^-1/2, whose largest eigenvalue (a Ritz value: never above lambda_max) closes in on the top of the spectrum
+    // in a few dozen products where the power iteration can rest on a plateau for as many (a start vector holds next to
+    // nothing of eigenvectors that live in the corners of the mesh).  Uses the level's r, d, q and second x buffers.
+    int krylov_lmax(Team &T, size_t l, int steps, double *ritz_max)
+    {
+      mi_ctx    *c0   = T.members[0];
+      Multigrid &mg0  = *c0->mg;
+      const bool dist = is_dist(T, l);
+      int        rc;
+      auto vec_r = [l](mi_ctx *m) { return m->mg->levels[l].r(); };
+      auto vec_p = [l](mi_ctx *m) { MgLevel &L = m->mg->levels[l]; return L.ws + 6 * L.ctx->n; };
+      auto precondition = [&]() { // z (in d) = D^-1 r
+        for (mi_ctx *m : T.members)
+          {
+            MgLevel &L = m->mg->levels[l];
+            mi_ctx  *c = L.ctx;
+            if (mg0.block)
+              mi::launch_blk_apply(c->dim, L.d(), L.r(), c->d_dinv_blk, c->mesh.nnodes, c->stream);
+            else
+              mi::launch_vec_scale_mul(L.d(), L.r(), c->work(W_DINV), 1.0, c->n, c->stream);
+          }
+      };
+      auto dot = [&](const std::function<double *(mi_ctx *)> &a, const std::function<double *(mi_ctx *)> &b, double *out) -> int {
+        for (mi_ctx *m : T.members)
+          {
+            mi_ctx *c = m->mg->levels[l].ctx;
+            mi::launch_dot_partials(a(m) + c->own0, b(m) + c->own0, c->own_n, m->part(5), m->grid_vec, c->stream);
+            mi::launch_finish_sum(m->part(5), m->grid_vec, m->d_sc + 14, c->stream);
+          }
+        int e;
+        if (dist && (e = team_allreduce(T, 14, 1)))
+          return e;
+        HIPCHK(c0, hipMemcpyAsync(c0->h_pinned, c0->d_sc + 14, sizeof(double), hipMemcpyDeviceToHost, c0->stream));
+        HIPCHK(c0, hipStreamSynchronize(c0->stream));
+        *out = c0->h_pinned[0];
+        return MI_OK;
+      };
+      auto vec_z = [l](mi_ctx *m) { return m->mg->levels[l].d(); };
+      auto vec_q = [l](mi_ctx *m) { return m->mg->levels[l].q(); };
+      for (mi_ctx *m : T.members) // r = the start vector, p = z = D^-1 r
+        {
+          MgLevel &L = m->mg->levels[l];
+          HIPCHK(m, hipMemcpyAsync(L.r(), L.ev(), size_t(L.ctx->n) * sizeof(double), hipMemcpyDeviceToDevice, L.ctx->stream));
+        }
+      precondition();
+      for (mi_ctx *m : T.members)
+        {
+          MgLevel &L = m->mg->levels[l];
+          HIPCHK(m, hipMemcpyAsync(vec_p(m), L.d(), size_t(L.ctx->n) * sizeof(double), hipMemcpyDeviceToDevice, L.ctx->stream));
+        }
+      double rz = 0.0;
+      if ((rc = dot(vec_r, vec_z, &rz)))
+        return rc;
+      std::vector<double> dg, of;
+      double              alpha_prev = 0.0, beta_prev = 0.0;
+      *ritz_max = 0.0;
+      for (int it = 0; it < steps && rz > 0.0 && std::isfinite(rz); ++it)
+        {
+          if ((rc = level_spmv(T, l, vec_p))) // q = A p (the ghost planes of p are exchanged on distributed levels)
+            return rc;
+          double pq = 0.0;
+          if ((rc = dot(vec_p, vec_q, &pq)))
+            return rc;
+          if (!(pq > 0.0) || !std::isfinite(pq))
+            break;
+          const double alpha = rz / pq;
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel &L = m->mg->levels[l];
+              mi::launch_vec_lincomb2(L.r(), 1.0, L.r(), -alpha, L.q(), L.ctx->n, L.ctx->stream); // r -= alpha q
+            }
+          precondition();
+          double rz_new = 0.0;
+          if ((rc = dot(vec_r, vec_z, &rz_new)))
+            return rc;
+          dg.push_back(1.0 / alpha + (it ? beta_prev / alpha_prev : 0.0));
+          if (it)
+            of.push_back(std::sqrt(beta_prev) / alpha_prev);
+          const double beta = rz_new / rz;
+          if (!(beta >= 0.0) || !std::isfinite(beta))
+            break;
+          for (mi_ctx *m : T.members)
+            {
+              MgLevel &L = m->mg->levels[l];
+              mi::launch_vec_lincomb2(vec_p(m), 1.0, L.d(), beta, vec_p(m), L.ctx->n, L.ctx->stream); // p = z + beta p
+            }
+          alpha_prev = alpha, beta_prev = beta, rz = rz_new;
+          if (rz_new <= 1e-28 * std::fabs(dg[0])) // the Krylov space is exhausted (tiny levels)
+            break;
+        }
+      if (of.size() + 1 > dg.size() && !dg.empty())
+        of.resize(dg.size() - 1);
+      *ritz_max = tridiag_max_eig(dg, of);
+      HIPCHK(c0, hipGetLastError());
+      return MI_OK;
+    }
+
     // power iteration for lambda_max(D^-1 A); level 0 is distributed over the team, the others are replicated
     int estimate_lmax(Team &T, size_t l)
     {
@@ -362,8 +494,19 @@ namespace mi_detail
       // above it -- the preconditioned CG then crawls (found in round 2 on the 120^3 mesh).  Refreshes continue from
       // the previous eigenvector with power_its_update iterations.
       const bool first = its < 0;
+      double     ritz  = 0.0;
       if (first)
-        its = 300;
+        {
+          its = 300;
+          // (round 6) the first estimate also asks the Krylov space of the same start vector: the power iteration below can
+          // settle on a plateau under lambda_max -- 2.57 against 3.13 on a 32 x 32 x 28 mesh cut into two slabs, found by a
+          // sweep over random meshes: a Chebyshev interval that ends below lambda_max makes the V-cycle indefinite, the PCG
+          // took 46-136 instead of 11 iterations
+          if ((rc = krylov_lmax(T, l, mg0.krylov_its, &ritz)))
+            return rc;
+          if (mi::exp_env("MI_MG_VERBOSE"))
+            fprintf(stderr, "mg level %d Krylov estimate: %.6f\n", int(l), ritz);
+        }
       double prev = 0.0;
       int    calm = 0;
       for (int it = 0; it < its; ++it)
@@ -413,8 +556,18 @@ namespace mi_detail
             }
         }
       HIPCHK(c0, hipGetLastError());
+      // what the Krylov estimate added to the power iteration's value is kept over the refreshes (two iterations from the
+      // previous eigenvector each) and given back as the power iteration climbs
+      MgLevel     &Lc    = c0->mg->levels[l];
+      const double boost = first ? std::max(1.0, lam > 0.0 ? ritz / lam : 1.0) :
+                                   std::max(1.0, lam > 0.0 ? Lc.lam_boost * Lc.lam_power / lam : 1.0);
       for (mi_ctx *m : T.members)
-        m->mg->levels[l].lmax = lam * mg0.lmax_safety;
+        {
+          MgLevel &L  = m->mg->levels[l];
+          L.lam_power = lam;
+          L.lam_boost = boost;
+          L.lmax      = lam * boost * mg0.lmax_safety;
+        }
       return MI_OK;
     }
   } // namespace
