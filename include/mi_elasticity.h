@@ -364,7 +364,8 @@ int mi_set_profiling(mi_ctx *ctx, int enable);
  *                                                  (3: cell-major, a cell's 81 results one contiguous run, the gathers read
  *                                                  through an index; 4: node-major) | forced (A/B; 2: line-major within an
  *                                                  x-row of cells, lattice meshes -- measured slower)
- *  spmv_as_smoother     0 | 1                      tests: mi_spmv / mi_bench_spmv apply the smoother's form of the operator -
+ *  spmv_as_smoother     0 | 1 | 2                  tests: mi_spmv / mi_bench_spmv apply the smoother's form of the operator -
+ *                                                  | 2: mi_spmv applies M^-1, one V-cycle of the last solve's hierarchy
  *  mg_scale_lmax_percent 10..400                   tests: spoil the eigenvalue estimates once                           -
  *
  * Further switches of the experiments build only (read at creation; diagnostics): MI_MG_NU, MI_MG_NU_COARSE, MI_MG_RATIO, MI_MG_KIND,
