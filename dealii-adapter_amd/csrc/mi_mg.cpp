@@ -556,11 +556,12 @@ namespace mi_detail
             }
         }
       HIPCHK(c0, hipGetLastError());
-      // what the Krylov estimate added to the power iteration's value is kept over the refreshes (two iterations from the
-      // previous eigenvector each) and given back as the power iteration climbs
+      // what the Krylov estimate added to the power iteration's value is kept, as a factor, over the refreshes (two iterations
+      // from the previous eigenvector each).  It is never given back: a power estimate that grows between two refreshes may
+      // have left its plateau or may follow a tangent that stiffens -- the two cannot be told apart, and an interval a
+      // little too long costs an iteration where one too short costs the positive definiteness of the cycle
       MgLevel     &Lc    = c0->mg->levels[l];
-      const double boost = first ? std::max(1.0, lam > 0.0 ? ritz / lam : 1.0) :
-                                   std::max(1.0, lam > 0.0 ? Lc.lam_boost * Lc.lam_power / lam : 1.0);
+      const double boost = first ? std::max(1.0, lam > 0.0 ? ritz / lam : 1.0) : std::max(1.0, Lc.lam_boost);
       for (mi_ctx *m : T.members)
         {
           MgLevel &L  = m->mg->levels[l];
