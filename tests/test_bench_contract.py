@@ -156,3 +156,13 @@ def test_committed_profile_agrees_with_its_bench_line():
     assert plain["cpu_baseline"]["value"] > 0 and plain["config"]["with_matrix_free_fine_level"]["ms_per_step"] <= 90.0
     readme = open(os.path.join(P, "README.md")).read()
     assert "%.2f ms per step" % plain["ms_per_step"] in readme
+
+
+def test_profile_digest_reads_the_committed_set():
+    """tools/r6_profile_digest.py prints the numbers profiles/r06/README.md quotes from the committed files (CPU test)"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "r6_profile_digest.py")], cwd=ROOT, capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    plain = json.load(open(os.path.join(ROOT, "profiles", "r06", "bench_plain_same_box_n59.json")))
+    assert ("headline: %.2f ms per step" % plain["ms_per_step"]) in out.stdout
+    assert "with_matrix_free_fine_level" in out.stdout and "emulated slabs" in out.stdout and "rank_share_n59.txt" in out.stdout
